@@ -1,0 +1,480 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+A plain CPU restatement (torch-CPU fp32 for the floating-point conv graph, numpy for the integer/index work)
+of the reference's CPN inference path.  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import this module, and only as the checker / reported baseline -- the product
+(``celldetection_amd``) never imports it and fails loudly when its HIP library is missing.
+
+Pinning: the reference's own tests hold NO golden vectors for this path, so the oracle is
+pinned against outputs of the reference itself, generated in the build container by
+``tests/golden/make_golden.py`` (committed, with the ``.npz`` fixtures in ``tests/golden/``) and checked by
+``tests/test_oracle_golden.py``.  The third-party pieces the reference calls but does not contain
+(torchvision ``nms`` / FPN forward / ResNet block forward) are restated from their published semantics and are
+"unpinned by the reference repository" (SURVEY.md section 8c).
+
+Every function cites the reference file:line (relative to /root/reference) it follows.
+"""
+import ctypes
+import os
+import subprocess
+from collections import OrderedDict
+from itertools import product
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+# =====================================================================================================
+# 1. conv graph (floating point; torch CPU fp32, unfused conv -> BN -> ReLU exactly like the reference)
+# =====================================================================================================
+
+def _bn(x, sd, p):
+    """nn.BatchNorm2d eval (running stats, eps 1e-5): lookup_nn('batchnorm2d'), models/commons.py:143-148."""
+    return F.batch_norm(x, sd[p + 'running_mean'], sd[p + 'running_var'], sd[p + 'weight'], sd[p + 'bias'],
+                        False, 0., 1e-5)
+
+
+def _conv(x, sd, p, stride=1, padding=0, groups=1):
+    return F.conv2d(x, sd[p + 'weight'], sd.get(p + 'bias'), stride, padding, 1, groups)
+
+
+def _two_conv_norm_relu(x, sd, p):
+    """TwoConvNormRelu: conv3x3-BN-ReLU x2, models/commons.py:120-149 (Sequential idx 0,1,2,3,4,5)."""
+    x = F.relu(_bn(_conv(x, sd, p + '0.', padding=1), sd, p + '1.'))
+    return F.relu(_bn(_conv(x, sd, p + '3.', padding=1), sd, p + '4.'))
+
+
+def _has(sd, prefix):
+    return any(k.startswith(prefix) for k in sd)
+
+
+def _unet_encoder(x, sd, p):
+    """UNetEncoder (U22 body): models/unet.py:29-58; block i>0 = Sequential(MaxPool2d(2,2), TwoConvNormRelu)."""
+    feats = OrderedDict()
+    i = 0
+    while _has(sd, f'{p}{i}.'):
+        if i == 0:
+            x = _two_conv_norm_relu(x, sd, f'{p}0.')
+        else:
+            x = F.max_pool2d(x, 2, 2)
+            x = _two_conv_norm_relu(x, sd, f'{p}{i}.1.')
+        feats[str(i)] = x
+        i += 1
+    return feats
+
+
+def _res_block(x, sd, p, stride):
+    """torchvision BasicBlock / Bottleneck forward as used by models/resnet.py:56-116 (stride on conv1 for
+    BasicBlock, on the 3x3 conv2 for Bottleneck; groups from the conv2 weight shape)."""
+    identity = x
+    if (p + 'conv3.weight') in sd:  # Bottleneck
+        w2 = sd[p + 'conv2.weight']
+        groups = w2.shape[0] // w2.shape[1] if w2.shape[1] != w2.shape[0] else 1
+        groups = sd[p + 'conv1.weight'].shape[0] // w2.shape[1]
+        out = F.relu(_bn(_conv(x, sd, p + 'conv1.'), sd, p + 'bn1.'))
+        out = F.relu(_bn(_conv(out, sd, p + 'conv2.', stride=stride, padding=w2.shape[-1] // 2, groups=groups),
+                         sd, p + 'bn2.'))
+        out = _bn(_conv(out, sd, p + 'conv3.'), sd, p + 'bn3.')
+    else:  # BasicBlock
+        k = sd[p + 'conv1.weight'].shape[-1]
+        out = F.relu(_bn(_conv(x, sd, p + 'conv1.', stride=stride, padding=k // 2), sd, p + 'bn1.'))
+        out = _bn(_conv(out, sd, p + 'conv2.', padding=1), sd, p + 'bn2.')
+    if (p + 'downsample.0.weight') in sd:
+        identity = _bn(_conv(x, sd, p + 'downsample.0.', stride=stride), sd, p + 'downsample.1.')
+    out = out + identity
+    return F.relu(out)
+
+
+def _resnet_body(x, sd, p):
+    """ResNet with fused_initial=False (models/resnet.py:265-297, unet.py:584-587): children
+    0 = Sequential(conv7x7 s2, BN, ReLU); 1 = Sequential(MaxPool(3,2,1), layer1); 2..4 = layer2..4."""
+    feats = OrderedDict()
+    x = F.relu(_bn(_conv(x, sd, p + '0.0.', stride=2, padding=3), sd, p + '0.1.'))
+    feats['0'] = x
+    x = F.max_pool2d(x, 3, 2, 1)
+    stage = 1
+    while _has(sd, f'{p}{stage}.'):
+        sp = f'{p}{stage}.1.' if stage == 1 else f'{p}{stage}.'
+        j = 0
+        while _has(sd, f'{sp}{j}.'):
+            x = _res_block(x, sd, f'{sp}{j}.', stride=2 if (j == 0 and stage > 1) else 1)
+            j += 1
+        feats[str(stage)] = x
+        stage += 1
+    return feats
+
+
+def _generalized_unet(feats, sd, p, bridges):
+    """GeneralizedUNet.forward, models/unet.py:178-249 (nearest upsample -> inner 1x1 -> cat(lateral, top_down)
+    -> layer block; bridge levels have no lateral and upsample by scale_factor 2)."""
+    x = list(feats.values())
+    depth = 0
+    while _has(sd, f'{p}layer_blocks.{depth}.'):
+        depth += 1
+    last_inner = x[-1]
+    results = [last_inner]
+    for i in range(depth - 1, -1, -1):
+        has_lat = (i - bridges) >= 0
+        lateral = x[i - bridges] if has_lat else None
+        if lateral is not None:
+            top = F.interpolate(last_inner, size=lateral.shape[2:], mode='nearest')
+        else:
+            top = F.interpolate(last_inner, scale_factor=2, mode='nearest')
+        ip = f'{p}inner_blocks.{i}.'  # inner_blocks[i] belongs to loop index i+1 in __init__ (unet.py:118-128)
+        if (ip + 'weight') in sd:
+            top = _conv(top, sd, ip)
+        inp = torch.cat((lateral, top), 1) if lateral is not None else top
+        last_inner = _two_conv_norm_relu(inp, sd, f'{p}layer_blocks.{i}.')
+        results.insert(0, last_inner)
+    return OrderedDict((str(i), r) for i, r in enumerate(results))
+
+
+def _fpn(feats, sd, p):
+    """torchvision FeaturePyramidNetwork.forward with celldetection ConvNorm(norm=Identity) blocks
+    (models/fpn.py:79-134): inner 1x1 (bias), top-down nearest + add, 3x3 layer conv (bias)."""
+    x = list(feats.values())
+    n = len(x)
+    last_inner = _conv(x[-1], sd, f'{p}inner_blocks.{n - 1}.0.')
+    results = [_conv(last_inner, sd, f'{p}layer_blocks.{n - 1}.0.', padding=1)]
+    for idx in range(n - 2, -1, -1):
+        lat = _conv(x[idx], sd, f'{p}inner_blocks.{idx}.0.')
+        top = F.interpolate(last_inner, size=lat.shape[-2:], mode='nearest')
+        last_inner = lat + top
+        results.insert(0, _conv(last_inner, sd, f'{p}layer_blocks.{idx}.0.', padding=1))
+    return OrderedDict((str(i), r) for i, r in enumerate(results))
+
+
+def _readout(x, sd, p):
+    """ReadOut: conv kxk (bias, pad k//2) -> BN -> ReLU -> Dropout(eval: id) -> conv1x1, commons.py:461-511."""
+    k = sd[p + 'block.0.weight'].shape[-1]
+    x = F.relu(_bn(_conv(x, sd, p + 'block.0.', padding=k // 2), sd, p + 'block.1.'))
+    return _conv(x, sd, p + 'block.4.')
+
+
+def core_forward(state_dict, x, refinement_margin=3.):
+    """CPNCore.forward, models/cpn.py:238-283 -> (raw scores, locations, refinement, fourier), all fp32 NCHW.
+
+    The backbone family is recognised from the state-dict keys (``unet.`` vs ``fpn.``; ``body.0.0.weight`` 7x7 =>
+    ResNet stem, otherwise UNetEncoder)."""
+    sd = {k: (v.float() if v.is_floating_point() else v) for k, v in state_dict.items()}
+    x = x.float()
+    # Normalize(mean 0, std 1, assert_range (0,1)): models/commons.py:694-700
+    assert bool(torch.all(x >= 0.)) and bool(torch.all(x <= 1.)), 'Inputs should be in interval (0.0, 1.0)'
+    p = 'core.backbone.'
+    with torch.no_grad():
+        if sd[p + 'body.0.0.weight'].shape[-1] == 7:
+            feats = _resnet_body(x, sd, p + 'body.')
+            bridges = 1
+        else:
+            feats = _unet_encoder(x, sd, p + 'body.')
+            bridges = 0
+        if _has(sd, p + 'unet.'):
+            feats = _generalized_unet(feats, sd, p + 'unet.', bridges)
+        else:
+            feats = _fpn(feats, sd, p + 'fpn.')
+        f1, f0 = feats['1'], feats['0']
+        scores = _readout(f1, sd, 'core.score_head.')
+        locations = _readout(f1, sd, 'core.location_head.')
+        fourier = _readout(f1, sd, 'core.fourier_head.')
+        if f0.shape[2:] != x.shape[2:]:  # cpn.py:277-278
+            f0 = F.interpolate(f0, x.shape[2:], mode='bilinear', align_corners=False)
+        refinement = torch.tanh(_readout(f0, sd, 'core.refinement_head.')) * refinement_margin
+        if refinement.shape[2:] != x.shape[2:]:
+            refinement = F.interpolate(refinement, x.shape[2:], mode='bilinear', align_corners=False)
+    return scores, locations, refinement, fourier
+
+
+# =====================================================================================================
+# 2. decode (numpy; index work bit-exact, float work in IEEE fp32 with the reference's operation order)
+# =====================================================================================================
+
+def sampling_table(order, samples):
+    """sin/cos table of ops/cpn.py:66-78: t = linspace(0,1,S); c = float(pi)*2*k*t (fp32); cos/sin via torch CPU
+    so that the bits equal the reference's CPU result."""
+    t = torch.linspace(0, 1.0, samples)
+    c = float(np.pi) * 2 * (torch.arange(1, order + 1)[..., None]) * t[None]
+    return torch.cos(c).numpy(), torch.sin(c).numpy()
+
+
+def fouriers2contours(fourier, locations, samples):
+    """ops/cpn.py:44-95: con = loc; con += sum_k(f[k,(1,3)]*sin_k); con += sum_k(f[k,(0,2)]*cos_k)
+    (fp32 products, sum over k in ascending order)."""
+    fourier = np.asarray(fourier, np.float32)
+    locations = np.asarray(locations, np.float32)
+    order = fourier.shape[-2]
+    c_cos, c_sin = sampling_table(order, samples)
+    con = np.zeros(fourier.shape[:-2] + (samples, 2), np.float32) + locations[..., None, :]
+    for cols, tab in (((1, 3), c_sin), ((0, 2), c_cos)):
+        acc = None
+        for k in range(order):
+            term = fourier[..., k, :][..., None, list(cols)] * tab[k][:, None]  # [..., S, 2]
+            acc = term if acc is None else acc + term
+        con = con + acc
+    return con.astype(np.float32)
+
+
+def local_refinement(contours, refinement, b, iterations, size):
+    """models/cpn.py:63-85 (buckets == 1): round-half-even, clamp, gather refinement[b,:,y,x], add."""
+    h, w = size
+    c = np.asarray(contours, np.float32).copy()
+    all_c = []
+    for _ in range(iterations):
+        c = np.rint(c)
+        c[..., 0] = np.clip(c[..., 0], 0, w - 1)
+        c[..., 1] = np.clip(c[..., 1], 0, h - 1)
+        idx = c.astype(np.int64)
+        resp = refinement[b[:, None], :, idx[:, :, 1], idx[:, :, 0]]  # [P, S, 2]
+        c = (c + resp).astype(np.float32)
+        all_c.append(c)
+    return c, all_c
+
+
+def nms_numpy(boxes, scores, thr):
+    """torchvision CPU nms semantics (third-party; restated, unpinned): stable descending score order, greedy,
+    suppress iff inter/(a_i+a_j-inter) > thr (NaN => keep)."""
+    boxes = np.asarray(boxes, np.float32)
+    scores = np.asarray(scores, np.float32)
+    n = len(boxes)
+    if n == 0:
+        return np.zeros((0,), np.int64)
+    order = np.argsort(-scores.astype(np.float64), kind='stable')  # negation is exact; stable => ties in index order
+    x1, y1, x2, y2 = boxes.T
+    areas = (x2 - x1) * (y2 - y1)
+    suppressed = np.zeros(n, bool)
+    keep = []
+    thr = np.float32(thr)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        for _i in range(n):
+            i = order[_i]
+            if suppressed[i]:
+                continue
+            keep.append(i)
+            rest = order[_i + 1:]
+            w = np.maximum(np.float32(0), np.minimum(x2[i], x2[rest]) - np.maximum(x1[i], x1[rest]))
+            h = np.maximum(np.float32(0), np.minimum(y2[i], y2[rest]) - np.maximum(y1[i], y1[rest]))
+            inter = w * h
+            ovr = inter / (areas[i] + areas[rest] - inter)
+            suppressed[rest[ovr > thr]] = True
+    return np.asarray(keep, np.int64)
+
+
+_NMS_C = None
+
+
+def _nms_c_lib():
+    """Compile/load oracle/nms_oracle.c (plain C restatement of the same greedy NMS)."""
+    global _NMS_C
+    if _NMS_C is None:
+        so = os.path.join(_HERE, 'libnms_oracle.so')
+        src = os.path.join(_HERE, 'nms_oracle.c')
+        if not os.path.isfile(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(['gcc', '-O2', '-ffp-contract=off', '-shared', '-fPIC', src, '-o', so])
+        lib = ctypes.CDLL(so)
+        lib.nms_oracle.restype = ctypes.c_long
+        lib.nms_oracle.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_float, ctypes.c_void_p]
+        _NMS_C = lib
+    return _NMS_C
+
+
+def nms(boxes, scores, thr):
+    """Greedy NMS through the C oracle (falls back to numpy when gcc is unavailable)."""
+    boxes = np.ascontiguousarray(boxes, np.float32)
+    scores = np.ascontiguousarray(scores, np.float32)
+    n = len(boxes)
+    if n == 0:
+        return np.zeros((0,), np.int64)
+    try:
+        lib = _nms_c_lib()
+    except Exception:
+        return nms_numpy(boxes, scores, thr)
+    order = np.ascontiguousarray(np.argsort(-scores.astype(np.float64), kind='stable').astype(np.int64))
+    keep = np.empty(n, np.int64)
+    k = lib.nms_oracle(boxes.ctypes.data, order.ctypes.data, n, ctypes.c_float(thr), keep.ctypes.data)
+    return keep[:k].copy()
+
+
+def batched_box_nmsi(boxes, scores, thr, batch_size=50000):
+    """ops/cpn.py:189-227 incl. the chunked (> batch_size boxes) path + final NMS."""
+    keeps = []
+    for con, sco in zip(boxes, scores):
+        n = len(con)
+        if n <= batch_size:
+            idx = nms(con, sco, thr)
+        else:
+            idx = np.zeros((0,), np.int64)
+            for s in range(0, n, batch_size):
+                e = min(s + batch_size, n)
+                idx = np.concatenate((idx, nms(con[s:e], sco[s:e], thr) + s))
+            if len(idx):
+                idx = idx[nms(con[idx], sco[idx], thr)]
+        keeps.append(idx)
+    return keeps
+
+
+def _resize_bilinear(x, size):
+    return F.interpolate(torch.as_tensor(x), size, mode='bilinear', align_corners=False).numpy()
+
+
+def cpn_postprocess(scores_raw, locations, refinement, fourier, *, input_size, order=None, samples=32,
+                    score_thresh=.9, nms_thresh=.2, refinement_iterations=4, nms=True, offsets=None,
+                    scores_lower_bound=None, scores_upper_bound=None, scores_are_probabilities=False):
+    """CPN.forward after the core, models/cpn.py:575-734 (binary classes path, eval mode).
+
+    Args are fp32 NCHW numpy arrays (or tensors).  Returns an OrderedDict of per-image lists like the reference.
+    """
+    to_np = lambda t: t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+    scores_raw, locations, refinement, fourier = map(to_np, (scores_raw, locations, refinement, fourier))
+    H, W = input_size
+    n, c, h, w = fourier.shape
+    if scores_are_probabilities:
+        scores = scores_raw.astype(np.float32)
+    else:
+        scores = torch.sigmoid(torch.as_tensor(scores_raw)).numpy()  # cpn.py:578
+    if scores_upper_bound is not None:  # cpn.py:118-123
+        ub = to_np(scores_upper_bound).astype(np.float32)
+        if ub.shape[2:] != scores.shape[2:]:
+            ub = _resize_bilinear(ub, scores.shape[2:])
+        scores = np.minimum(scores, ub)
+    if scores_lower_bound is not None:
+        lb = to_np(scores_lower_bound).astype(np.float32)
+        if lb.shape[2:] != scores.shape[2:]:
+            lb = _resize_bilinear(lb, scores.shape[2:])
+        scores = np.maximum(scores, lb)
+    classes = (scores > np.float32(score_thresh)).astype(np.int64)[:, 0]  # cpn.py:579
+    fourier = fourier.reshape(n, c // 4, 4, h, w)  # cpn.py:594
+    if order is not None and order < c // 4:
+        fourier = fourier[:, :order]  # cpn.py:597-598
+    # rel_location2abs_location, ops/cpn.py:15-41
+    gx = np.arange(w, dtype=np.float32)[None] + np.zeros((h, 1), np.float32)
+    gy = np.zeros((1, w), np.float32) + np.arange(h, dtype=np.float32)[:, None]
+    locations = locations + np.stack((gx, gy), 0)
+    b, y, x = np.where(classes > 0)  # row-major (b, y, x) order, cpn.py:620
+    sel_fourier = fourier[b, :, :, y, x].astype(np.float32)  # [P, O, 4]
+    sel_loc = locations[b, :, y, x].astype(np.float32)  # [P, 2]
+    sel_classes = classes[b, y, x]
+    sel_scores = scores[b, 0, y, x]
+    proposals = fouriers2contours(sel_fourier, sel_loc, samples)
+    scale = np.array([W / w, H / h], np.float32)  # get_scale flip -> (x, y), ops/cpn.py:98-103
+    proposals = proposals * scale
+    sel_fourier = sel_fourier.copy()
+    sel_fourier[..., [0, 1]] = sel_fourier[..., [0, 1]] * scale[0]
+    sel_fourier[..., [2, 3]] = sel_fourier[..., [2, 3]] * scale[1]
+    sel_loc = sel_loc * scale
+    if refinement is not None and refinement_iterations > 0:
+        contours, _ = local_refinement(proposals, refinement, b, refinement_iterations, (H, W))
+    else:
+        contours = proposals.copy()
+    contours[..., 0] = np.clip(contours[..., 0], 0, W - 1)  # cpn.py:661-663 (also clamps the proposals when
+    contours[..., 1] = np.clip(contours[..., 1], 0, H - 1)  # no refinement is applied: same tensor object)
+    if refinement is None or refinement_iterations <= 0:
+        proposals = contours
+    if len(contours):
+        boxes = np.concatenate((contours.min(1), contours.max(1)), 1)
+    else:
+        boxes = np.zeros((0, 4), np.float32)
+    if offsets is not None:  # cpn.py:695-702
+        offs = to_np(offsets)[b]
+        contours = contours + offs[:, None].astype(np.float32)
+        if proposals is not contours:
+            proposals = proposals + offs[:, None].astype(np.float32)
+        else:
+            proposals = contours
+        boxes = boxes + np.tile(offs, (1, 2)).astype(np.float32)
+        sel_loc = sel_loc + offs.astype(np.float32)
+    flat = OrderedDict(contours=contours.astype(np.float32), boxes=boxes.astype(np.float32), scores=sel_scores,
+                       classes=sel_classes, locations=sel_loc.astype(np.float32), fourier=sel_fourier,
+                       contour_proposals=proposals.astype(np.float32))
+    out = OrderedDict((k, [v[b == i] for i in range(n)]) for k, v in flat.items())  # cpn.py:42-50
+    if nms:
+        keeps = batched_box_nmsi(out['boxes'], out['scores'], nms_thresh)
+        out = OrderedDict((k, [v[i][keeps[i]] for i in range(n)]) for k, v in out.items())  # cpn.py:53-60
+    out['box_uncertainties'] = None
+    return out
+
+
+def cpn_forward(state_dict, x, **kw):
+    """Full eval-mode CPN.forward (core + post-processing) on CPU."""
+    s, l, r, f = core_forward(state_dict, x, refinement_margin=kw.pop('refinement_margin', 3.))
+    return cpn_postprocess(s, l, r, f, input_size=tuple(x.shape[-2:]), **kw)
+
+
+# =====================================================================================================
+# 3. tiling / stitching (integer work)
+# =====================================================================================================
+
+def get_tiling_slices(size, crop_size, strides):
+    """util/util.py:1305-1354 -> (list of per-tile ((h0,h1),(w0,w1)), list of per-tile overlaps, tiles per axis)."""
+    nd = len(size)
+    crop_size = (crop_size,) * nd if np.isscalar(crop_size) else tuple(crop_size)
+    strides = (strides,) * nd if np.isscalar(strides) else tuple(strides)
+    slices, shape, overlaps = [], [], []
+    for ax in range(nd):
+        if crop_size[ax] >= size[ax]:
+            tl = [size[ax]]
+        else:
+            tl = list(range(crop_size[ax], 1 + crop_size[ax] + int(np.ceil((size[ax] - crop_size[ax]) / strides[ax]))
+                            * strides[ax], strides[ax]))
+        stops = np.minimum(tl, size[ax])
+        starts = np.maximum(0, stops - crop_size[ax])
+        ov_start = np.concatenate((starts[:1], stops[:-1])) - starts
+        ov_end = np.concatenate((ov_start[1:], [0]))
+        slices.append([(int(a), int(b_)) for a, b_ in zip(starts, stops)])
+        overlaps.append([(int(a), int(b_)) for a, b_ in zip(ov_start, ov_end)])
+        shape.append(len(starts))
+    return list(product(*slices)), list(product(*overlaps)), shape
+
+
+def remove_border_contours(contours, size, padding=1, top=True, right=True, bottom=True, left=True, offsets=None):
+    """ops/cpn.py:258-290."""
+    h, w = size[:2]
+    c = np.asarray(contours, np.float32)
+    if offsets is not None:
+        c = c + np.asarray(offsets, np.float32)
+    x, y = c[..., 0], c[..., 1]
+    keep = np.ones(len(c), bool)
+    if top:
+        keep &= (y > padding).all(1)
+    if right:
+        keep &= (x < (w - padding)).all(1)
+    if bottom:
+        keep &= (y < (h - padding)).all(1)
+    if left:
+        keep &= (x > padding).all(1)
+    return keep
+
+
+def filter_contours_by_stitching_rule(contours, tile_size, overlaps, offsets=None):
+    """ops/cpn.py:293-325, rule 'ex_br'."""
+    c = np.asarray(contours, np.float32)
+    if offsets is not None:
+        c = c + np.asarray(offsets, np.float32)
+    stop = (np.asarray(tile_size) - np.asarray(overlaps)[:, 1])[[1, 0]]
+    right_bottom = (c >= stop).any(-1).all(-1)
+    return ~right_bottom
+
+
+def tiled_inference(state_dict, img, crop_size, strides, border_removal=4, **kw):
+    """celldetection_scripts/cpn_inference.py:336-408 (single model, stitching_rule='nms'):
+    tiles -> CPN.forward(offsets) -> remove_border_contours -> concat -> one global NMS."""
+    nms_thresh = kw.get('nms_thresh', .2)
+    H, W = img.shape[-2:]
+    slices, overlaps, shape = get_tiling_slices((H, W), crop_size, strides)
+    h_tiles, w_tiles = shape
+    coll = {}
+    keys = ('contours', 'boxes', 'scores', 'classes', 'locations', 'fourier', 'contour_proposals')
+    for idx, ((h0, h1), (w0, w1)) in enumerate(slices):
+        tile = img[..., h0:h1, w0:w1]
+        offs = np.array([[w0, h0]], np.int64)
+        y = cpn_forward(state_dict, tile, offsets=offs, **kw)
+        h_i, w_i = np.unravel_index(idx, shape)
+        keep = remove_border_contours(y['contours'][0], (h1 - h0, w1 - w0), border_removal, top=h_i > 0,
+                                      right=w_i < w_tiles - 1, bottom=h_i < h_tiles - 1, left=w_i > 0,
+                                      offsets=-offs[0])
+        for k in keys:
+            v = y[k][0][keep]
+            coll[k] = np.concatenate((coll[k], v)) if k in coll else v
+    keep = nms(coll['boxes'], coll['scores'], nms_thresh)
+    return OrderedDict((k, v[keep]) for k, v in coll.items()), len(coll['scores'])

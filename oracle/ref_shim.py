@@ -1,0 +1,410 @@
+"""TEST INFRASTRUCTURE ONLY -- build-container helper, never shipped, never imported by the product.
+
+Makes the read-only Python reference at /root/reference importable in the build container, which lacks
+torchvision / pytorch_lightning / cv2 / h5py / ....  Used exclusively by
+``tests/golden/make_golden.py`` to emit golden input/output vectors; the reference itself never travels
+to the GPU box and nothing in ``celldetection_amd`` imports this file.
+
+Two kinds of stand-ins are installed into ``sys.modules`` *before* ``import celldetection``:
+
+* permissive empty modules for packages whose symbols are only *named* on the CPN inference path
+  (cv2, h5py, pynvml, skimage, albumentations, timm, ...);
+* small *functional* stand-ins, written from the public documented behaviour of the third-party symbol,
+  for the few third-party functions with arithmetic or structural meaning on the path
+  (torchvision ``nms``/``IntermediateLayerGetter``/``FeaturePyramidNetwork.forward``/resnet block forwards/
+  ``transforms.Normalize``; pytorch_lightning ``HyperparametersMixin``).
+
+Vectors that flow through the functional stand-ins (NMS keep order, FPN top-down add, residual block
+forward) are therefore pinned by THIS restatement of third-party behaviour, not by the reference repository;
+DESIGN.md lists them as "third-party, unpinned by reference tests".
+"""
+import importlib.abc
+import importlib.machinery
+import sys
+import types
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+REFERENCE_ROOT = '/root/reference'
+
+_STUB_ROOTS = ('torchvision', 'pytorch_lightning', 'lightning_fabric', 'cv2', 'h5py', 'pynvml', 'skimage',
+               'albumentations', 'tifffile', 'seaborn', 'timm', 'segmentation_models_pytorch', 'imageio',
+               'mpi4py', 'tensorboard', 'pytiff', 'matplotlib', 'PIL', 'pandas_stub_never')
+
+
+class _AnyMeta(type):
+    """Metaclass: unknown class-level attributes of a stub class are again stub classes."""
+
+    def __getattr__(cls, item):
+        if item.startswith('__') and item.endswith('__'):
+            raise AttributeError(item)
+        return _AnyMeta(item, (_Anything,), {})
+
+    def __iter__(cls):
+        return iter(())
+
+
+class _Anything(metaclass=_AnyMeta):
+    """Class returned for any attribute of a permissive stub module (usable as base class / decorator)."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        if len(a) == 1 and callable(a[0]) and not k:
+            return a[0]
+        return _Anything()
+
+    def __getattr__(self, item):
+        if item.startswith('__') and item.endswith('__'):
+            raise AttributeError(item)
+        return _Anything()
+
+    def __iter__(self):
+        return iter(())
+
+
+class _StubModule(types.ModuleType):
+    __path__ = []
+    __all__ = []
+
+    def __getattr__(self, item):
+        if item.startswith('__') and item.endswith('__'):
+            raise AttributeError(item)
+        cls = _AnyMeta(item, (_Anything,), {'__module__': self.__name__})
+        setattr(self, item, cls)
+        return cls
+
+
+class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, fullname, path=None, target=None):
+        root = fullname.split('.')[0]
+        if root in _STUB_ROOTS and fullname not in sys.modules:
+            return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        return _StubModule(spec.name)
+
+    def exec_module(self, module):
+        pass
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# functional stand-ins (own restatement of documented third-party behaviour)
+# ----------------------------------------------------------------------------------------------------------------
+
+class HyperparametersMixin:
+    """pytorch_lightning.core.mixins.HyperparametersMixin: records ctor kwargs in ``hparams``."""
+
+    def save_hyperparameters(self, *args, ignore=None, frame=None, logger=True):
+        import inspect
+        if not hasattr(self, '_hparams'):
+            self._hparams = {}
+            self._hparams_initial = {}
+        self._log_hyperparams = False
+        fr = inspect.currentframe().f_back
+        try:
+            info = inspect.getargvalues(fr)
+            loc = info.locals
+            names = [a for a in info.args if a != 'self']
+            hp = {n: loc[n] for n in names if n in loc}
+            if info.keywords and info.keywords in loc:
+                hp.update(loc[info.keywords])
+            if ignore:
+                ignore = [ignore] if isinstance(ignore, str) else ignore
+                hp = {k: v for k, v in hp.items() if k not in ignore}
+            hp.pop('__class__', None)
+            self._hparams.update(hp)
+            self._hparams_initial.update(hp)
+        finally:
+            del fr
+
+    def _set_hparams(self, hp):
+        self._hparams = dict(hp)
+
+    @property
+    def hparams(self):
+        if not hasattr(self, '_hparams'):
+            self._hparams = {}
+            self._hparams_initial = {}
+        return self._hparams
+
+    @property
+    def hparams_initial(self):
+        if not hasattr(self, '_hparams_initial'):
+            self._hparams_initial = {}
+        return self._hparams_initial
+
+
+class IntermediateLayerGetter(nn.ModuleDict):
+    """torchvision.models._utils.IntermediateLayerGetter: run children in order, collect named outputs."""
+
+    def __init__(self, model, return_layers):
+        orig = dict(return_layers)
+        return_layers = {str(k): str(v) for k, v in return_layers.items()}
+        layers = OrderedDict()
+        for name, module in model.named_children():
+            layers[name] = module
+            if name in return_layers:
+                del return_layers[name]
+            if not return_layers:
+                break
+        super().__init__(layers)
+        self.return_layers = {str(k): str(v) for k, v in orig.items()}
+
+    def forward(self, x):
+        out = OrderedDict()
+        for name, module in self.items():
+            x = module(x)
+            if name in self.return_layers:
+                out[self.return_layers[name]] = x
+        return out
+
+
+class ExtraFPNBlock(nn.Module):
+    pass
+
+
+class TvFeaturePyramidNetwork(nn.Module):
+    """torchvision.ops.feature_pyramid_network.FeaturePyramidNetwork (forward: top-down nearest + add)."""
+
+    def __init__(self, in_channels_list, out_channels, extra_blocks=None, norm_layer=None):
+        super().__init__()
+        self.inner_blocks = nn.ModuleList()
+        self.layer_blocks = nn.ModuleList()
+        self.extra_blocks = extra_blocks
+
+    def get_result_from_inner_blocks(self, x, idx):
+        n = len(self.inner_blocks)
+        if idx < 0:
+            idx += n
+        return self.inner_blocks[idx](x)
+
+    def get_result_from_layer_blocks(self, x, idx):
+        n = len(self.layer_blocks)
+        if idx < 0:
+            idx += n
+        return self.layer_blocks[idx](x)
+
+    def forward(self, x):
+        names = list(x.keys())
+        x = list(x.values())
+        last_inner = self.get_result_from_inner_blocks(x[-1], -1)
+        results = [self.get_result_from_layer_blocks(last_inner, -1)]
+        for idx in range(len(x) - 2, -1, -1):
+            inner_lateral = self.get_result_from_inner_blocks(x[idx], idx)
+            feat_shape = inner_lateral.shape[-2:]
+            inner_top_down = F.interpolate(last_inner, size=feat_shape, mode='nearest')
+            last_inner = inner_lateral + inner_top_down
+            results.insert(0, self.get_result_from_layer_blocks(last_inner, idx))
+        if self.extra_blocks is not None:
+            results, names = self.extra_blocks(results, x, names)
+        return OrderedDict([(k, v) for k, v in zip(names, results)])
+
+
+class TvBackboneWithFPN(nn.Module):
+    pass
+
+
+class TvBasicBlock:
+    expansion = 1
+
+    def forward(self, x):
+        identity = x
+        out = self.conv1(x)
+        out = self.bn1(out)
+        out = self.relu(out)
+        out = self.conv2(out)
+        out = self.bn2(out)
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        out += identity
+        out = self.relu(out)
+        return out
+
+
+class TvBottleneck:
+    expansion = 4
+
+    def forward(self, x):
+        identity = x
+        out = self.conv1(x)
+        out = self.bn1(out)
+        out = self.relu(out)
+        out = self.conv2(out)
+        out = self.bn2(out)
+        out = self.relu(out)
+        out = self.conv3(out)
+        out = self.bn3(out)
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        out += identity
+        out = self.relu(out)
+        return out
+
+
+class TvNormalize(nn.Module):
+    def __init__(self, mean, std, inplace=False):
+        super().__init__()
+        self.mean, self.std = mean, std
+
+    def forward(self, x):
+        mean = torch.as_tensor(self.mean, dtype=x.dtype, device=x.device)
+        std = torch.as_tensor(self.std, dtype=x.dtype, device=x.device)
+        if mean.ndim == 1:
+            mean = mean.view(-1, 1, 1)
+        if std.ndim == 1:
+            std = std.view(-1, 1, 1)
+        return (x.clone() - mean) / std
+
+
+class TvCompose:
+    def __init__(self, transforms):
+        self.transforms = transforms
+
+    def __call__(self, x):
+        for t in self.transforms:
+            x = t(x)
+        return x
+
+
+def _upcast(t):
+    if t.is_floating_point():
+        return t if t.dtype in (torch.float32, torch.float64) else t.float()
+    return t if t.dtype in (torch.int32, torch.int64) else t.int()
+
+
+def box_area(boxes):
+    boxes = _upcast(boxes)
+    return (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+
+
+def box_iou(boxes1, boxes2):
+    area1 = box_area(boxes1)
+    area2 = box_area(boxes2)
+    lt = torch.max(boxes1[:, None, :2], boxes2[:, :2])
+    rb = torch.min(boxes1[:, None, 2:], boxes2[:, 2:])
+    wh = _upcast(rb - lt).clamp(min=0)
+    inter = wh[:, :, 0] * wh[:, :, 1]
+    union = area1[:, None] + area2 - inter
+    return inter / union
+
+
+def nms_cpu(dets, scores, iou_threshold):
+    """Restatement of torchvision's public CPU NMS kernel (csrc/ops/cpu/nms_kernel.cpp semantics):
+    areas=(x2-x1)*(y2-y1); order = scores.sort(descending, stable); greedy; suppress j when
+    inter/(area_i+area_j-inter) > thr (NaN compares false); returns kept original indices in that order."""
+    import numpy as np
+    if dets.numel() == 0:
+        return torch.empty((0,), dtype=torch.long)
+    d = dets.detach().cpu().float().numpy()
+    s = scores.detach().cpu().float()
+    order = torch.sort(s, stable=True, descending=True).indices.numpy()
+    x1, y1, x2, y2 = d[:, 0], d[:, 1], d[:, 2], d[:, 3]
+    areas = (x2 - x1) * (y2 - y1)
+    n = d.shape[0]
+    suppressed = np.zeros(n, dtype=bool)
+    keep = []
+    thr = np.float32(iou_threshold)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        for _i in range(n):
+            i = order[_i]
+            if suppressed[i]:
+                continue
+            keep.append(i)
+            rest = order[_i + 1:]
+            xx1 = np.maximum(x1[i], x1[rest])
+            yy1 = np.maximum(y1[i], y1[rest])
+            xx2 = np.minimum(x2[i], x2[rest])
+            yy2 = np.minimum(y2[i], y2[rest])
+            w = np.maximum(np.float32(0), xx2 - xx1)
+            h = np.maximum(np.float32(0), yy2 - yy1)
+            inter = w * h
+            ovr = inter / (areas[i] + areas[rest] - inter)
+            suppressed[rest[ovr > thr]] = True
+    return torch.as_tensor(np.asarray(keep, dtype='int64'))
+
+
+def remove_small_boxes(boxes, min_size):
+    ws, hs = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
+    keep = (ws >= min_size) & (hs >= min_size)
+    return torch.where(keep)[0]
+
+
+_INSTALLED = False
+
+
+def install():
+    """Install stubs + functional stand-ins and put the reference on sys.path. Idempotent."""
+    global _INSTALLED
+    if _INSTALLED:
+        return
+    sys.dont_write_bytecode = True
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    finder = _StubFinder()
+    sys.meta_path.insert(0, finder)
+
+    def mod(name):
+        m = _StubModule(name)
+        sys.modules[name] = m
+        parent, _, child = name.rpartition('.')
+        if parent and parent in sys.modules:
+            setattr(sys.modules[parent], child, m)
+        return m
+
+    # pytorch_lightning
+    pl = mod('pytorch_lightning')
+    mod('pytorch_lightning.core')
+    mix = mod('pytorch_lightning.core.mixins')
+    mix.HyperparametersMixin = HyperparametersMixin
+    pl.LightningModule = type('LightningModule', (nn.Module, HyperparametersMixin), {})
+    pl.Callback = object
+    lf = mod('lightning_fabric')
+    mod('lightning_fabric.utilities')
+    rz = mod('lightning_fabric.utilities.rank_zero')
+    rz.rank_zero_only = lambda f: f
+
+    # torchvision
+    mod('torchvision')
+    mod('torchvision.models')
+    u = mod('torchvision.models._utils')
+    u.IntermediateLayerGetter = IntermediateLayerGetter
+    r = mod('torchvision.models.resnet')
+    r.BasicBlock = TvBasicBlock
+    r.Bottleneck = TvBottleneck
+    mod('torchvision.models.detection')
+    bu = mod('torchvision.models.detection.backbone_utils')
+    bu.BackboneWithFPN = TvBackboneWithFPN
+    mod('torchvision.ops')
+    fp = mod('torchvision.ops.feature_pyramid_network')
+    fp.FeaturePyramidNetwork = TvFeaturePyramidNetwork
+    fp.ExtraFPNBlock = ExtraFPNBlock
+    bx = mod('torchvision.ops.boxes')
+    bx.box_area, bx.box_iou, bx._upcast, bx.nms, bx.remove_small_boxes = \
+        box_area, box_iou, _upcast, nms_cpu, remove_small_boxes
+    sys.modules['torchvision.ops'].nms = nms_cpu
+    sys.modules['torchvision.ops'].boxes = bx
+    tr = mod('torchvision.transforms')
+    tr.Normalize = TvNormalize
+    tr.Compose = TvCompose
+
+    # dispatcher op torch.ops.torchvision.nms
+    try:
+        lib = torch.library.Library('torchvision', 'DEF')
+        lib.define('nms(Tensor dets, Tensor scores, float iou_threshold) -> Tensor')
+        lib.impl('nms', nms_cpu, 'CPU')
+        install._lib = lib
+    except Exception as e:  # already defined
+        print('torchvision::nms define failed:', e)
+    _INSTALLED = True
+
+
+def import_reference():
+    install()
+    import celldetection as cd
+    return cd

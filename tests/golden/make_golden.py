@@ -1,0 +1,256 @@
+"""Golden-vector generator (BUILD CONTAINER ONLY; needs /root/reference, which never travels).
+
+Imports the read-only Python reference (celldetection 0.4.9) through ``oracle/ref_shim.py`` and writes small
+``.npz`` fixtures (inputs + expected outputs, nothing of the reference's source) next to this file:
+
+* ``ops.npz``      G1-G5: fouriers2contours / local_refinement / rel_location2abs_location / scale_* /
+                   NMS (+chunked ``batched_box_nmsi``) / remove_border_contours / stitching rule
+* ``tiling.npz``   G6: ``get_tiling_slices`` tables
+* ``model_<name>.npz`` G7: tiny-model end-to-end: synthetic weights are re-creatable from (seed, key names)
+                   via ``celldetection_amd.synth``; the file holds the 8 calibrated head tensors, the input,
+                   the five ``CPNCore`` maps and the full ``CPN.forward`` outputs (nms on/off, offsets, bounds)
+* ``stitch.npz``   G8: multi-tile stitch (TileLoader offsets/overlaps -> border removal -> global NMS)
+
+Run:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+sys.path.insert(0, ROOT)
+warnings.filterwarnings('ignore')
+
+import ref_shim  # noqa: E402
+
+cd = ref_shim.import_reference()
+from celldetection.models.cpn import local_refinement  # noqa: E402
+from celldetection.ops import cpn as rops  # noqa: E402
+from celldetection_amd.synth import synth_state_dict, calibrate_heads  # noqa: E402
+
+torch.set_num_threads(4)
+
+MODEL_SPECS = {
+    # name: (class, kwargs, input shape)
+    'CpnU22': ('CpnU22', dict(in_channels=3, backbone_kwargs={'backbone_kwargs': {'base_channels': 8}}),
+               (2, 3, 64, 96)),
+    'CpnResNeXt101UNet': ('CpnResNeXt101UNet',
+                          dict(in_channels=3, backbone_kwargs={'backbone_kwargs': {'base_channel': 8}}),
+                          (2, 3, 64, 96)),
+    'CpnResNet18FPN': ('CpnResNet18FPN', dict(in_channels=3, backbone_kwargs={
+        'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}), (2, 3, 64, 96)),
+    'CpnResNet50FPN': ('CpnResNet50FPN', dict(in_channels=3, backbone_kwargs={
+        'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}), (1, 3, 96, 64)),
+    'CpnResNet50UNet': ('CpnResNet50UNet',
+                        dict(in_channels=3, backbone_kwargs={'backbone_kwargs': {'base_channel': 8}}),
+                        (1, 3, 64, 64)),
+    # wider variant whose channel counts are MFMA-friendly (multiples of 32), samples/order changed
+    'CpnU22_wide': ('CpnU22', dict(in_channels=3, order=7, samples=48, score_thresh=.8, nms_thresh=.3,
+                                   backbone_kwargs={'backbone_kwargs': {'base_channels': 32}}),
+                    (1, 3, 96, 128)),
+}
+
+
+def npy(t):
+    if isinstance(t, (list, tuple)):
+        return [npy(i) for i in t]
+    if isinstance(t, torch.Tensor):
+        return t.detach().cpu().numpy()
+    return np.asarray(t)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f'{name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(arrays)} arrays')
+
+
+# ------------------------------------------------------------------------------------------------------------
+def gen_ops():
+    g = torch.Generator().manual_seed(1234)
+    out = {}
+    # G1 fouriers2contours
+    for tag, (p, o, s) in {'a': (37, 5, 32), 'b': (5, 8, 128), 'c': (3, 1, 7), 'd': (11, 12, 64)}.items():
+        f = torch.randn(p, o, 4, generator=g) * 3
+        loc = torch.rand(p, 2, generator=g) * 200
+        con, sampling = rops.fouriers2contours(f, loc, samples=s)
+        out[f'f2c_{tag}_fourier'], out[f'f2c_{tag}_loc'], out[f'f2c_{tag}_out'] = npy(f), npy(loc), npy(con)
+    # G2 local_refinement (buckets=1): includes .5 coordinates, out-of-range, negative
+    n, h, w = 2, 24, 40
+    refinement = (torch.rand(n, 2, h, w, generator=g) * 2 - 1) * 3
+    con = torch.rand(9, 16, 2, generator=g) * torch.tensor([w + 8., h + 8.]) - 4
+    con[0, :8] = torch.floor(con[0, :8]) + .5  # exact halves -> round-half-even
+    con[1, :4] = torch.tensor([[-.5, .5], [1.5, 2.5], [w - .5, h - .5], [w + 3., -7.]])
+    b = torch.tensor([0, 1, 1, 0, 0, 1, 0, 1, 1])
+    for iters in (1, 4):
+        res, all_res = local_refinement(con.clone(), refinement, num_loops=iters, num_buckets=1,
+                                        original_size=(h, w), sampling=None, b=b)
+        out[f'refine_out_{iters}'] = npy(res)
+        if iters == 4:
+            out['refine_all'] = np.stack(npy(all_res))
+    out['refine_in'], out['refine_map'], out['refine_b'] = npy(con), npy(refinement), npy(b)
+    # G3 locations / scaling
+    loc = torch.randn(2, 2, 5, 7, generator=g)
+    out['rel2abs_in'], out['rel2abs_out'] = npy(loc), npy(rops.rel_location2abs_location(loc))
+    c = torch.randn(6, 9, 2, generator=g) * 10
+    out['scale_con_in'] = npy(c)
+    out['scale_con_out'] = npy(rops.scale_contours((24, 40), (96, 120), c))
+    f, l = torch.randn(6, 5, 4, generator=g), torch.randn(6, 2, generator=g)
+    out['scale_f_in'], out['scale_l_in'] = npy(f), npy(l)
+    fo, lo = rops.scale_fourier((24, 40), (96, 120), f.clone(), l.clone())
+    out['scale_f_out'], out['scale_l_out'] = npy(fo), npy(lo)
+    # G4 NMS (third-party torchvision semantics as restated in oracle/ref_shim.py -> "unpinned")
+    m = 700
+    xy = torch.rand(m, 2, generator=g) * 100
+    wh = torch.rand(m, 2, generator=g) * 30
+    boxes = torch.cat((xy, xy + wh), 1)
+    boxes[5] = boxes[4]  # duplicates
+    boxes[10, 2:] = boxes[10, :2]  # zero area
+    boxes[11] = boxes[10]  # identical zero-area boxes -> NaN IoU
+    scores = torch.rand(m, generator=g)
+    scores[20:40] = scores[20]  # ties
+    scores[4] = scores[5]
+    out['nms_boxes'], out['nms_scores'] = npy(boxes), npy(scores)
+    for thr in (.2, .5, 0.):
+        out[f'nms_keep_{thr}'] = npy(torch.ops.torchvision.nms(boxes, scores, thr))
+    out['nmsi_chunked_keep'] = npy(rops.batched_box_nmsi([boxes], [scores], .2, batch_size=128)[0])
+    out['nmsi_plain_keep'] = npy(rops.batched_box_nmsi([boxes, boxes[:50]], [scores, scores[:50]], .2)[1])
+    # G5 border removal / stitching rule
+    con = torch.rand(40, 12, 2, generator=g) * torch.tensor([64., 48.])
+    offsets = torch.tensor([-3., 5.])
+    for i, flags in enumerate([(True, True, True, True), (False, True, False, True), (True, False, True, False)]):
+        top, right, bottom, left = flags
+        out[f'border_keep_{i}'] = npy(rops.remove_border_contours(con, (48, 64), 4, top=top, right=right,
+                                                                  bottom=bottom, left=left, offsets=offsets))
+    out['border_in'], out['border_offsets'] = npy(con), npy(offsets)
+    overlaps = torch.tensor([[8, 12], [0, 16]])
+    out['stitch_overlaps'] = npy(overlaps)
+    out['stitch_keep'] = npy(rops.filter_contours_by_stitching_rule(con, (48, 64), overlaps, rule='ex_br',
+                                                                    offsets=offsets))
+    save('ops.npz', **out)
+
+
+def gen_tiling():
+    out = {}
+    cases = {'a': ((16384, 16384), 512, 384), 'b': ((16384, 16384), 512, 512), 'c': ((16384, 16384), 1024, 768),
+             'd': ((1000, 700), 512, 384), 'e': ((300, 300), 512, 384), 'f': ((1025, 513), (512, 256), (500, 200))}
+    for tag, (size, crop, stride) in cases.items():
+        slices, overlaps, shape = cd.get_tiling_slices(size, crop, stride, return_overlaps=True)
+        sl = np.array([[[s.start, s.stop] for s in item] for item in slices], dtype=np.int64)
+        ov = np.array([[list(o) for o in item] for item in overlaps], dtype=np.int64)
+        out[f'{tag}_size'] = np.array(size)
+        out[f'{tag}_crop'] = np.array(crop if isinstance(crop, tuple) else (crop, crop))
+        out[f'{tag}_stride'] = np.array(stride if isinstance(stride, tuple) else (stride, stride))
+        out[f'{tag}_slices'], out[f'{tag}_overlaps'], out[f'{tag}_shape'] = sl, ov, np.array(shape)
+    save('tiling.npz', **out)
+
+
+def build_ref_model(name, seed=0, **cal_kw):
+    cls, kwargs, shape = MODEL_SPECS[name]
+    model = getattr(cd.models, cls)(**kwargs).eval()
+    sd = synth_state_dict(model.state_dict(), seed=seed)
+    x_cal = torch.rand(*shape, generator=torch.Generator().manual_seed(99))
+
+    def core_fn(sd_):
+        model.load_state_dict(sd_)
+        with torch.no_grad():
+            s, l, r, f, _ = model.core(x_cal)
+        return s, l, r, f
+
+    sd, overrides = calibrate_heads(sd, core_fn, **cal_kw)
+    model.load_state_dict(sd)
+    return model, overrides, shape
+
+
+def flat_outputs(prefix, y, out):
+    for k, v in y.items():
+        if v is None:
+            continue
+        for i, t in enumerate(v):
+            out[f'{prefix}.{k}.{i}'] = npy(t)
+
+
+def gen_model(name, seed=0):
+    model, overrides, shape = build_ref_model(name, seed)
+    out = {f'override.{k}': npy(v) for k, v in overrides.items()}
+    out['seed'] = np.array(seed)
+    tmpl = model.state_dict()
+    out['sd_keys'] = np.array(list(tmpl.keys()))
+    out['sd_shapes'] = np.array([','.join(str(int(d)) for d in v.shape) for v in tmpl.values()])
+    x = torch.rand(*shape, generator=torch.Generator().manual_seed(7))
+    out['x'] = npy(x)
+    with torch.no_grad():
+        s, l, r, f, _ = model.core(x)
+        out['core.scores'], out['core.locations'], out['core.refinement'], out['core.fourier'] = \
+            npy(s), npy(l), npy(r), npy(f)
+        flat_outputs('nms', model(x), out)
+        flat_outputs('nonms', model(x, nms=False), out)
+        offsets = torch.tensor([[100, 200], [-5, 7]][:shape[0]])
+        out['offsets'] = npy(offsets)
+        flat_outputs('offs', model(x, offsets=offsets.clone()), out)
+        g = torch.Generator().manual_seed(3)
+        ub = (torch.rand(shape[0], 1, shape[2] // 4, shape[3] // 4, generator=g) > .3).float()
+        lb = (torch.rand(shape[0], 1, shape[2] // 8, shape[3] // 8, generator=g) > .97).float()
+        out['scores_upper_bound'], out['scores_lower_bound'] = npy(ub), npy(lb)
+        flat_outputs('bounds', model(x, scores_upper_bound=ub, scores_lower_bound=lb), out)
+        if name == 'CpnU22':  # run-time attribute changes (config/flags)
+            model.samples, model.refinement_iterations, model.score_thresh, model.nms_thresh = 17, 2, .7, .5
+            flat_outputs('attr', model(x), out)
+            model.order = 3
+            flat_outputs('attr_order3', model(x), out)
+    n_det = [len(t) for t in model(x)['scores']] if name != 'CpnU22' else None
+    print(name, 'detections/img (last config):', n_det, 'proposals:',
+          [int((torch.sigmoid(s[i]) > model.score_thresh).sum()) for i in range(shape[0])])
+    save(f'model_{name}.npz', **out)
+
+
+def gen_stitch():
+    """G8: TileLoader/apply_model semantics on a 2x3-tile image with the tiny CpnU22 (reference loop restated with
+    the reference's own functions: get_tiling_slices, CPN.forward(offsets), remove_border_contours, nms)."""
+    model, overrides, _ = build_ref_model('CpnU22', 0, fourier_std=.6, location_std=.5, score_shift=-3.)
+    H, W, crop, stride = 160, 224, (96, 96), (64, 64)
+    img = torch.rand(1, 3, H, W, generator=torch.Generator().manual_seed(11))
+    slices, overlaps, shape = cd.get_tiling_slices((H, W), crop, stride, return_overlaps=True)
+    slices, overlaps = list(slices), list(overlaps)
+    h_tiles, w_tiles = shape
+    coll = {}
+    with torch.no_grad():
+        for idx, (sl, ov) in enumerate(zip(slices, overlaps)):
+            tile = img[(...,) + sl]
+            offs = torch.as_tensor([[sl[1].start, sl[0].start]])
+            y = model(tile, offsets=offs.clone())
+            h_i, w_i = np.unravel_index(idx, shape)
+            keep = rops.remove_border_contours(y['contours'][0], crop, 4, top=h_i > 0, right=w_i < w_tiles - 1,
+                                               bottom=h_i < h_tiles - 1, left=w_i > 0, offsets=-offs[0])
+            for k in ('contours', 'boxes', 'scores', 'classes', 'locations', 'fourier', 'contour_proposals'):
+                v = y[k][0][keep]
+                coll[k] = torch.cat((coll[k], v)) if k in coll else v
+    keep = torch.ops.torchvision.nms(coll['boxes'], coll['scores'], model.nms_thresh)
+    out = {f'override.{k}': npy(v) for k, v in overrides.items()}
+    out.update(img=npy(img), crop=np.array(crop), stride=np.array(stride), border=np.array(4))
+    tmpl = model.state_dict()
+    out['sd_keys'] = np.array(list(tmpl.keys()))
+    out['sd_shapes'] = np.array([','.join(str(int(d)) for d in v.shape) for v in tmpl.values()])
+    out['pre_nms_count'] = np.array(len(coll['scores']))
+    for k, v in coll.items():
+        out[f'final.{k}'] = npy(v[keep])
+    print('stitch: tiles', shape, 'pre-nms', len(coll['scores']), 'final', len(keep))
+    save('stitch.npz', **out)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['ops', 'tiling', 'models', 'stitch']
+    if 'ops' in which:
+        gen_ops()
+    if 'tiling' in which:
+        gen_tiling()
+    if 'models' in which:
+        for name_ in MODEL_SPECS:
+            gen_model(name_)
+    if 'stitch' in which:
+        gen_stitch()

@@ -1,0 +1,39 @@
+"""Model configurations shared by the golden generator (tests/golden/make_golden.py, keep in sync) and the tests."""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+_DEF = dict(samples=32, score_thresh=.9, nms_thresh=.2, refinement_iterations=4)
+
+MODEL_SPECS = {
+    'CpnU22': dict(cls='CpnU22', kwargs=dict(in_channels=3, backbone_kwargs={'backbone_kwargs': {'base_channels': 8}}),
+                   cpn_kwargs=dict(_DEF)),
+    'CpnResNeXt101UNet': dict(cls='CpnResNeXt101UNet',
+                              kwargs=dict(in_channels=3, backbone_kwargs={'backbone_kwargs': {'base_channel': 8}}),
+                              cpn_kwargs=dict(_DEF)),
+    'CpnResNet18FPN': dict(cls='CpnResNet18FPN', kwargs=dict(in_channels=3, backbone_kwargs={
+        'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}), cpn_kwargs=dict(_DEF)),
+    'CpnResNet50FPN': dict(cls='CpnResNet50FPN', kwargs=dict(in_channels=3, backbone_kwargs={
+        'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}), cpn_kwargs=dict(_DEF)),
+    'CpnResNet50UNet': dict(cls='CpnResNet50UNet',
+                            kwargs=dict(in_channels=3, backbone_kwargs={'backbone_kwargs': {'base_channel': 8}}),
+                            cpn_kwargs=dict(_DEF)),
+    'CpnU22_wide': dict(cls='CpnU22', kwargs=dict(in_channels=3, order=7, samples=48, score_thresh=.8, nms_thresh=.3,
+                                                 backbone_kwargs={'backbone_kwargs': {'base_channels': 32}}),
+                        cpn_kwargs=dict(samples=48, score_thresh=.8, nms_thresh=.3, refinement_iterations=4)),
+}
+
+
+def ref_template_state_dict(name, fixture=None):
+    """Reference state-dict key names + shapes, as recorded in the golden fixture (no reference import needed)."""
+    g = np.load(os.path.join(G, fixture or f'model_{name}.npz'))
+    out = OrderedDict()
+    for k, s in zip(g['sd_keys'], g['sd_shapes']):
+        shape = tuple(int(i) for i in str(s).split(',') if i != '')
+        k = str(k)
+        out[k] = torch.empty(shape, dtype=torch.long if k.endswith('num_batches_tracked') else torch.float32)
+    return out
