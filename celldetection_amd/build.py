@@ -1,0 +1,68 @@
+"""Builds libcpn_hip.so (hand-written HIP kernels + C ABI) in-tree for gfx950 with hipcc.
+
+    python -m celldetection_amd.build [--force]
+
+hipcc cross-compiles without a GPU; the resulting .so is git-ignored but travels with the repo snapshot to the
+GPU box.  Only gfx950 (MI355X / CDNA4) is targeted -- no multi-arch, no compatibility paths.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OUT = os.path.join(HERE, 'libcpn_hip.so')
+ARCH = 'gfx950'
+
+SOURCES = {
+    # file: extra flags
+    'conv_igemm.hip': [],
+    'misc_kernels.hip': [],
+    # decode/NMS must reproduce the reference's fp32 operation order bit-for-bit: no FMA contraction
+    'decode_nms.hip': ['-ffp-contract=off'],
+    'cpn_abi.hip': [],
+}
+HEADERS = ['cpn_kernels.h', 'cpn_error.h', os.path.join('..', '..', 'include', 'cpn_hip.h')]
+
+
+def _hipcc():
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (os.path.isfile(c) or c == 'hipcc'):
+            return c
+    return 'hipcc'
+
+
+def _stale(target, deps):
+    if not os.path.isfile(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.isfile(d))
+
+
+def build(force=False, verbose=True):
+    objdir = os.path.join(HERE, 'build')
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    objs, procs = [], []
+    for src, extra in SOURCES.items():
+        s = os.path.join(CSRC, src)
+        o = os.path.join(objdir, src.replace('.hip', '.o'))
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            cmd = [_hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-c', s, '-o', o] + extra
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f'hipcc failed on {src}')
+    if force or procs or _stale(OUT, objs):
+        cmd = [_hipcc(), f'--offload-arch={ARCH}', '-shared', '-fPIC'] + objs + ['-o', OUT]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

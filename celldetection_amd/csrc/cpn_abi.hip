@@ -1,0 +1,297 @@
+// C ABI + native graph executor of the CPN conv stack (see include/cpn_hip.h).
+// The executor owns no device memory: activations live in a caller-provided arena whose layout is planned once
+// per input shape with a liveness-based first-fit allocator (static workspace planning instead of a caching
+// allocator; 288 GB of HBM3E make arena reuse a locality optimisation, not a necessity).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/cpn_hip.h"
+#include "cpn_error.h"
+#include "cpn_kernels.h"
+
+namespace cpn {
+
+static thread_local std::string g_last_error;
+
+int fail(int code, const char *msg) {
+    g_last_error = msg;
+    return code;
+}
+int check_hip(hipError_t e, const char *where) {
+    if (e == hipSuccess) return 0;
+    g_last_error = std::string(where) + ": " + hipGetErrorString(e);
+    return (int) e;
+}
+
+struct ShapePlan {
+    std::vector<int64_t> offsets;  // per tensor
+    int64_t total = 0;
+};
+
+}  // namespace cpn
+
+struct cpn_plan {
+    std::vector<cpn_tensor_desc> tensors;
+    std::vector<cpn_op_desc> ops;
+    const unsigned char *weights = nullptr;
+    size_t weight_bytes = 0;
+    const float *bias = nullptr;
+    size_t bias_count = 0;
+    std::map<std::tuple<int, int, int>, cpn::ShapePlan> shape_plans;
+};
+
+namespace cpn {
+
+static int64_t tensor_bytes(const cpn_tensor_desc &t, int N, int H, int W) {
+    const int64_t b = (int64_t) N * (H / t.down) * (W / t.down) * t.channels * 2;
+    return (b + 255) / 256 * 256;
+}
+
+static const ShapePlan &get_shape_plan(cpn_plan *p, int N, int H, int W) {
+    auto key = std::make_tuple(N, H, W);
+    auto it = p->shape_plans.find(key);
+    if (it != p->shape_plans.end()) return it->second;
+    const int nt = (int) p->tensors.size();
+    std::vector<int> def(nt, -1), last(nt, -1);
+    for (int i = 0; i < (int) p->ops.size(); ++i) {
+        const cpn_op_desc &o = p->ops[i];
+        if (o.dst >= 0 && def[o.dst] < 0) def[o.dst] = i;
+        for (int s : {o.src0, o.src1, o.res})
+            if (s >= 0) last[s] = std::max(last[s], i);
+        if (o.dst >= 0) last[o.dst] = std::max(last[o.dst], i);
+    }
+    ShapePlan sp;
+    sp.offsets.assign(nt, -1);
+    std::vector<int> order;
+    for (int t = 0; t < nt; ++t)
+        if (def[t] >= 0) order.push_back(t);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return def[a] < def[b]; });
+    std::vector<int> placed;
+    for (int t : order) {
+        const int64_t sz = tensor_bytes(p->tensors[t], N, H, W);
+        // candidate offsets: 0 and the end of every conflicting placed tensor; take the lowest that fits
+        std::vector<std::pair<int64_t, int64_t>> busy;  // [begin, end) of live-overlapping tensors
+        for (int q : placed)
+            if (!(last[q] < def[t] || last[t] < def[q]))
+                busy.emplace_back(sp.offsets[q], sp.offsets[q] + tensor_bytes(p->tensors[q], N, H, W));
+        std::sort(busy.begin(), busy.end());
+        int64_t off = 0;
+        for (auto &b : busy) {
+            if (off + sz <= b.first) break;
+            off = std::max(off, b.second);
+        }
+        sp.offsets[t] = off;
+        sp.total = std::max(sp.total, off + sz);
+        placed.push_back(t);
+    }
+    return p->shape_plans.emplace(key, std::move(sp)).first->second;
+}
+
+struct Dims {
+    int h, w;
+};
+
+static int build_conv_args(const cpn_plan *p, const cpn_op_desc &o, int N, int H, int W, ConvArgs &a, const void *s0,
+                           int c0s, const void *s1, int c1s, const void *res, int rs, void *dst, int ds, int Hin,
+                           int Win) {
+    (void) H; (void) W;
+    a = ConvArgs{};
+    a.src0 = s0; a.src1 = s1; a.c0_stride = c0s; a.c1_stride = c1s;
+    a.c0_used = o.c0_used;
+    a.up0 = o.up0; a.up1 = o.up1;
+    a.N = N; a.Hin = Hin; a.Win = Win;
+    a.KH = o.kh; a.KW = o.kw; a.stride = o.stride; a.pad = o.pad;
+    a.Hout = (Hin + 2 * o.pad - o.kh) / o.stride + 1;
+    a.Wout = (Win + 2 * o.pad - o.kw) / o.stride + 1;
+    a.bundles = o.bundles; a.cin_b = o.cin_b; a.cout_b = o.cout_b;
+    a.weights = p ? p->weights + o.weight_offset : nullptr;
+    a.bias = (p && o.bias_offset >= 0) ? p->bias + o.bias_offset : nullptr;
+    a.res = res; a.res_stride = rs; a.res_up = o.res_up;
+    a.act = o.act; a.act_scale = o.act_scale;
+    a.out_mode = o.dst >= 0 ? OUT_BF16_NHWC : OUT_F32_NCHW;
+    a.dst = dst; a.dst_stride = ds; a.dst_coff = o.dst_coff;
+    a.cout_real = o.cout_real;
+    if (o.cin_b <= 0 || o.cin_b % 32 || o.cout_b <= 0 || o.cout_b % 32 || o.c0_used % 32 || o.bundles < 1)
+        return fail(CPN_E_INVALID, "conv: channel counts must be positive multiples of 32");
+    if (o.bundles > 1 && s1) return fail(CPN_E_INVALID, "conv: grouped conv with two sources");
+    if (!s1 && o.c0_used < o.bundles * o.cin_b) return fail(CPN_E_INVALID, "conv: c0_used smaller than input channels");
+    if ((int64_t) N * Hin * Win * std::max(c0s, c1s) >= (1ll << 31) || (int64_t) N * a.Hout * a.Wout * std::max(ds, 1) >= (1ll << 31))
+        return fail(CPN_E_UNSUPPORTED, "conv: tensor exceeds 2^31 elements (32-bit offsets)");
+    // plain 1x1 convs are GEMMs over the flattened pixel axis: re-tile as [1, M/32, 32] so that narrow images
+    // (16x16 at stride 32) still fill the 32-pixel MFMA column fragments
+    if (o.kh == 1 && o.kw == 1 && o.stride == 1 && o.pad == 0 && !o.up0 && !o.up1 && !o.res_up &&
+        a.out_mode == OUT_BF16_NHWC) {
+        const int64_t M = (int64_t) N * Hin * Win;
+        if (M % 32 == 0) {
+            a.N = 1; a.Hin = a.Hout = (int) (M / 32); a.Win = a.Wout = 32;
+        }
+    }
+    return 0;
+}
+
+}  // namespace cpn
+
+using namespace cpn;
+
+extern "C" {
+
+const char *cpn_last_error(void) { return g_last_error.c_str(); }
+int cpn_abi_version(void) { return CPN_ABI_VERSION; }
+
+int cpn_plan_create(cpn_plan **plan, const cpn_tensor_desc *tensors, int32_t n_tensors, const cpn_op_desc *ops,
+                    int32_t n_ops, const void *weights, size_t weight_bytes, const float *bias, size_t bias_count) {
+    if (!plan || !tensors || !ops || n_tensors <= 0 || n_ops <= 0) return fail(CPN_E_INVALID, "cpn_plan_create: null/empty");
+    cpn_plan *p = new cpn_plan();
+    p->tensors.assign(tensors, tensors + n_tensors);
+    p->ops.assign(ops, ops + n_ops);
+    p->weights = (const unsigned char *) weights;
+    p->weight_bytes = weight_bytes;
+    p->bias = bias;
+    p->bias_count = bias_count;
+    for (const auto &t : p->tensors)
+        if (t.channels <= 0 || t.channels % 32 || t.down < 1 || (t.down & (t.down - 1)) || t.down > 32) {
+            delete p;
+            return fail(CPN_E_INVALID, "cpn_plan_create: tensor channels must be multiples of 32, down a power of two <= 32");
+        }
+    for (const auto &o : p->ops) {
+        for (int s : {o.src0, o.src1, o.res, o.dst})
+            if (s >= n_tensors) {
+                delete p;
+                return fail(CPN_E_INVALID, "cpn_plan_create: tensor id out of range");
+            }
+        if (o.op == CPN_OP_CONV) {
+            const size_t wbytes = (size_t) o.bundles * o.cin_b * o.kh * o.kw * o.cout_b * 2;
+            if (o.weight_offset < 0 || (size_t) o.weight_offset + wbytes > weight_bytes ||
+                (o.bias_offset >= 0 && (size_t) o.bias_offset + (size_t) o.bundles * o.cout_b > bias_count)) {
+                delete p;
+                return fail(CPN_E_INVALID, "cpn_plan_create: weight/bias offset out of range");
+            }
+        }
+    }
+    *plan = p;
+    return 0;
+}
+
+void cpn_plan_destroy(cpn_plan *plan) { delete plan; }
+
+int64_t cpn_plan_workspace_bytes(cpn_plan *plan, int32_t N, int32_t H, int32_t W) {
+    if (!plan || N <= 0 || H <= 0 || W <= 0 || H % 32 || W % 32) {
+        fail(CPN_E_INVALID, "cpn_plan_workspace_bytes: H and W must be positive multiples of 32");
+        return CPN_E_INVALID;
+    }
+    return get_shape_plan(plan, N, H, W).total;
+}
+
+static int run_or_count(cpn_plan *plan, const void *input, int32_t in_dtype, int32_t N, int32_t H, int32_t W,
+                        void *workspace, int64_t workspace_bytes, float *const *outputs, int32_t *range_flag,
+                        hipStream_t st, double *flops) {
+    if (!plan || N <= 0 || H <= 0 || W <= 0 || H % 32 || W % 32)
+        return fail(CPN_E_INVALID, "cpn_plan_run: H and W must be positive multiples of 32");
+    const ShapePlan &sp = get_shape_plan(plan, N, H, W);
+    if (!flops && sp.total > workspace_bytes) return fail(CPN_E_WORKSPACE, "cpn_plan_run: workspace too small");
+    char *ws = (char *) workspace;
+    auto tptr = [&](int t) -> void * { return t >= 0 ? (void *) (ws + sp.offsets[t]) : nullptr; };
+    auto tch = [&](int t) -> int { return t >= 0 ? plan->tensors[t].channels : 0; };
+    for (size_t i = 0; i < plan->ops.size(); ++i) {
+        const cpn_op_desc &o = plan->ops[i];
+        int rc = 0;
+        switch (o.op) {
+            case CPN_OP_INPUT: {
+                if (flops) break;
+                InputArgs a{input, tptr(o.dst), N, o.in_channels, H, W, tch(o.dst), in_dtype, range_flag};
+                rc = check_hip((hipError_t) launch_input(a, st), "input kernel");
+                break;
+            }
+            case CPN_OP_MAXPOOL: {
+                if (flops) break;
+                const int din = plan->tensors[o.src0].down, dout = plan->tensors[o.dst].down;
+                PoolArgs a{tptr(o.src0), tptr(o.dst), N, H / din, W / din, H / dout, W / dout, tch(o.src0), o.kh, o.stride, o.pad};
+                rc = check_hip((hipError_t) launch_maxpool(a, st), "maxpool kernel");
+                break;
+            }
+            case CPN_OP_BILINEAR: {
+                if (flops) break;
+                const int din = plan->tensors[o.src0].down, dout = plan->tensors[o.dst].down;
+                ResizeArgs a{tptr(o.src0), tptr(o.dst), N, H / din, W / din, H / dout, W / dout, tch(o.src0)};
+                rc = check_hip((hipError_t) launch_bilinear(a, st), "bilinear kernel");
+                break;
+            }
+            case CPN_OP_CONV: {
+                const int din = plan->tensors[o.src0].down;
+                const int Hin = (H / din) * (o.up0 ? 2 : 1), Win = (W / din) * (o.up0 ? 2 : 1);
+                void *dst = o.dst >= 0 ? tptr(o.dst) : (outputs ? (void *) outputs[o.out_index] : nullptr);
+                ConvArgs a;
+                rc = build_conv_args(plan, o, N, H, W, a, tptr(o.src0), tch(o.src0), tptr(o.src1), tch(o.src1),
+                                     tptr(o.res), tch(o.res), dst, o.dst >= 0 ? tch(o.dst) : 0, Hin, Win);
+                if (rc) return rc;
+                if (o.dst >= 0) {
+                    const int dout = plan->tensors[o.dst].down;
+                    const int64_t M = (int64_t) N * (H / dout) * (W / dout);
+                    if ((int64_t) a.N * a.Hout * a.Wout != M) return fail(CPN_E_INVALID, "cpn_plan_run: conv output size mismatch");
+                }
+                if (flops) { *flops += conv_executed_flops(a); break; }
+                if (!dst) return fail(CPN_E_INVALID, "cpn_plan_run: missing external output buffer");
+                rc = check_hip((hipError_t) launch_conv(a, st), "conv kernel");
+                break;
+            }
+            default: return fail(CPN_E_INVALID, "cpn_plan_run: unknown op");
+        }
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int cpn_plan_run(cpn_plan *plan, const void *input, int32_t in_dtype, int32_t N, int32_t H, int32_t W,
+                 void *workspace, int64_t workspace_bytes, float *const *outputs, int32_t *range_flag, void *stream) {
+    return run_or_count(plan, input, in_dtype, N, H, W, workspace, workspace_bytes, outputs, range_flag,
+                        (hipStream_t) stream, nullptr);
+}
+
+double cpn_plan_executed_flops(cpn_plan *plan, int32_t N, int32_t H, int32_t W) {
+    double f = 0.;
+    if (run_or_count(plan, nullptr, 0, N, H, W, nullptr, 0, nullptr, nullptr, nullptr, &f)) return -1.;
+    return f;
+}
+
+int cpn_conv2d(const cpn_op_desc *op, const void *src0, int32_t c0_stride, const void *src1, int32_t c1_stride,
+               const void *res, int32_t res_stride, void *dst, int32_t dst_stride, int32_t N, int32_t Hin, int32_t Win,
+               const void *weights, const float *bias, void *stream) {
+    if (!op || !src0 || !dst || !weights) return fail(CPN_E_INVALID, "cpn_conv2d: null pointer");
+    ConvArgs a;
+    int rc = build_conv_args(nullptr, *op, N, 0, 0, a, src0, c0_stride, src1, c1_stride, res, res_stride, dst,
+                             dst_stride, Hin, Win);
+    if (rc) return rc;
+    a.weights = weights;
+    a.bias = bias;
+    return check_hip((hipError_t) launch_conv(a, (hipStream_t) stream), "cpn_conv2d");
+}
+
+int cpn_maxpool2d(const void *src, void *dst, int32_t N, int32_t Hin, int32_t Win, int32_t C, int32_t k, int32_t stride,
+                  int32_t pad, void *stream) {
+    if (C % 8) return fail(CPN_E_INVALID, "cpn_maxpool2d: C must be a multiple of 8");
+    PoolArgs a{src, dst, N, Hin, Win, (Hin + 2 * pad - k) / stride + 1, (Win + 2 * pad - k) / stride + 1, C, k, stride, pad};
+    return check_hip((hipError_t) launch_maxpool(a, (hipStream_t) stream), "cpn_maxpool2d");
+}
+
+int cpn_resize_bilinear(const void *src, void *dst, int32_t N, int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout,
+                        int32_t C, void *stream) {
+    if (C % 8) return fail(CPN_E_INVALID, "cpn_resize_bilinear: C must be a multiple of 8");
+    ResizeArgs a{src, dst, N, Hin, Win, Hout, Wout, C};
+    return check_hip((hipError_t) launch_bilinear(a, (hipStream_t) stream), "cpn_resize_bilinear");
+}
+
+int cpn_convert_input(const void *src, int32_t in_dtype, void *dst, int32_t N, int32_t C, int32_t H, int32_t W,
+                      int32_t Cpad, int32_t *range_flag, void *stream) {
+    if (Cpad % 8 || Cpad < C) return fail(CPN_E_INVALID, "cpn_convert_input: bad Cpad");
+    InputArgs a{src, dst, N, C, H, W, Cpad, in_dtype, range_flag};
+    return check_hip((hipError_t) launch_input(a, (hipStream_t) stream), "cpn_convert_input");
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+// Internal (non-ABI) declarations shared by the HIP translation units of libcpn_hip.so.
+// Target: gfx950 (MI355X, CDNA4) only -- wave64, MFMA 32x32x16 bf16, 160 KiB LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cpn {
+
+// ---------------------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution (NHWC bf16 activations, packed bf16 weights, fp32 accumulate on MFMA)
+// ---------------------------------------------------------------------------------------------------------
+enum OutMode : int { OUT_BF16_NHWC = 0, OUT_F32_NCHW = 1 };
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_TANH_SCALED = 3 };
+
+struct ConvArgs {
+    // sources (NHWC bf16).  The conv input is the virtual channel concat [src0 | src1]; a source flagged "up"
+    // is stored at half resolution and read through a nearest x2 upsample (index >> 1).
+    const void *src0, *src1;
+    int c0_stride, c1_stride;   // channel stride (= padded channel count) of the source buffers
+    int c0_used;                // channels of the virtual concat that come from src0 (multiple of 32)
+    int up0, up1;
+    int N, Hin, Win;            // virtual (post-upsample) input size
+    int Hout, Wout;
+    int KH, KW, stride, pad;
+    int bundles;                // grid.z: independent channel bundles (grouped conv); 1 for dense
+    int cin_b, cout_b;          // channels per bundle (cin_b multiple of 32; cout_b multiple of 32)
+    const void *weights;        // [bundle][cin_b/32][KH*KW][cout_b][32] bf16
+    const float *bias;          // [bundles*cout_b] fp32 (BN folded) or nullptr
+    // epilogue
+    const void *res;            // residual NHWC bf16 (added before activation) or nullptr
+    int res_stride, res_up;
+    int act;
+    float act_scale;
+    int out_mode;
+    void *dst;
+    int dst_stride, dst_coff;   // OUT_BF16_NHWC: channel stride / channel offset of the destination buffer
+    int cout_real;              // OUT_F32_NCHW: number of real output channels (planes written)
+};
+
+// picks a tile configuration and launches; returns hipError_t as int
+int launch_conv(const ConvArgs &a, hipStream_t stream);
+// algorithmic FLOPs actually executed by the MFMA loop of that launch (for utilisation reports)
+double conv_executed_flops(const ConvArgs &a);
+
+struct PoolArgs {
+    const void *src; void *dst;
+    int N, Hin, Win, Hout, Wout, C;   // C = channel stride (multiple of 8)
+    int k, stride, pad;
+};
+int launch_maxpool(const PoolArgs &a, hipStream_t stream);
+
+struct ResizeArgs {
+    const void *src; void *dst;
+    int N, Hin, Win, Hout, Wout, C;
+};
+int launch_bilinear(const ResizeArgs &a, hipStream_t stream);
+
+struct InputArgs {
+    const void *src;   // f32 NCHW (dtype 0) or u8 NCHW (dtype 1, scaled by 1/255)
+    void *dst;         // bf16 NHWC, channel stride Cpad (zero padded)
+    int N, C, H, W, Cpad, dtype;
+    int *range_flag;   // set to 1 when a value is outside [0,1] (reference: models/commons.py:694-697)
+};
+int launch_input(const InputArgs &a, hipStream_t stream);
+
+}  // namespace cpn

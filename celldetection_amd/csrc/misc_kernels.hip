@@ -1,0 +1,162 @@
+// HBM-bound helper kernels of the conv graph (NHWC bf16, 16-byte vector accesses, gfx950 only):
+//   * input conversion  f32/u8 NCHW -> bf16 NHWC (zero-padded channels) + [0,1] range check
+//     (reference: Normalize assert, celldetection/models/commons.py:694-700; LitBase.prepare_inputs u8->f32/255,
+//      celldetection/models/lightning_base.py:774-780)
+//   * MaxPool2d(3,2,1) / MaxPool2d(2,2)   (celldetection/models/resnet.py:279, unet.py:56)
+//   * bilinear resize, align_corners=False (celldetection/models/cpn.py:109-115,277-279 `_equal_size`)
+#include "cpn_kernels.h"
+
+namespace cpn {
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+__device__ __forceinline__ unsigned int to_bf16(float f) {
+    unsigned int u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ float from_bf16(unsigned int b) { return __uint_as_float(b << 16); }
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void input_kernel(const InputArgs a) {
+    // one thread per (pixel, 8-channel group); Cpad is a multiple of 8
+    const int groups = a.Cpad >> 3;
+    const long total = (long) a.N * a.H * a.W * groups;
+    const long HW = (long) a.H * a.W;
+    int bad = 0;
+    for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < total; i += (long) gridDim.x * blockDim.x) {
+        const int gidx = (int) (i % groups);
+        const long pix = i / groups;
+        const long n = pix / HW, p = pix - n * HW;
+        unsigned int h[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = gidx * 8 + e;
+            float v = 0.f;
+            if (c < a.C) {
+                const long si = (n * a.C + c) * HW + p;
+                if (a.dtype == 0) v = ((const float *) a.src)[si];
+                else v = (float) ((const unsigned char *) a.src)[si] / 255.f;
+                if (!(v >= 0.f && v <= 1.f)) bad = 1;
+            }
+            h[e] = to_bf16(v);
+        }
+        u32x4 o;
+        o.x = h[0] | (h[1] << 16);
+        o.y = h[2] | (h[3] << 16);
+        o.z = h[4] | (h[5] << 16);
+        o.w = h[6] | (h[7] << 16);
+        *(u32x4 *) ((unsigned short *) a.dst + pix * a.Cpad + gidx * 8) = o;
+    }
+    if (bad && a.range_flag) atomicOr(a.range_flag, 1);
+}
+
+int launch_input(const InputArgs &a, hipStream_t stream) {
+    const long total = (long) a.N * a.H * a.W * (a.Cpad >> 3);
+    int blocks = (int) ((total + 255) / 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(input_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    return (int) hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_kernel(const PoolArgs a) {
+    const int groups = a.C >> 3;
+    const long total = (long) a.N * a.Hout * a.Wout * groups;
+    for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < total; i += (long) gridDim.x * blockDim.x) {
+        const int gidx = (int) (i % groups);
+        long pix = i / groups;
+        const int ox = (int) (pix % a.Wout);
+        pix /= a.Wout;
+        const int oy = (int) (pix % a.Hout);
+        const int n = (int) (pix / a.Hout);
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = -__builtin_inff();
+        for (int ky = 0; ky < a.k; ++ky) {
+            const int iy = oy * a.stride - a.pad + ky;
+            if (iy < 0 || iy >= a.Hin) continue;
+            for (int kx = 0; kx < a.k; ++kx) {
+                const int ix = ox * a.stride - a.pad + kx;
+                if (ix < 0 || ix >= a.Win) continue;
+                const u32x4 v = *(const u32x4 *) ((const unsigned short *) a.src +
+                                                 (((long) n * a.Hin + iy) * a.Win + ix) * a.C + gidx * 8);
+                const unsigned int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    m[2 * e] = fmaxf(m[2 * e], from_bf16(w[e] & 0xffffu));
+                    m[2 * e + 1] = fmaxf(m[2 * e + 1], from_bf16(w[e] >> 16));
+                }
+            }
+        }
+        u32x4 o;
+        o.x = to_bf16(m[0]) | (to_bf16(m[1]) << 16);
+        o.y = to_bf16(m[2]) | (to_bf16(m[3]) << 16);
+        o.z = to_bf16(m[4]) | (to_bf16(m[5]) << 16);
+        o.w = to_bf16(m[6]) | (to_bf16(m[7]) << 16);
+        *(u32x4 *) ((unsigned short *) a.dst + (((long) n * a.Hout + oy) * a.Wout + ox) * a.C + gidx * 8) = o;
+    }
+}
+
+int launch_maxpool(const PoolArgs &a, hipStream_t stream) {
+    const long total = (long) a.N * a.Hout * a.Wout * (a.C >> 3);
+    int blocks = (int) ((total + 255) / 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(maxpool_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    return (int) hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bilinear_kernel(const ResizeArgs a) {
+    // PyTorch upsample_bilinear2d, align_corners=False: src = max(scale*(dst+0.5)-0.5, 0), scale = in/out
+    const int groups = a.C >> 3;
+    const long total = (long) a.N * a.Hout * a.Wout * groups;
+    const float sy = (float) a.Hin / (float) a.Hout, sx = (float) a.Win / (float) a.Wout;
+    for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < total; i += (long) gridDim.x * blockDim.x) {
+        const int gidx = (int) (i % groups);
+        long pix = i / groups;
+        const int ox = (int) (pix % a.Wout);
+        pix /= a.Wout;
+        const int oy = (int) (pix % a.Hout);
+        const int n = (int) (pix / a.Hout);
+        const float fy = fmaxf(sy * ((float) oy + 0.5f) - 0.5f, 0.f);
+        const float fx = fmaxf(sx * ((float) ox + 0.5f) - 0.5f, 0.f);
+        const int y0 = (int) fy, x0 = (int) fx;
+        const int y1 = y0 + (y0 < a.Hin - 1 ? 1 : 0), x1 = x0 + (x0 < a.Win - 1 ? 1 : 0);
+        const float ly = fy - (float) y0, lx = fx - (float) x0;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const unsigned short *base = (const unsigned short *) a.src + (long) n * a.Hin * a.Win * a.C + gidx * 8;
+        const u32x4 v00 = *(const u32x4 *) (base + ((long) y0 * a.Win + x0) * a.C);
+        const u32x4 v01 = *(const u32x4 *) (base + ((long) y0 * a.Win + x1) * a.C);
+        const u32x4 v10 = *(const u32x4 *) (base + ((long) y1 * a.Win + x0) * a.C);
+        const u32x4 v11 = *(const u32x4 *) (base + ((long) y1 * a.Win + x1) * a.C);
+        const unsigned int a00[4] = {v00.x, v00.y, v00.z, v00.w}, a01[4] = {v01.x, v01.y, v01.z, v01.w};
+        const unsigned int a10[4] = {v10.x, v10.y, v10.z, v10.w}, a11[4] = {v11.x, v11.y, v11.z, v11.w};
+        unsigned int o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float lo = hy * (hx * from_bf16(a00[e] & 0xffffu) + lx * from_bf16(a01[e] & 0xffffu)) +
+                             ly * (hx * from_bf16(a10[e] & 0xffffu) + lx * from_bf16(a11[e] & 0xffffu));
+            const float hi = hy * (hx * from_bf16(a00[e] >> 16) + lx * from_bf16(a01[e] >> 16)) +
+                             ly * (hx * from_bf16(a10[e] >> 16) + lx * from_bf16(a11[e] >> 16));
+            o[e] = to_bf16(lo) | (to_bf16(hi) << 16);
+        }
+        u32x4 ov;
+        ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
+        *(u32x4 *) ((unsigned short *) a.dst + (((long) n * a.Hout + oy) * a.Wout + ox) * a.C + gidx * 8) = ov;
+    }
+}
+
+int launch_bilinear(const ResizeArgs &a, hipStream_t stream) {
+    const long total = (long) a.N * a.Hout * a.Wout * (a.C >> 3);
+    int blocks = (int) ((total + 255) / 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(bilinear_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    return (int) hipGetLastError();
+}
+
+}  // namespace cpn

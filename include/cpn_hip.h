@@ -1,0 +1,161 @@
+/* libcpn_hip.so -- C ABI of the MI355X (gfx950) Contour Proposal Network inference path.
+ *
+ * The reference (FZJ-INM1-BDA/celldetection v0.4.9) is pure Python: the "FFI" this library replaces is the set of
+ * PyTorch / torchvision operator calls on the CPN inference path.  Each entry point cites the reference call
+ * site(s) it replaces (paths relative to the reference repository root).  The Python binding a maintainer would
+ * add is a ctypes stub (see INTEGRATION.md and celldetection_amd/_lib.py).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch types.  All device pointers are HIP device memory owned by the
+ *     caller (e.g. PyTorch's caching allocator); the library allocates no device memory after plan creation
+ *     except what the caller hands it as workspace.
+ *   - every call enqueues on the caller's HIP stream (`stream` = hipStream_t cast to void*), no internal threads,
+ *     no host synchronisation unless stated.
+ *   - return value: 0 = ok, otherwise a negative CPN_E_* code or a positive hipError_t; cpn_last_error() returns a
+ *     thread-local message.  No exceptions cross the ABI.
+ */
+#ifndef CPN_HIP_H
+#define CPN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPN_ABI_VERSION 1
+
+#define CPN_E_INVALID (-1)
+#define CPN_E_UNSUPPORTED (-2)
+#define CPN_E_WORKSPACE (-3)
+
+const char *cpn_last_error(void);
+int cpn_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Conv-graph plan: the backbone + head convolution stack.
+ * Replaces CPNCore.forward (celldetection/models/cpn.py:238-283): backbone(inputs) [models/unet.py:296-304,178-249;
+ * models/fpn.py:180-185; models/resnet.py:265-297 + torchvision block forwards], the four ReadOut heads
+ * (models/commons.py:461-511) and Normalize's range assert (models/commons.py:694-700).
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* activation tensors of the graph (NHWC bf16, channel count padded to a multiple of 32) */
+typedef struct {
+    int32_t channels;  /* padded channel count (multiple of 32)                                   */
+    int32_t down;      /* spatial size = input size / down (down in 1,2,4,...,32)                 */
+} cpn_tensor_desc;
+
+enum { CPN_OP_INPUT = 0, CPN_OP_CONV = 1, CPN_OP_MAXPOOL = 2, CPN_OP_BILINEAR = 3 };
+enum { CPN_ACT_NONE = 0, CPN_ACT_RELU = 1, CPN_ACT_SIGMOID = 2, CPN_ACT_TANH_SCALED = 3 };
+enum { CPN_OUT_SCORES = 0, CPN_OUT_LOCATIONS = 1, CPN_OUT_FOURIER = 2, CPN_OUT_REFINEMENT = 3 };
+
+typedef struct {
+    int32_t op;               /* CPN_OP_*                                                                   */
+    int32_t src0, src1, res;  /* tensor ids (-1 = none). src1: second source of a virtual channel concat      */
+    int32_t dst;              /* tensor id, or -1 when the op writes an external fp32 NCHW output             */
+    int32_t up0, up1, res_up; /* source is stored at half resolution, read through nearest x2 upsampling      */
+    int32_t c0_used;          /* channels of the concat taken from src0 (multiple of 32)                      */
+    int32_t kh, kw, stride, pad;
+    int32_t bundles, cin_b, cout_b; /* grouped convs run as `bundles` dense convs of cin_b -> cout_b channels  */
+    int64_t weight_offset;    /* byte offset into the packed weight blob: [bundle][cin_b/32][kh*kw][cout_b][32] bf16 */
+    int64_t bias_offset;      /* float offset into the bias blob, -1 = no bias                                 */
+    int32_t act;              /* CPN_ACT_*                                                                    */
+    float act_scale;
+    int32_t out_index;        /* dst == -1: CPN_OUT_* index of the external output                            */
+    int32_t cout_real;        /* dst == -1: real number of output channels                                    */
+    int32_t dst_coff;         /* channel offset inside dst                                                    */
+    int32_t in_channels;      /* CPN_OP_INPUT: real input channels                                            */
+} cpn_op_desc;
+
+typedef struct cpn_plan cpn_plan;
+
+/* Creates a plan (host-side object; copies the descriptors).  `weights` / `bias` are DEVICE pointers to the packed
+ * blobs and must stay alive as long as the plan. */
+int cpn_plan_create(cpn_plan **plan, const cpn_tensor_desc *tensors, int32_t n_tensors, const cpn_op_desc *ops,
+                    int32_t n_ops, const void *weights, size_t weight_bytes, const float *bias, size_t bias_count);
+void cpn_plan_destroy(cpn_plan *plan);
+/* Workspace (activation arena, liveness-planned) needed for a batch of N inputs of H x W (H, W multiples of 32). */
+int64_t cpn_plan_workspace_bytes(cpn_plan *plan, int32_t N, int32_t H, int32_t W);
+/* 2*MAC FLOPs executed by the MFMA loops for that shape (includes channel/tile padding). */
+double cpn_plan_executed_flops(cpn_plan *plan, int32_t N, int32_t H, int32_t W);
+
+/* Runs the conv graph.  input: fp32 (dtype 0) or uint8 (dtype 1, scaled by 1/255) NCHW [N,C,H,W].
+ * outputs[CPN_OUT_*]: fp32 NCHW device buffers: scores [N,1,h,w] (sigmoid applied), locations [N,2,h,w],
+ * fourier [N,4*order,h,w], refinement [N,2,H,W] (tanh*margin applied).
+ * range_flag: device int32, zeroed by the caller; set to 1 if an input value lies outside [0,1]
+ * (the caller raises the reference's AssertionError, models/commons.py:696-697). */
+int cpn_plan_run(cpn_plan *plan, const void *input, int32_t in_dtype, int32_t N, int32_t H, int32_t W,
+                 void *workspace, int64_t workspace_bytes, float *const *outputs, int32_t *range_flag, void *stream);
+
+/* Single convolution (testing / building blocks); same semantics as one CPN_OP_CONV. */
+int cpn_conv2d(const cpn_op_desc *op, const void *src0, int32_t c0_stride, const void *src1, int32_t c1_stride,
+               const void *res, int32_t res_stride, void *dst, int32_t dst_stride, int32_t N, int32_t Hin, int32_t Win,
+               const void *weights, const float *bias, void *stream);
+int cpn_maxpool2d(const void *src, void *dst, int32_t N, int32_t Hin, int32_t Win, int32_t C, int32_t k, int32_t stride,
+                  int32_t pad, void *stream);
+int cpn_resize_bilinear(const void *src, void *dst, int32_t N, int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout,
+                        int32_t C, void *stream);
+int cpn_convert_input(const void *src, int32_t in_dtype, void *dst, int32_t N, int32_t C, int32_t H, int32_t W,
+                      int32_t Cpad, int32_t *range_flag, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Proposal extraction + contour decode.
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* Order-preserving stream compaction of (scores > thresh), replaces `torch.where(fg_mask)`
+ * (celldetection/models/cpn.py:579,616-620): writes the linear indices (b*h*w + y*w + x, ascending = (b,y,x)
+ * row-major order) of the selected pixels to `indices` (capacity N*h*w int32) and the per-image counts to
+ * `counts` (N+1 int32: counts[b] = proposals of image b, counts[N] = total).  `workspace`: cpn_compact_workspace_bytes. */
+int64_t cpn_compact_workspace_bytes(int32_t N, int32_t h, int32_t w);
+int cpn_compact(const float *scores, int32_t N, int32_t h, int32_t w, float thresh, int32_t *indices, int32_t *counts,
+                void *workspace, void *stream);
+
+/* Fused gather + rel->abs location + Fourier-to-contour synthesis + rescale + local refinement + clamp + boxes
+ * (+ per-image offsets).  Replaces celldetection/models/cpn.py:613-702 i.e. rel_location2abs_location
+ * (ops/cpn.py:15-41), advanced-index gathers (cpn.py:621-628), fouriers2contours (ops/cpn.py:44-95), scale_contours /
+ * scale_fourier (ops/cpn.py:106-165), local_refinement (cpn.py:63-85), clamp + min/max boxes (cpn.py:661-670) and the
+ * offsets add (cpn.py:695-702).
+ *   indices[P]           from cpn_compact
+ *   scores [N,1,h,w], locations [N,2,h,w], fourier [N,4*order_total,h,w], refinement [N,2,H,W] or NULL (fp32 NCHW)
+ *   order <= order_total (cpn.py:597-598 "changed order"), samples = S, iterations = refinement iterations
+ *   cos_table/sin_table [order][samples] fp32 device (built by the host exactly like ops/cpn.py:69-78)
+ *   offsets: int64 [N,2] (xy) device or NULL
+ * outputs (device, row-major): contours [P,S,2], proposals [P,S,2], boxes [P,4], out_scores [P], out_locations [P,2],
+ *   out_fourier [P,order,4], batch_index [P] int32. */
+int cpn_decode(const int32_t *indices, int32_t P, const float *scores, const float *locations, const float *fourier,
+               const float *refinement, int32_t N, int32_t h, int32_t w, int32_t H, int32_t W, int32_t order_total,
+               int32_t order, int32_t samples, int32_t iterations, const float *cos_table, const float *sin_table,
+               const int64_t *offsets, float *contours, float *proposals, float *boxes, float *out_scores,
+               float *out_locations, float *out_fourier, int32_t *batch_index, void *stream);
+
+/* Standalone pieces of the decode (parity tests, reference ops API celldetection/ops/cpn.py). */
+int cpn_fouriers2contours(const float *fourier, const float *locations, int32_t P, int32_t order, int32_t samples,
+                          const float *cos_table, const float *sin_table, float *contours, void *stream);
+int cpn_local_refinement(float *contours /* in/out [P,S,2] */, const int32_t *batch_index, int32_t P, int32_t samples,
+                         const float *refinement, int32_t N, int32_t H, int32_t W, int32_t iterations, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Box NMS.  Replaces torch.ops.torchvision.nms as called from batched_box_nmsi (celldetection/ops/cpn.py:189-227)
+ * and the slide-level NMS (celldetection_scripts/cpn_inference.py:405-408,426): greedy, stable descending-score
+ * order, suppress iff inter/(area_i+area_j-inter) > thresh (NaN never suppresses), output = kept indices in that
+ * order.  Segmented: boxes/scores hold `nseg` consecutive segments (images) [seg_offsets[s], seg_offsets[s+1]);
+ * segments are independent.  seg_offsets_host: host int64[nseg+1]; seg_offsets_dev: same values on the device.
+ * keep (int64 [P], device): for each segment the kept indices (relative to the segment start) are written from
+ * position seg_offsets[s]; keep_counts (int32 [nseg], device) receives the number kept per segment.
+ * ---------------------------------------------------------------------------------------------------------- */
+int64_t cpn_nms_workspace_bytes(int64_t P, int64_t max_segment, int32_t nseg);
+int cpn_nms(const float *boxes, const float *scores, int64_t P, const int64_t *seg_offsets_host,
+            const int64_t *seg_offsets_dev, int32_t nseg, float thresh, int64_t *keep, int32_t *keep_counts,
+            void *workspace, int64_t workspace_bytes, void *stream);
+
+/* remove_border_contours (celldetection/ops/cpn.py:258-290): keep[i] = 1 iff all points of contour i (+offset)
+ * satisfy y>pad (top), x<w-pad (right), y<h-pad (bottom), x>pad (left) on the enabled sides.
+ * sides: bit0 top, bit1 right, bit2 bottom, bit3 left. */
+int cpn_border_keep(const float *contours, int64_t P, int32_t samples, float off_x, float off_y, float h, float w,
+                    float pad, int32_t sides, uint8_t *keep, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPN_HIP_H */
