@@ -1,0 +1,306 @@
+"""Drop-in ``cd.models.CPN`` inference modules running on the MI355X HIP engine.
+
+Mirrors the reference's public surface for the inference path (celldetection/models/cpn.py:287-439,561-734):
+constructor signatures of the ``Cpn<Backbone>`` classes, mutable attributes (``score_thresh``, ``nms_thresh``,
+``samples``, ``order``, ``refinement_iterations`` ... honoured at run time), ``state_dict()`` key names/shapes
+(reference checkpoints load unchanged), ``hparams`` and the ``forward(inputs, targets=None, nms=True, **kwargs)``
+output ``OrderedDict`` of per-image lists.  Training (``compute_loss``, cpn.py:441-559) is out of scope.
+
+The conv stack runs through the native graph executor of libcpn_hip.so (bf16 NHWC, MFMA), the post-processing
+through the fused decode / NMS kernels; PyTorch only provides device memory, streams and indexing glue.
+"""
+from collections import OrderedDict
+from ctypes import c_void_p
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib, graph, ops
+
+__all__ = ['CPN']
+
+
+class _Container(nn.Module):
+    """Anonymous node of the parameter tree (mirrors the reference's module hierarchy for state_dict keys)."""
+
+    def forward(self, *a, **k):
+        raise RuntimeError('parameter container; the compute graph runs in the HIP engine')
+
+
+def _register(root: nn.Module, key: str, shape, kind: str):
+    parts = key.split('.')
+    m = root
+    for p in parts[:-1]:
+        if p not in m._modules:
+            m.add_module(p, _Container())
+        m = m._modules[p]
+    leaf = parts[-1]
+    if kind == 'param':
+        t = torch.empty(shape)
+        if len(shape) >= 2:
+            nn.init.kaiming_uniform_(t, a=1)
+        elif leaf == 'weight':
+            t.fill_(1.)
+        else:
+            t.zero_()
+        m.register_parameter(leaf, nn.Parameter(t, requires_grad=False))
+    elif kind == 'long':
+        m.register_buffer(leaf, torch.zeros(shape, dtype=torch.long))
+    else:
+        if leaf == 'running_var':
+            t = torch.ones(shape)
+        elif key == 'order_weights':
+            x = torch.arange(shape[0]).float()
+            spread = max(shape[0] - 1, 1)
+            t = (1 + 4 * (1 - (x / spread).clamp(0., 1.)) ** 2)[:, None]  # celldetection/ops/cpn.py:230-235
+        else:
+            t = torch.zeros(shape)
+        m.register_buffer(leaf, t)
+
+
+class _Engine:
+    """Packed weights + native plan for one device."""
+
+    def __init__(self, plan: graph.Plan, state_dict, device):
+        lib = _lib.load()
+        self.device = device
+        self.tens, self.ops_desc, self.wblob, self.bblob = graph.pack(plan, state_dict, device)
+        handle = c_void_p()
+        _lib.check(lib.cpn_plan_create(handle, self.tens, len(self.tens), self.ops_desc, len(self.ops_desc),
+                                       _lib.ptr(self.wblob), self.wblob.numel() * 2, _lib.ptr(self.bblob),
+                                       self.bblob.numel()), 'plan_create')
+        self.handle = handle
+        self.plan = plan
+        self._ws = None
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                _lib.load().cpn_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def workspace(self, n, h, w):
+        need = int(_lib.load().cpn_plan_workspace_bytes(self.handle, n, h, w))
+        if need < 0:
+            _lib.check(need, 'plan_workspace_bytes')
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws, need
+
+    def executed_flops(self, n, h, w):
+        return float(_lib.load().cpn_plan_executed_flops(self.handle, n, h, w))
+
+    def profile(self, x: torch.Tensor, order_total: int, refinement: bool):
+        """Per-op timing of one conv-graph execution: list of dicts(op, name, ms, gflop_executed)."""
+        from ctypes import c_double, c_float
+        lib = _lib.load()
+        nops = lib.cpn_plan_num_ops(self.handle)
+        ms, fl = (c_float * nops)(), (c_double * nops)()
+        self.run(x, order_total, refinement, _timed=(ms, fl))
+        out = []
+        for i, op in enumerate(self.plan.ops):
+            out.append(dict(index=i, op=op['op'], name=op.get('w', ''), ms=float(ms[i]), gflop=float(fl[i]) / 1e9,
+                            k=op.get('k'), cin=op.get('cin'), cout=op.get('cout'), groups=op.get('groups'),
+                            stride=op.get('stride')))
+        return out
+
+    def run(self, x: torch.Tensor, order_total: int, refinement: bool, _timed=None):
+        """x: [N,C,H,W] float32 in [0,1] (or uint8) on self.device -> (scores, locations, refinement, fourier, flag)."""
+        lib = _lib.load()
+        n, c, h, w = x.shape
+        if h % 32 or w % 32:
+            raise ValueError(f'Input height and width must be multiples of 32 on the HIP path, got {(h, w)}.')
+        if x.dtype == torch.uint8:
+            dt = 1
+        else:
+            dt = 0
+            if x.dtype != torch.float32:
+                x = x.float()
+        x = x.contiguous()
+        d = self.plan.meta['head_down']
+        f32 = dict(dtype=torch.float32, device=self.device)
+        scores = torch.empty((n, 1, h // d, w // d), **f32)
+        locations = torch.empty((n, 2, h // d, w // d), **f32)
+        fourier = torch.empty((n, 4 * order_total, h // d, w // d), **f32)
+        ref = torch.empty((n, 2, h, w), **f32) if refinement else None
+        flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        ws, need = self.workspace(n, h, w)
+        outs = (c_void_p * 4)(scores.data_ptr(), locations.data_ptr(), fourier.data_ptr(),
+                              0 if ref is None else ref.data_ptr())
+        if _timed is not None:
+            _lib.check(lib.cpn_plan_run_timed(self.handle, _lib.ptr(x), dt, n, h, w, _lib.ptr(ws), need, outs,
+                                              _lib.ptr(flag), _lib.stream_ptr(), _timed[0], _timed[1]), 'plan_run_timed')
+        else:
+            _lib.check(lib.cpn_plan_run(self.handle, _lib.ptr(x), dt, n, h, w, _lib.ptr(ws), need, outs, _lib.ptr(flag),
+                                        _lib.stream_ptr()), 'plan_run')
+        return scores, locations, ref, fourier, flag
+
+
+def _equal_size(x, reference):
+    """celldetection/models/cpn.py:109-115."""
+    if reference.shape[2:] != x.shape[2:]:
+        x = F.interpolate(x, reference.shape[2:], mode='bilinear', align_corners=False)
+    return x
+
+
+class CPN(nn.Module):
+    """Contour Proposal Network (inference) on the HIP engine; ``backbone`` is the reference backbone class name,
+    e.g. ``'ResNeXt101UNet'``, ``'U22'``, ``'ResNet18FPN'`` (celldetection/models/cpn.py:287-439)."""
+
+    def __init__(self, backbone: str, in_channels: int, order: int = 5, nms_thresh: float = .2,
+                 score_thresh: float = .9, certainty_thresh: float = None, samples: int = 32, classes: int = 2,
+                 refinement: bool = True, refinement_iterations: int = 4, refinement_margin: float = 3.,
+                 refinement_buckets: int = 1, uncertainty_head=False, uncertainty_nms=False, order_weights=True,
+                 backbone_kwargs: dict = None, **kwargs):
+        super().__init__()
+        if uncertainty_head:
+            raise NotImplementedError('uncertainty_head is not implemented on the HIP path')
+        unsupported = {k: v for k, v in kwargs.items() if k in ('contour_head_channels', 'refinement_head_channels',
+                                                                'contour_head_stride', 'refinement_head_stride')
+                       and v not in (None, 1)}
+        if unsupported:
+            raise NotImplementedError(f'Unsupported CPN options on the HIP path: {unsupported}')
+        self.order = order
+        self.nms_thresh = nms_thresh
+        self.samples = samples
+        self.score_thresh = score_thresh
+        self.score_channels = 1 if classes in (1, 2) else classes
+        self.refinement = refinement
+        self.refinement_iterations = refinement_iterations
+        self.refinement_margin = refinement_margin
+        self.functional = False
+        self.full_detail = False
+        self.score_target_dtype = None
+        self.certainty_thresh = certainty_thresh
+        self.uncertainty_nms = uncertainty_nms
+        self._backbone_name = backbone
+        self._plan = graph.build_plan(backbone, in_channels, order=order, score_channels=self.score_channels,
+                                      refinement=refinement, refinement_margin=refinement_margin,
+                                      refinement_buckets=refinement_buckets, order_weights=bool(order_weights),
+                                      backbone_kwargs=backbone_kwargs)
+        for key, shape, kind in self._plan.entries:
+            _register(self, key, shape, kind)
+        self.core.order = order
+        self.core.refinement_buckets = refinement_buckets
+        self._engine = None
+        self._hparams = {}
+        self.max_imsize = None
+        self.eval()
+
+    # ---- reference-compatible plumbing -------------------------------------------------------------------------
+    @property
+    def hparams(self):
+        return self._hparams
+
+    def _set_hparams(self, hp):
+        self._hparams = dict(hp)
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        self._engine = None  # weights change -> repack on next forward
+        return super().load_state_dict(state_dict, strict=strict, **kw)
+
+    def repack(self):
+        """Call after modifying parameters in place."""
+        self._engine = None
+
+    def _apply(self, fn, *a, **k):
+        self._engine = None
+        return super()._apply(fn, *a, **k)
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise NotImplementedError('celldetection_amd.CPN is an inference engine; training is out of scope.')
+        return super().train(False)
+
+    def engine(self, device=None) -> _Engine:
+        device = torch.device(device) if device is not None else self.order_weights_device()
+        if device.type != 'cuda':
+            raise RuntimeError('celldetection_amd runs on the MI355X (HIP) only: move the model and inputs to a GPU. '
+                               'There is no CPU fallback in the product path.')
+        if self._engine is None or self._engine.device != device:
+            self._engine = _Engine(self._plan, self.state_dict(), device)
+        return self._engine
+
+    def order_weights_device(self):
+        return next(self.parameters()).device
+
+    # ---- forward --------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def core_forward(self, inputs: torch.Tensor):
+        """CPNCore.forward (cpn.py:238-283) -> (scores(sigmoid applied), locations, refinement, fourier)."""
+        eng = self.engine(inputs.device)
+        scores, locations, refinement, fourier, flag = eng.run(inputs, self.core.order, self.refinement)
+        self._last_flag = flag
+        return scores, locations, refinement, fourier
+
+    @torch.no_grad()
+    def forward(self, inputs, targets=None, nms=True, **kwargs):
+        if targets is not None:
+            raise NotImplementedError('Loss computation / training is out of scope of the HIP inference engine.')
+        if not inputs.is_cuda:
+            raise RuntimeError('celldetection_amd.CPN.forward needs GPU inputs (no CPU fallback).')
+        original_size = tuple(inputs.shape[-2:])
+        scores, locations, refinement, fourier = self.core_forward(inputs)
+        return self.postprocess(scores, locations, refinement, fourier, original_size, nms=nms, flag=self._last_flag,
+                                **kwargs)
+
+    @torch.no_grad()
+    def postprocess(self, scores, locations, refinement, fourier, original_size, nms=True, flag=None, **kwargs):
+        """CPN.forward after the core (cpn.py:575-734) on given head maps: ``scores`` are probabilities
+        (sigmoid already applied) [N,1,h,w]; locations [N,2,h,w]; refinement [N,2,H,W] or None; fourier [N,4*O,h,w]."""
+        n = scores.shape[0]
+        lb, ub = kwargs.get('scores_lower_bound'), kwargs.get('scores_upper_bound')
+        if ub is not None:  # cpn.py:118-123
+            scores = torch.minimum(scores, _equal_size(ub.to(scores), scores))
+        if lb is not None:
+            scores = torch.maximum(scores, _equal_size(lb.to(scores), scores))
+        order = min(self.order, self.core.order)  # cpn.py:597-598
+        indices, counts, flag_v = ops.compact_scores(scores, self.score_thresh, extra_flag=flag)
+        if flag_v:
+            raise AssertionError('Inputs should be in interval (0.0, 1.0)')  # models/commons.py:696-697
+        iters = self.refinement_iterations if (self.refinement and refinement is not None) else 0
+        flat = ops.decode_proposals(indices, scores, locations, fourier, refinement if iters > 0 else None,
+                                    size=original_size, order=order, samples=self.samples, iterations=iters,
+                                    offsets=kwargs.get('offsets'))
+        offs = [0]
+        for c in counts:
+            offs.append(offs[-1] + c)
+        flat['classes'] = torch.ones((offs[-1],), dtype=torch.int64, device=scores.device)
+        keys = ('contours', 'boxes', 'scores', 'classes', 'locations', 'fourier', 'contour_proposals')
+        outputs = OrderedDict((k, [flat[k][offs[i]:offs[i + 1]] for i in range(n)]) for k in keys)  # cpn.py:42-50
+        outputs['box_uncertainties'] = None
+        if nms:
+            keep = ops.batched_box_nmsi(outputs['boxes'], outputs['scores'], self.nms_thresh)
+            for k in keys:  # cpn.py:53-60
+                outputs[k] = [v[kp] for v, kp in zip(outputs[k], keep)]
+        return outputs
+
+
+def _make(backbone):
+    def __init__(self, in_channels: int, order: int = 5, nms_thresh: float = .2, score_thresh: float = .9,
+                 samples: int = 32, classes: int = 2, refinement: bool = True, refinement_iterations: int = 4,
+                 refinement_margin: float = 3., refinement_buckets: int = 1, backbone_kwargs: dict = None, **kwargs):
+        hp = dict(in_channels=in_channels, order=order, nms_thresh=nms_thresh, score_thresh=score_thresh,
+                  samples=samples, classes=classes, refinement=refinement, refinement_iterations=refinement_iterations,
+                  refinement_margin=refinement_margin, refinement_buckets=refinement_buckets,
+                  backbone_kwargs=backbone_kwargs, **kwargs)
+        CPN.__init__(self, backbone, in_channels, order=order, nms_thresh=nms_thresh, score_thresh=score_thresh,
+                     samples=samples, classes=classes, refinement=refinement,
+                     refinement_iterations=refinement_iterations, refinement_margin=refinement_margin,
+                     refinement_buckets=refinement_buckets, backbone_kwargs=backbone_kwargs, **kwargs)
+        self._set_hparams(hp)
+
+    cls = type(f'Cpn{backbone}', (CPN,), {'__init__': __init__, '__doc__': (
+        f'Contour Proposal Network with a {backbone} backbone (celldetection/models/cpn.py Cpn{backbone}); '
+        f'inference on the MI355X HIP engine.')})
+    return cls
+
+
+for _bb in graph.BACKBONES:
+    _c = _make(_bb)
+    globals()[_c.__name__] = _c
+    __all__.append(_c.__name__)

@@ -191,7 +191,7 @@ int64_t cpn_plan_workspace_bytes(cpn_plan *plan, int32_t N, int32_t H, int32_t W
 
 static int run_or_count(cpn_plan *plan, const void *input, int32_t in_dtype, int32_t N, int32_t H, int32_t W,
                         void *workspace, int64_t workspace_bytes, float *const *outputs, int32_t *range_flag,
-                        hipStream_t st, double *flops) {
+                        hipStream_t st, double *flops, hipEvent_t *events = nullptr, double *op_flops = nullptr) {
     if (!plan || N <= 0 || H <= 0 || W <= 0 || H % 32 || W % 32)
         return fail(CPN_E_INVALID, "cpn_plan_run: H and W must be positive multiples of 32");
     const ShapePlan &sp = get_shape_plan(plan, N, H, W);
@@ -202,6 +202,7 @@ static int run_or_count(cpn_plan *plan, const void *input, int32_t in_dtype, int
     for (size_t i = 0; i < plan->ops.size(); ++i) {
         const cpn_op_desc &o = plan->ops[i];
         int rc = 0;
+        if (events) (void) hipEventRecord(events[i], st);
         switch (o.op) {
             case CPN_OP_INPUT: {
                 if (flops) break;
@@ -236,6 +237,7 @@ static int run_or_count(cpn_plan *plan, const void *input, int32_t in_dtype, int
                     const int64_t M = (int64_t) N * (H / dout) * (W / dout);
                     if ((int64_t) a.N * a.Hout * a.Wout != M) return fail(CPN_E_INVALID, "cpn_plan_run: conv output size mismatch");
                 }
+                if (op_flops) op_flops[i] = conv_executed_flops(a);
                 if (flops) { *flops += conv_executed_flops(a); break; }
                 if (!dst) return fail(CPN_E_INVALID, "cpn_plan_run: missing external output buffer");
                 rc = check_hip((hipError_t) launch_conv(a, st), "conv kernel");
@@ -245,7 +247,27 @@ static int run_or_count(cpn_plan *plan, const void *input, int32_t in_dtype, int
         }
         if (rc) return rc;
     }
+    if (events) (void) hipEventRecord(events[plan->ops.size()], st);
     return 0;
+}
+
+int cpn_plan_num_ops(cpn_plan *plan) { return plan ? (int) plan->ops.size() : 0; }
+
+int cpn_plan_run_timed(cpn_plan *plan, const void *input, int32_t in_dtype, int32_t N, int32_t H, int32_t W,
+                       void *workspace, int64_t workspace_bytes, float *const *outputs, int32_t *range_flag,
+                       void *stream, float *op_ms, double *op_flops) {
+    if (!plan || !op_ms) return fail(CPN_E_INVALID, "cpn_plan_run_timed: null");
+    const size_t n = plan->ops.size();
+    std::vector<hipEvent_t> ev(n + 1);
+    for (auto &e : ev)
+        if (hipEventCreate(&e) != hipSuccess) return fail(CPN_E_INVALID, "cpn_plan_run_timed: event create failed");
+    if (op_flops) std::fill(op_flops, op_flops + n, 0.);
+    int rc = run_or_count(plan, input, in_dtype, N, H, W, workspace, workspace_bytes, outputs, range_flag,
+                          (hipStream_t) stream, nullptr, ev.data(), op_flops);
+    if (!rc) rc = check_hip(hipEventSynchronize(ev[n]), "cpn_plan_run_timed: sync");
+    for (size_t i = 0; i < n && !rc; ++i) (void) hipEventElapsedTime(&op_ms[i], ev[i], ev[i + 1]);
+    for (auto &e : ev) (void) hipEventDestroy(e);
+    return rc;
 }
 
 int cpn_plan_run(cpn_plan *plan, const void *input, int32_t in_dtype, int32_t N, int32_t H, int32_t W,

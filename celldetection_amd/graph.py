@@ -1,0 +1,450 @@
+"""Layer plans of the CPN model families and weight packing for the HIP conv engine.
+
+A *plan* is built from constructor hyper-parameters only (no weights): an ordered list of state-dict entries
+(names + shapes identical to the reference's ``state_dict()``, so reference checkpoints load unchanged) and a small
+IR of fused ops (conv + folded BN + activation (+ residual / virtual concat / nearest upsample)).  ``pack`` turns a
+state dict into the bf16 weight blob + fp32 bias blob + ``cpn_op_desc`` array the native executor consumes.
+
+Reference structures mirrored (file:line relative to the reference repository):
+  ResNet / ResNeXt encoders   celldetection/models/resnet.py:56-193,265-297,300-460
+  UNetEncoder (U22)           celldetection/models/unet.py:29-58
+  GeneralizedUNet decoder     celldetection/models/unet.py:62-249
+  FeaturePyramidNetwork       celldetection/models/fpn.py:79-134 (+ torchvision FPN.forward)
+  ReadOut heads / CPNCore     celldetection/models/commons.py:461-511, celldetection/models/cpn.py:126-283
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+
+__all__ = ['Plan', 'build_plan', 'BACKBONES']
+
+
+def _pad32(c):
+    return (int(c) + 31) // 32 * 32
+
+
+class Plan:
+    def __init__(self):
+        self.entries = []      # (key, shape, kind) kind in {'param', 'buffer', 'long'}
+        self.tensors = []      # dict(c=real channels, down=...)
+        self.ops = []          # IR dicts
+        self.meta = {}
+
+    # ---- state-dict entries
+    def conv_keys(self, prefix, cout, cin_g, k, bias):
+        self.entries.append((prefix + 'weight', (cout, cin_g, k, k), 'param'))
+        if bias:
+            self.entries.append((prefix + 'bias', (cout,), 'param'))
+
+    def bn_keys(self, prefix, c):
+        self.entries += [(prefix + 'weight', (c,), 'param'), (prefix + 'bias', (c,), 'param'),
+                         (prefix + 'running_mean', (c,), 'buffer'), (prefix + 'running_var', (c,), 'buffer'),
+                         (prefix + 'num_batches_tracked', (), 'long')]
+
+    # ---- IR
+    def tensor(self, c, down):
+        self.tensors.append(dict(c=int(c), down=int(down)))
+        return len(self.tensors) - 1
+
+    def conv(self, src0, cout, k, *, w, bn=None, bias=False, stride=1, pad=None, groups=1, act='none', act_scale=0.,
+             src1=None, up0=False, up1=False, res=None, res_up=False, out_index=None):
+        """Adds conv(+BN)(+residual)(+act); returns the destination tensor id (None for external outputs)."""
+        pad = k // 2 if pad is None else pad
+        t0 = self.tensors[src0]
+        down_in = t0['down'] // (2 if up0 else 1)
+        assert t0['down'] % (2 if up0 else 1) == 0
+        cin = t0['c'] + (self.tensors[src1]['c'] if src1 is not None else 0)
+        if src1 is not None:
+            assert self.tensors[src1]['down'] // (2 if up1 else 1) == down_in
+        down_out = down_in * stride
+        dst = self.tensor(cout, down_out) if out_index is None else None
+        self.conv_keys(w, cout, cin // groups, k, bias)
+        if bn is not None:
+            self.bn_keys(bn, cout)
+        self.ops.append(dict(op='conv', src0=src0, src1=src1, res=res, dst=dst, up0=up0, up1=up1, res_up=res_up, k=k,
+                             stride=stride, pad=pad, groups=groups, cin=cin, cout=cout, w=w, bn=bn, bias=bias, act=act,
+                             act_scale=act_scale, out_index=out_index))
+        return dst
+
+    def maxpool(self, src, k, stride, pad):
+        t = self.tensors[src]
+        dst = self.tensor(t['c'], t['down'] * stride)
+        self.ops.append(dict(op='maxpool', src0=src, dst=dst, k=k, stride=stride, pad=pad))
+        return dst
+
+    def bilinear_up2(self, src):
+        t = self.tensors[src]
+        assert t['down'] % 2 == 0
+        dst = self.tensor(t['c'], t['down'] // 2)
+        self.ops.append(dict(op='bilinear', src0=src, dst=dst))
+        return dst
+
+    def input(self, in_channels):
+        dst = self.tensor(in_channels, 1)
+        self.ops.append(dict(op='input', dst=dst, in_channels=in_channels))
+        return dst
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# encoders
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _two_conv_norm_relu(P, x, cout, prefix, bias=True, src1=None, up0=False, up1=False):
+    """TwoConvNormRelu (commons.py:120-149): Sequential(conv, bn, relu, conv, bn, relu) -> indices 0,1,3,4."""
+    x = P.conv(x, cout, 3, w=prefix + '0.', bn=prefix + '1.', bias=bias, act='relu', src1=src1, up0=up0, up1=up1)
+    return P.conv(x, cout, 3, w=prefix + '3.', bn=prefix + '4.', bias=bias, act='relu')
+
+
+def _unet_encoder(P, x, in_channels, prefix, depth=5, base_channels=64, factor=2, **unused):
+    """UNetEncoder (unet.py:29-58) with pool=True, TwoConvNormRelu blocks."""
+    feats, channels = [], []
+    for i in range(depth):
+        out_c = base_channels * (factor ** i)
+        if i == 0:
+            x = _two_conv_norm_relu(P, x, out_c, f'{prefix}0.')
+        else:
+            x = P.maxpool(x, 2, 2, 0)
+            x = _two_conv_norm_relu(P, x, out_c, f'{prefix}{i}.1.')
+        feats.append(x)
+        channels.append(out_c)
+    return feats, channels, [2 ** i for i in range(depth)]
+
+
+_RESNETS = {
+    # name: (block, layers, groups, base_width)
+    'ResNet18': ('basic', (2, 2, 2, 2), 1, 64), 'ResNet34': ('basic', (3, 4, 6, 3), 1, 64),
+    'ResNet50': ('bottle', (3, 4, 6, 3), 1, 64), 'ResNet101': ('bottle', (3, 4, 23, 3), 1, 64),
+    'ResNet152': ('bottle', (3, 8, 36, 3), 1, 64),
+    'ResNeXt50': ('bottle', (3, 4, 6, 3), 32, 4), 'ResNeXt101': ('bottle', (3, 4, 23, 3), 32, 8),
+    'ResNeXt152': ('bottle', (3, 8, 36, 3), 32, 8),
+    'WideResNet50': ('bottle', (3, 4, 6, 3), 1, 128), 'WideResNet101': ('bottle', (3, 4, 23, 3), 1, 128),
+}
+
+
+def _resnet(P, x, in_channels, prefix, kind, base_channel=64, **unused):
+    """ResNet(fused_initial=False) (resnet.py:265-297): body.0 = conv7x7 s2 + BN + ReLU (feature '0'),
+    body.1 = Sequential(MaxPool(3,2,1), layer1), body.2..4 = layer2..4; blocks per torchvision forward."""
+    block, layers, groups, base_width = _RESNETS[kind]
+    bc = base_channel
+    x = P.conv(x, bc, 7, w=prefix + '0.0.', bn=prefix + '0.1.', stride=2, pad=3, act='relu')
+    feats, channels = [x], [bc]
+    x = P.maxpool(x, 3, 2, 1)
+    inplanes = bc
+    expansion = 4 if block == 'bottle' else 1
+    for si in range(4):
+        planes = bc * (2 ** si)  # oc[si] // expansion
+        stage_prefix = f'{prefix}1.1.' if si == 0 else f'{prefix}{si + 1}.'
+        for j in range(layers[si]):
+            stride = 2 if (j == 0 and si > 0) else 1
+            p = f'{stage_prefix}{j}.'
+            has_ds = j == 0 and (stride != 1 or inplanes != planes * expansion)
+            if block == 'bottle':
+                width = int(planes * (base_width / 64.0)) * groups
+                t = P.conv(x, width, 1, w=p + 'conv1.', bn=p + 'bn1.', act='relu')
+                t = P.conv(t, width, 3, w=p + 'conv2.', bn=p + 'bn2.', stride=stride, groups=groups, act='relu')
+                # key order in the reference: conv3, bn3, then downsample -> emit conv3 keys before downsample keys
+                n_before = len(P.entries)
+                out_c = planes * expansion
+                if has_ds:
+                    # IR order: downsample must exist before conv3 (residual); entries order fixed afterwards
+                    idt = P.conv(x, out_c, 1, w=p + 'downsample.0.', bn=p + 'downsample.1.', stride=stride)
+                    ds_entries = P.entries[n_before:]
+                    del P.entries[n_before:]
+                else:
+                    idt, ds_entries = x, []
+                x = P.conv(t, out_c, 1, w=p + 'conv3.', bn=p + 'bn3.', res=idt, act='relu')
+                P.entries += ds_entries
+            else:
+                out_c = planes
+                n_before = len(P.entries)
+                if has_ds:
+                    idt = P.conv(x, out_c, 1, w=p + 'downsample.0.', bn=p + 'downsample.1.', stride=stride)
+                    ds_entries = P.entries[n_before:]
+                    del P.entries[n_before:]
+                else:
+                    idt, ds_entries = x, []
+                t = P.conv(x, planes, 3, w=p + 'conv1.', bn=p + 'bn1.', stride=stride, act='relu')
+                x = P.conv(t, planes, 3, w=p + 'conv2.', bn=p + 'bn2.', res=idt, act='relu')
+                P.entries += ds_entries
+            inplanes = planes * expansion
+        feats.append(x)
+        channels.append(inplanes)
+    return feats, channels, [2, 4, 8, 16, 32]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# decoders
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _generalized_unet(P, feats, channels, strides, prefix):
+    """GeneralizedUNet (unet.py:62-249), default kwargs: nearest interpolation, cat_order 0, TwoConvNormRelu blocks,
+    bridge blocks (bias=False) for the log2(first stride) missing levels.  The 1x1 ``inner`` conv is applied BEFORE
+    the nearest upsample (bit-identical per pixel, 4x fewer MACs); the upsample itself and the channel concat are
+    folded into the consumer conv's loader (up flag + two sources)."""
+    bridges = int(math.log2(strides[0]))
+    in_list = [0] * bridges + list(channels)
+    out_list = list(channels)  # out_channels_list is NOT extended for one bridge (unet.py:100-107)
+    if len(out_list) < len(channels) + bridges - 1:
+        out_list = [out_list[0]] * (len(channels) + bridges - 1 - len(out_list)) + out_list
+    n = len(in_list)
+    # entries: all inner_blocks first, then layer_blocks (torchvision FPN registers inner_blocks before layer_blocks)
+    inner = {}
+    for i in range(1, n):
+        ouc = out_list[i - 1]
+        inc = out_list[i] if i < n - 1 else in_list[i]
+        inner[i - 1] = (inc, ouc) if (inc > 0 and ouc < inc) else None
+    depth = n - 1
+    last = feats[-1]
+    results = {}
+    entries_inner, entries_layer = {}, {}
+    for i in range(depth - 1, -1, -1):
+        lat = feats[i - bridges] if (i - bridges) >= 0 else None
+        top = last
+        mark = len(P.entries)
+        if inner[i] is not None:
+            top = P.conv(top, inner[i][1], 1, w=f'{prefix}inner_blocks.{i}.', bias=True)
+        entries_inner[i] = P.entries[mark:]
+        del P.entries[mark:]
+        ouc = out_list[i]
+        if lat is not None:
+            last = _two_conv_norm_relu(P, lat, ouc, f'{prefix}layer_blocks.{i}.', bias=True, src1=top, up1=True)
+        else:
+            last = _two_conv_norm_relu(P, top, ouc, f'{prefix}layer_blocks.{i}.', bias=False, up0=True)
+        entries_layer[i] = P.entries[mark:]
+        del P.entries[mark:]
+        results[i] = last
+    for i in sorted(entries_inner):
+        P.entries += entries_inner[i]
+    for i in sorted(entries_layer):
+        P.entries += entries_layer[i]
+    return results, out_list
+
+
+def _fpn(P, feats, channels, prefix, fpn_channels):
+    """FeaturePyramidNetwork (fpn.py:79-134; forward = torchvision): ConvNorm(norm=Identity) 1x1 laterals with bias,
+    top-down nearest upsample + add (fused as an upsampled residual), 3x3 output convs.  Levels whose outputs the CPN
+    never reads (layer_blocks 2..4, 'pool') are skipped but their parameters stay in the state dict."""
+    n = len(feats)
+    lat_entries, out_entries = {}, {}
+    last = None
+    outs = {}
+    for idx in range(n - 1, -1, -1):
+        mark = len(P.entries)
+        last = P.conv(feats[idx], fpn_channels, 1, w=f'{prefix}inner_blocks.{idx}.0.', bias=True,
+                      res=last, res_up=last is not None)
+        lat_entries[idx] = P.entries[mark:]
+        del P.entries[mark:]
+        if idx <= 1:
+            outs[idx] = P.conv(last, fpn_channels, 3, w=f'{prefix}layer_blocks.{idx}.0.', bias=True)
+        else:  # dead level: keep the parameters only
+            P.conv_keys(f'{prefix}layer_blocks.{idx}.0.', fpn_channels, fpn_channels, 3, True)
+        out_entries[idx] = P.entries[mark:]
+        del P.entries[mark:]
+    for idx in range(n):
+        P.entries += lat_entries[idx]
+    for idx in range(n):
+        P.entries += out_entries[idx]
+    return outs
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# full CPN
+# ---------------------------------------------------------------------------------------------------------------------
+
+BACKBONES = {}
+for _k in _RESNETS:
+    BACKBONES[f'{_k}UNet'] = ('unet', _k)
+    BACKBONES[f'{_k}FPN'] = ('fpn', _k)
+BACKBONES['U22'] = ('unet', 'U22')
+
+
+def _readout(P, x, cmid, cout, prefix, act, act_scale, out_index, k=7):
+    """ReadOut (commons.py:461-511): conv kxk(bias) -> BN -> ReLU -> Dropout2d(eval: identity) -> conv 1x1(bias)."""
+    t = P.conv(x, cmid, k, w=prefix + 'block.0.', bn=prefix + 'block.1.', bias=True, act='relu')
+    P.conv(t, cout, 1, w=prefix + 'block.4.', bias=True, act=act, act_scale=act_scale, out_index=out_index)
+
+
+def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: int = 1, refinement: bool = True,
+               refinement_margin: float = 3., refinement_buckets: int = 1, order_weights: bool = True,
+               backbone_kwargs: dict = None) -> Plan:
+    """Plan of ``Cpn<backbone>`` (celldetection/models/cpn.py:287-439,771-2061)."""
+    if backbone not in BACKBONES:
+        raise ValueError(f'Unsupported backbone {backbone!r}; supported: {sorted(BACKBONES)}')
+    if score_channels != 1:
+        raise NotImplementedError('Only binary CPNs (classes in (1, 2)) are implemented on the HIP path.')
+    if refinement_buckets != 1:
+        raise NotImplementedError('refinement_buckets > 1 is not implemented on the HIP path.')
+    family, enc = BACKBONES[backbone]
+    bkw = dict(backbone_kwargs or {})
+    P = Plan()
+    if order_weights:
+        P.entries.append(('order_weights', (order, 1), 'buffer'))
+    x = P.input(in_channels)
+    bp = 'core.backbone.'
+    if enc == 'U22':
+        ekw = dict(bkw.get('backbone_kwargs') or {})
+        feats, channels, strides = _unet_encoder(P, x, in_channels, bp + 'body.', **ekw)
+    else:
+        ekw = dict(bkw.get('backbone_kwargs') or {})
+        feats, channels, strides = _resnet(P, x, in_channels, bp + 'body.', enc, **ekw)
+    if family == 'unet':
+        results, out_list = _generalized_unet(P, feats, channels, strides, bp + 'unet.')
+        f0, f1 = results[0], results[1]
+        c0, c1 = out_list[0], out_list[1]
+        scale = P.tensors[f1]['down']
+    else:
+        fc = bkw.get('fpn_channels', 256)
+        outs = _fpn(P, feats, channels, bp + 'fpn.', fc)
+        f0, f1 = outs[0], outs[1]
+        c0 = c1 = fc
+        scale = P.tensors[f1]['down']
+    _readout(P, f1, c1, score_channels, 'core.score_head.', 'sigmoid', 0., _lib.OUT_SCORES)
+    _readout(P, f1, c1, 2, 'core.location_head.', 'none', 0., _lib.OUT_LOCATIONS)
+    _readout(P, f1, c1, order * 4, 'core.fourier_head.', 'none', 0., _lib.OUT_FOURIER)
+    if refinement:
+        r = f0
+        while P.tensors[r]['down'] > 1:  # cpn.py:277-278: bilinear resize of the features to the input size
+            r = P.bilinear_up2(r)
+        _readout(P, r, c0, 2 * refinement_buckets, 'core.refinement_head.', 'tanh_scaled', float(refinement_margin),
+                 _lib.OUT_REFINEMENT)
+    P.meta = dict(backbone=backbone, order=order, head_down=scale, refinement=refinement, in_channels=in_channels)
+    return P
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# packing
+# ---------------------------------------------------------------------------------------------------------------------
+_ACT = {'none': _lib.ACT_NONE, 'relu': _lib.ACT_RELU, 'sigmoid': _lib.ACT_SIGMOID, 'tanh_scaled': _lib.ACT_TANH_SCALED}
+
+
+def _fold(sd, op):
+    """Conv weight/bias with eval-mode BatchNorm (eps 1e-5) folded in, float64 math."""
+    w = sd[op['w'] + 'weight'].detach().double().cpu()
+    cout = w.shape[0]
+    b = sd[op['w'] + 'bias'].detach().double().cpu() if op['bias'] else torch.zeros(cout, dtype=torch.float64)
+    if op['bn'] is not None:
+        g = sd[op['bn'] + 'weight'].detach().double().cpu()
+        beta = sd[op['bn'] + 'bias'].detach().double().cpu()
+        mu = sd[op['bn'] + 'running_mean'].detach().double().cpu()
+        var = sd[op['bn'] + 'running_var'].detach().double().cpu()
+        s = g / torch.sqrt(var + 1e-5)
+        w = w * s[:, None, None, None]
+        b = (b - mu) * s + beta
+    return w, b
+
+
+def _bundle_geometry(cin, cout, groups):
+    """(bundles, cin_b, cout_b, groups_per_bundle) or None when the grouped conv must be densified."""
+    if groups == 1:
+        return None
+    cig, cog = cin // groups, cout // groups
+    if cig != cog:
+        return None
+    bw = cig if cig % 32 == 0 else (32 if 32 % cig == 0 else None)
+    if bw is None or cin % bw:
+        return None
+    return cin // bw, bw, bw, bw // cig
+
+
+def pack(plan: Plan, state_dict, device):
+    """-> (tensor_descs, op_descs, weight_blob[bf16, device], bias_blob[f32, device])."""
+    tens = (_lib.TensorDesc * len(plan.tensors))()
+    for i, t in enumerate(plan.tensors):
+        tens[i].channels, tens[i].down = _pad32(t['c']), t['down']
+    ops = (_lib.OpDesc * len(plan.ops))()
+    wparts, bparts = [], []
+    woff = boff = 0
+    for i, op in enumerate(plan.ops):
+        d = ops[i]
+        d.src0 = d.src1 = d.res = d.dst = -1
+        d.bias_offset = -1
+        if op['op'] == 'input':
+            d.op, d.dst, d.in_channels = _lib.OP_INPUT, op['dst'], op['in_channels']
+            continue
+        if op['op'] == 'maxpool':
+            d.op, d.src0, d.dst = _lib.OP_MAXPOOL, op['src0'], op['dst']
+            d.kh = d.kw = op['k']
+            d.stride, d.pad = op['stride'], op['pad']
+            continue
+        if op['op'] == 'bilinear':
+            d.op, d.src0, d.dst = _lib.OP_BILINEAR, op['src0'], op['dst']
+            continue
+        # conv
+        w, b = _fold(state_dict, op)
+        k, groups, cin, cout = op['k'], op['groups'], op['cin'], op['cout']
+        c0 = plan.tensors[op['src0']]['c']
+        c0p = _pad32(c0)
+        c1 = plan.tensors[op['src1']]['c'] if op['src1'] is not None else 0
+        cinp = c0p + (_pad32(c1) if op['src1'] is not None else 0)
+        coutp = _pad32(cout)
+        geo = _bundle_geometry(cin, cout, groups)
+        if geo is None:
+            dense = torch.zeros(coutp, cinp, k, k, dtype=torch.float64)
+            if groups == 1:
+                dense[:cout, :c0] = w[:, :c0]
+                if c1:
+                    dense[:cout, c0p:c0p + c1] = w[:, c0:]
+            else:  # densified grouped conv (block diagonal)
+                cig, cog = cin // groups, cout // groups
+                for g in range(groups):
+                    dense[g * cog:(g + 1) * cog, g * cig:(g + 1) * cig] = w[g * cog:(g + 1) * cog]
+            bundles, cin_b, cout_b = 1, cinp, coutp
+            packed = dense.reshape(1, coutp, cinp // 32, 32, k * k).permute(0, 2, 4, 1, 3)
+            bias = torch.zeros(coutp, dtype=torch.float64)
+            bias[:cout] = b
+        else:
+            bundles, cin_b, cout_b, gpb = geo
+            cig = cin // groups
+            dense = torch.zeros(bundles, cout_b, cin_b, k, k, dtype=torch.float64)
+            wg = w.reshape(bundles, gpb, cig, cig, k, k)  # [bundle, group-in-bundle, cout_g, cin_g, k, k]
+            for g in range(gpb):
+                dense[:, g * cig:(g + 1) * cig, g * cig:(g + 1) * cig] = wg[:, g]
+            packed = dense.reshape(bundles, cout_b, cin_b // 32, 32, k * k).permute(0, 2, 4, 1, 3)
+            bias = b.clone()
+        wparts.append(packed.contiguous().reshape(-1).to(torch.bfloat16))
+        bparts.append(bias.to(torch.float32))
+        d.op = _lib.OP_CONV
+        d.src0 = op['src0']
+        d.src1 = -1 if op['src1'] is None else op['src1']
+        d.res = -1 if op['res'] is None else op['res']
+        d.dst = -1 if op['dst'] is None else op['dst']
+        d.up0, d.up1, d.res_up = int(op['up0']), int(op['up1']), int(op['res_up'])
+        d.c0_used = c0p if op['src1'] is not None else cinp
+        d.kh = d.kw = k
+        d.stride, d.pad = op['stride'], op['pad']
+        d.bundles, d.cin_b, d.cout_b = bundles, cin_b, cout_b
+        d.weight_offset, d.bias_offset = woff, boff
+        d.act, d.act_scale = _ACT[op['act']], float(op['act_scale'])
+        d.out_index = -1 if op['out_index'] is None else op['out_index']
+        d.cout_real = cout
+        woff += wparts[-1].numel() * 2
+        boff += bparts[-1].numel()
+        # keep blob offsets 16-byte aligned
+        padw = (-wparts[-1].numel()) % 8
+        if padw:
+            wparts.append(torch.zeros(padw, dtype=torch.bfloat16))
+            woff += padw * 2
+    wblob = torch.cat(wparts).to(device)
+    bblob = torch.cat(bparts).to(device)
+    return tens, ops, wblob, bblob
+
+
+def reference_flops(plan: Plan, H, W):
+    """2*MAC FLOPs of the reference graph per input (convs only, batch 1)."""
+    total = 0.
+    for op in plan.ops:
+        if op['op'] != 'conv':
+            continue
+        t0 = plan.tensors[op['src0']]
+        down_in = t0['down'] // (2 if op['up0'] else 1)
+        ho, wo = H // (down_in * op['stride']), W // (down_in * op['stride'])
+        f = 2. * ho * wo * op['cout'] * (op['cin'] // op['groups']) * op['k'] ** 2
+        # the reference runs the UNet inner 1x1 after the upsample (4x the pixels), unet.py:213-218
+        if 'inner_blocks' in op['w'] and '.unet.' in op['w']:
+            f *= 4
+        total += f
+    return total

@@ -1,0 +1,234 @@
+"""Host-side mirror of ``celldetection.ops`` for the CPN inference path, backed by libcpn_hip.so.
+
+Same names, argument meaning and return conventions as the reference (celldetection/ops/cpn.py, ops/boxes.py);
+tensors must live on the GPU -- there is no CPU fallback in the product path (the CPU restatement lives in
+``oracle/`` and is test infrastructure only).
+"""
+from ctypes import c_int64
+from typing import List
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+__all__ = ['fouriers2contours', 'local_refinement', 'nms', 'batched_box_nmsi', 'remove_border_contours',
+           'filter_contours_by_stitching_rule', 'compact_scores', 'decode_proposals', 'sampling_tables',
+           'NMS_BATCH_SIZE']
+
+NMS_BATCH_SIZE = 50000  # celldetection/ops/cpn.py:12
+
+_table_cache = {}
+
+
+def _need_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('celldetection_amd ops run on the MI355X only (got a CPU tensor); '
+                               'the CPU restatement is test infrastructure under oracle/.')
+
+
+def sampling_tables(order: int, samples: int, device):
+    """cos/sin tables exactly as the reference builds them on the CPU (celldetection/ops/cpn.py:66-78):
+    t = linspace(0, 1, S); c = float(pi) * 2 * k * t; cos(c), sin(c) -> [order, samples] fp32."""
+    key = (order, samples, str(device))
+    if key not in _table_cache:
+        t = torch.linspace(0, 1.0, samples)
+        c = float(np.pi) * 2 * (torch.arange(1, order + 1)[..., None]) * t[None]
+        if len(_table_cache) > 64:
+            _table_cache.clear()
+        _table_cache[key] = (torch.cos(c).contiguous().to(device), torch.sin(c).contiguous().to(device))
+    return _table_cache[key]
+
+
+def fouriers2contours(fourier: Tensor, locations: Tensor, samples: int = 64, sampling=None, cache=None):
+    """celldetection/ops/cpn.py:44-95 (default sampling only). fourier [..., order, 4], locations [..., 2]
+    -> (contours [..., samples, 2], sampling)."""
+    if sampling is not None:
+        raise NotImplementedError('custom sampling is a training-time feature (out of scope)')
+    _need_cuda(fourier, locations)
+    lead = fourier.shape[:-2]
+    order = fourier.shape[-2]
+    f = fourier.reshape(-1, order, 4).contiguous().float()
+    loc = locations.reshape(-1, 2).contiguous().float()
+    P = f.shape[0]
+    cos_t, sin_t = sampling_tables(order, samples, f.device)
+    out = torch.empty((P, samples, 2), dtype=torch.float32, device=f.device)
+    check(_lib.load().cpn_fouriers2contours(ptr(f), ptr(loc), P, order, samples, ptr(cos_t), ptr(sin_t), ptr(out),
+                                            stream_ptr()), 'fouriers2contours')
+    return out.reshape(*lead, samples, 2), torch.linspace(0, 1.0, samples, device=f.device)
+
+
+def local_refinement(contours: Tensor, refinement: Tensor, num_loops: int, b: Tensor, original_size=None):
+    """celldetection/models/cpn.py:63-85 with num_buckets == 1. contours [P,S,2], refinement [N,2,H,W], b [P]."""
+    _need_cuda(contours, refinement, b)
+    c = contours.contiguous().float().clone()
+    r = refinement.contiguous().float()
+    N, _, H, W = r.shape
+    if original_size is not None and tuple(original_size) != (H, W):
+        raise ValueError('refinement tensor must have the original size')
+    bi = b.to(torch.int32).contiguous()
+    check(_lib.load().cpn_local_refinement(ptr(c), ptr(bi), c.shape[0], c.shape[1], ptr(r), N, H, W, int(num_loops),
+                                           stream_ptr()), 'local_refinement')
+    return c
+
+
+def _nms_segments(boxes: Tensor, scores: Tensor, seg_offsets: List[int], thresh: float):
+    """-> (keep int64 [P] (per segment, relative indices written from the segment start), keep_counts list)."""
+    lib = _lib.load()
+    P = int(boxes.shape[0])
+    nseg = len(seg_offsets) - 1
+    dev = boxes.device
+    boxes = boxes.contiguous().float()
+    scores = scores.contiguous().float()
+    max_seg = max([seg_offsets[i + 1] - seg_offsets[i] for i in range(nseg)] + [0])
+    ws_bytes = int(lib.cpn_nms_workspace_bytes(P, max_seg, nseg))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    keep = torch.empty(max(P, 1), dtype=torch.int64, device=dev)
+    keep_counts = torch.empty(nseg, dtype=torch.int32, device=dev)
+    host = (c_int64 * (nseg + 1))(*seg_offsets)
+    dev_off = torch.tensor(seg_offsets, dtype=torch.int64, device=dev)
+    check(lib.cpn_nms(ptr(boxes), ptr(scores), P, host, ptr(dev_off), nseg, float(thresh), ptr(keep), ptr(keep_counts),
+                      ptr(ws), ws_bytes, stream_ptr()), 'nms')
+    return keep, keep_counts.cpu().tolist()
+
+
+def nms(boxes: Tensor, scores: Tensor, iou_threshold: float) -> Tensor:
+    """torch.ops.torchvision.nms semantics (greedy, stable descending score order, NaN IoU never suppresses);
+    returns kept indices (int64) in descending-score order.  Replaces celldetection/ops/cpn.py:211 and
+    celldetection_scripts/cpn_inference.py:407."""
+    _need_cuda(boxes, scores)
+    P = int(boxes.shape[0])
+    if P == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    keep, counts = _nms_segments(boxes, scores, [0, P], iou_threshold)
+    return keep[:counts[0]]
+
+
+def batched_box_nmsi(boxes: List[Tensor], scores: List[Tensor], iou_threshold: float, batch_size: int = None
+                     ) -> List[Tensor]:
+    """celldetection/ops/cpn.py:189-227 incl. the chunked path for > batch_size boxes.  All images that fit one
+    batch are processed by ONE segmented NMS launch sequence."""
+    assert len(scores) == len(boxes), 'The number of score tensors must match the number of box tensors.'
+    batch_size = NMS_BATCH_SIZE if batch_size is None else batch_size
+    keeps = [None] * len(boxes)
+    small = [i for i, b in enumerate(boxes) if b.shape[0] <= batch_size]
+    if small:
+        _need_cuda(*[boxes[i] for i in small])
+        sizes = [int(boxes[i].shape[0]) for i in small]
+        offs = [0]
+        for s in sizes:
+            offs.append(offs[-1] + s)
+        if offs[-1] > 0:
+            keep, counts = _nms_segments(torch.cat([boxes[i] for i in small]), torch.cat([scores[i] for i in small]),
+                                         offs, iou_threshold)
+            for j, i in enumerate(small):
+                keeps[i] = keep[offs[j]:offs[j] + counts[j]]
+        else:
+            for i in small:
+                keeps[i] = torch.empty((0,), dtype=torch.int64, device=boxes[i].device)
+    for i, (con, sco) in enumerate(zip(boxes, scores)):
+        if keeps[i] is not None:
+            continue
+        num = con.shape[0]
+        indices = torch.zeros(0, dtype=torch.long, device=con.device)
+        for s in range(0, num, batch_size):
+            e = min(s + batch_size, num)
+            indices = torch.cat((indices, nms(con[s:e], sco[s:e], iou_threshold) + s))
+        if indices.numel() > 0:
+            indices = indices[nms(con[indices], sco[indices], iou_threshold)]
+        keeps[i] = indices
+    return keeps
+
+
+def remove_border_contours(contours: Tensor, size, padding=1, top=True, right=True, bottom=True, left=True,
+                           offsets=None) -> Tensor:
+    """celldetection/ops/cpn.py:258-290 -> bool keep mask [num_contours]."""
+    _need_cuda(contours)
+    P, S = int(contours.shape[0]), int(contours.shape[1])
+    keep = torch.empty(P, dtype=torch.uint8, device=contours.device)
+    if P == 0:
+        return keep.bool()
+    h, w = size[:2]
+    ox = oy = 0.
+    if offsets is not None:
+        o = torch.as_tensor(offsets).flatten().tolist()
+        ox, oy = float(o[0]), float(o[1])
+    sides = (1 if top else 0) | (2 if right else 0) | (4 if bottom else 0) | (8 if left else 0)
+    c = contours.contiguous().float()
+    check(_lib.load().cpn_border_keep(ptr(c), P, S, ox, oy, float(h), float(w), float(padding), sides, ptr(keep),
+                                      stream_ptr()), 'remove_border_contours')
+    return keep.bool()
+
+
+def filter_contours_by_stitching_rule(contours: Tensor, tile_size, overlaps, rule='ex_br', offsets=None,
+                                      indices=False):
+    """celldetection/ops/cpn.py:293-325 (plain tensor arithmetic; not a hot spot)."""
+    if not isinstance(tile_size, Tensor):
+        tile_size = torch.as_tensor(tile_size, device=contours.device)
+    overlaps = torch.as_tensor(overlaps, device=contours.device)
+    if offsets is not None:
+        contours = contours + torch.as_tensor(offsets, device=contours.device)
+    if 'ex_br' in rule.split(','):
+        stop = (tile_size - overlaps[:, 1])[[1, 0]]
+        keep = ~((contours >= stop).any(-1).all(-1))
+    else:
+        raise ValueError(f'Unknown stitching rule: {rule}')
+    if indices:
+        keep, = torch.where(keep)
+    return keep
+
+
+def compact_scores(scores: Tensor, thresh: float, extra_flag: Tensor = None):
+    """Ordered (b, y, x) indices of ``scores > thresh`` (replaces torch.where, celldetection/models/cpn.py:616-620).
+    scores [N,1,h,w] fp32 -> (indices int32 [P] (device), per-image counts (host list), flag value or None).
+    One host sync (the D2H copy of the counts), like the reference's torch.where."""
+    _need_cuda(scores)
+    lib = _lib.load()
+    N, _, h, w = scores.shape
+    s = scores.contiguous().float()
+    dev = s.device
+    indices = torch.empty(N * h * w, dtype=torch.int32, device=dev)
+    counts = torch.empty(N + 1, dtype=torch.int32, device=dev)
+    ws = torch.empty(int(lib.cpn_compact_workspace_bytes(N, h, w)), dtype=torch.uint8, device=dev)
+    check(lib.cpn_compact(ptr(s), N, h, w, float(thresh), ptr(indices), ptr(counts), ptr(ws), stream_ptr()), 'compact')
+    if extra_flag is not None:
+        host = torch.cat((counts, extra_flag.reshape(1).to(torch.int32))).cpu().tolist()
+        flag = host.pop()
+    else:
+        host, flag = counts.cpu().tolist(), None
+    total = host[N]
+    return indices[:total], host[:N], flag
+
+
+def decode_proposals(indices: Tensor, scores: Tensor, locations: Tensor, fourier: Tensor, refinement, *, size,
+                     order: int, samples: int, iterations: int, offsets=None):
+    """Fused proposal decode (celldetection/models/cpn.py:613-702): gather + rel->abs locations + Fourier synthesis +
+    rescale + local refinement + clamp + boxes (+ offsets).  Returns a dict of flat [P, ...] tensors + 'b' [P]."""
+    _need_cuda(indices, scores, locations, fourier)
+    lib = _lib.load()
+    H, W = size
+    N, c4, h, w = fourier.shape
+    order_total = c4 // 4
+    P = int(indices.shape[0])
+    dev = fourier.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    out = dict(contours=torch.empty((P, samples, 2), **f32), contour_proposals=torch.empty((P, samples, 2), **f32),
+               boxes=torch.empty((P, 4), **f32), scores=torch.empty((P,), **f32), locations=torch.empty((P, 2), **f32),
+               fourier=torch.empty((P, order, 4), **f32), b=torch.empty((P,), dtype=torch.int32, device=dev))
+    if P == 0:
+        return out
+    cos_t, sin_t = sampling_tables(order, samples, dev)
+    offs = None
+    if offsets is not None:
+        offs = torch.as_tensor(offsets).to(device=dev, dtype=torch.int64).contiguous()
+        assert offs.shape == (N, 2), 'offsets must be Tensor[N, 2] (xy)'
+    ref = None if refinement is None else refinement.contiguous().float()
+    check(lib.cpn_decode(ptr(indices), P, ptr(scores.contiguous()), ptr(locations.contiguous()),
+                         ptr(fourier.contiguous()), ptr(ref), N, h, w, H, W, order_total, order, samples,
+                         int(iterations), ptr(cos_t), ptr(sin_t), ptr(offs), ptr(out['contours']),
+                         ptr(out['contour_proposals']), ptr(out['boxes']), ptr(out['scores']), ptr(out['locations']),
+                         ptr(out['fourier']), ptr(out['b']), stream_ptr()), 'decode')
+    return out

@@ -1,0 +1,138 @@
+"""Model (de)serialisation and tiling helpers of the reference's ``cd.util`` that sit on the inference path.
+
+File format = the reference's ``save_fetchable_model`` format (celldetection/util/util.py:545-560):
+``torch.save({'cd.__version__', 'cd.models': {'model': class_name, 'kwargs': hparams, 'updated_kwargs': {...}},
+'state_dict'})`` -- files written by the reference load here and vice versa.
+"""
+import os
+from itertools import product
+from os.path import isfile, splitext
+
+import numpy as np
+import torch
+
+__all__ = ['dict2model', 'model2dict', 'load_model', 'fetch_model', 'save_fetchable_model', 'get_tiling_slices',
+           'HOSTED_MODELS', 'HOST_TEMPLATE']
+
+HOST_TEMPLATE = 'https://celldetection.org/torch/models/{name}.pt'  # celldetection/models/hosted.py:1
+HOSTED_MODELS = {'ginoro': 'ginoro_CpnResNeXt101UNet-fbe875f1a3e5ce2c'}  # celldetection/models/hosted.py:2-4
+
+
+def dict2model(conf, updated_kwargs=True, **kwargs):
+    """celldetection/util/util.py:373-461 (class-name form and model-file form)."""
+    from . import cpn as src
+    if len(conf) == 1:
+        key, = conf.keys()
+        if key not in ('model', 'lightning_model') and getattr(src, key, None) is not None:
+            return getattr(src, key)(**conf[key])
+    kw = conf.get('kwargs', conf.get('kw', {}))
+    if updated_kwargs:
+        kw = {**kw, **conf.get('updated_kwargs', {})}
+    kw = {**kw, **kwargs}
+    name = conf.get('lightning_model', conf.get('model'))
+    assert name is not None, 'Config should define either ``lightning_model`` or ``model``.'
+    args = conf.get('args', conf.get('a', ()))
+    if isfile(name):
+        return load_model(name, **kw)
+    if hasattr(src, name):
+        return getattr(src, name)(*args, **kw)
+    return fetch_model(name, **kw)
+
+
+def _load_cd_format(m, pretrained=True, **kwargs):
+    """celldetection/util/util.py:464-472."""
+    assert isinstance(m, dict) and 'cd.models' in m.keys()
+    strict = kwargs.pop('pretrained_strict', True)
+    model = dict2model(m['cd.models'], **kwargs)
+    if pretrained:
+        model.load_state_dict(m['state_dict'], strict=strict)
+    return model
+
+
+def load_model(filename, map_location=None, **kwargs):
+    """celldetection/util/util.py:474-479."""
+    assert isfile(filename), f'Could not find file: {filename}'
+    load_kwargs = kwargs.pop('load_kwargs', {})
+    load_kwargs.setdefault('weights_only', False)
+    m = torch.load(filename, map_location=map_location or 'cpu', **load_kwargs)
+    if isinstance(m, dict) and 'cd.models' in m.keys():
+        model = _load_cd_format(m, **kwargs)
+        if map_location is not None and str(map_location) != 'cpu':
+            model = model.to(map_location)
+        return model
+    return m
+
+
+def fetch_model(name, map_location=None, **kwargs):
+    """celldetection/util/util.py:482-509.  There is no network on the target systems: a local file (or a file in
+    ``$CELLDETECTION_AMD_MODEL_DIR`` / the torch hub checkpoint cache named like the hosted model) is used."""
+    if name.startswith('cd://'):
+        name = name[len('cd://'):]
+    name = HOSTED_MODELS.get(name, name)
+    cands = [name] if isfile(name) else []
+    base = name if splitext(name)[1] in ('.pt', '.pth', '.ckpt') else name + '.pt'
+    for d in (os.environ.get('CELLDETECTION_AMD_MODEL_DIR'), os.path.join(torch.hub.get_dir(), 'checkpoints'), '.'):
+        if d and isfile(os.path.join(d, os.path.basename(base))):
+            cands.append(os.path.join(d, os.path.basename(base)))
+    if not cands:
+        if name.startswith('http'):
+            m = torch.hub.load_state_dict_from_url(name, map_location=map_location or 'cpu', weights_only=False)
+            return _load_cd_format(m, **kwargs) if isinstance(m, dict) and 'cd.models' in m else m
+        raise FileNotFoundError(f'Model {name!r} not found locally (searched $CELLDETECTION_AMD_MODEL_DIR, torch hub '
+                                f'cache, cwd) and cannot be downloaded from {HOST_TEMPLATE.format(name=name)} offline.')
+    return load_model(cands[0], map_location=map_location, **kwargs)
+
+
+def model2dict(model):
+    """celldetection/util/util.py:527-542."""
+    kwargs = dict(model.hparams)
+    updated = {}
+    for k, v in kwargs.items():
+        if k in model.__dict__:
+            cv = model.__dict__[k]
+            r = v != cv
+            if hasattr(r, 'any'):
+                r = r.any()
+            if r:
+                updated[k] = cv
+    return dict(model=model.__class__.__name__, kwargs=kwargs, updated_kwargs=updated)
+
+
+def save_fetchable_model(model, filename, **kwargs):
+    """celldetection/util/util.py:545-560 (without the hash suffix renaming)."""
+    if not len(splitext(filename)[1]):
+        filename += '.pt'
+    sd = OrderedDictCPU(model.state_dict())
+    torch.save({'cd.__version__': '0.4.9', 'cd.models': model2dict(model), 'state_dict': sd, **kwargs}, filename)
+    return filename
+
+
+def OrderedDictCPU(sd):
+    from collections import OrderedDict
+    return OrderedDict((k, v.detach().cpu()) for k, v in sd.items())
+
+
+def get_tiling_slices(size, crop_size, strides, return_overlaps=False):
+    """celldetection/util/util.py:1305-1354: the last tile per axis is shifted back so that all tiles are full-size;
+    overlaps = (overlap with previous tile, overlap with next tile) per axis.  Row-major cartesian product."""
+    assert isinstance(size, (tuple, list))
+    nd = len(size)
+    crop_size = (crop_size,) * nd if np.isscalar(crop_size) else tuple(crop_size)
+    strides = (strides,) * nd if np.isscalar(strides) else tuple(strides)
+    slices, shape, overlaps = [], [], []
+    for axis in range(nd):
+        if crop_size[axis] >= size[axis]:
+            tl = [size[axis]]
+        else:
+            tl = range(crop_size[axis], 1 + crop_size[axis] + int(np.ceil((size[axis] - crop_size[axis]) /
+                                                                        strides[axis])) * strides[axis], strides[axis])
+        stops = np.minimum(tl, size[axis])
+        starts = np.maximum(0, stops - crop_size[axis])
+        ov_start = np.concatenate((starts[:1], stops[:-1])) - starts
+        ov_end = np.concatenate((ov_start[1:], [0]))
+        slices.append([slice(int(a), int(b)) for a, b in zip(starts, stops)])
+        overlaps.append([[int(a), int(b)] for a, b in zip(ov_start, ov_end)])
+        shape.append(len(starts))
+    if return_overlaps:
+        return product(*slices), product(*overlaps), shape
+    return product(*slices), shape

@@ -88,6 +88,13 @@ double cpn_plan_executed_flops(cpn_plan *plan, int32_t N, int32_t H, int32_t W);
 int cpn_plan_run(cpn_plan *plan, const void *input, int32_t in_dtype, int32_t N, int32_t H, int32_t W,
                  void *workspace, int64_t workspace_bytes, float *const *outputs, int32_t *range_flag, void *stream);
 
+/* Profiling variant: brackets every op with HIP events on `stream`, synchronises, and returns the per-op duration
+ * (ms, op_ms[cpn_plan_num_ops]) and the executed MFMA FLOPs per op (op_flops, may be NULL). */
+int cpn_plan_num_ops(cpn_plan *plan);
+int cpn_plan_run_timed(cpn_plan *plan, const void *input, int32_t in_dtype, int32_t N, int32_t H, int32_t W,
+                       void *workspace, int64_t workspace_bytes, float *const *outputs, int32_t *range_flag,
+                       void *stream, float *op_ms, double *op_flops);
+
 /* Single convolution (testing / building blocks); same semantics as one CPN_OP_CONV. */
 int cpn_conv2d(const cpn_op_desc *op, const void *src0, int32_t c0_stride, const void *src1, int32_t c1_stride,
                const void *res, int32_t res_stride, void *dst, int32_t dst_stride, int32_t N, int32_t Hin, int32_t Win,

@@ -326,7 +326,8 @@ def cpn_postprocess(scores_raw, locations, refinement, fourier, *, input_size, o
     Args are fp32 NCHW numpy arrays (or tensors).  Returns an OrderedDict of per-image lists like the reference.
     """
     to_np = lambda t: t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
-    scores_raw, locations, refinement, fourier = map(to_np, (scores_raw, locations, refinement, fourier))
+    scores_raw, locations, fourier = map(to_np, (scores_raw, locations, fourier))
+    refinement = None if refinement is None else to_np(refinement)
     H, W = input_size
     n, c, h, w = fourier.shape
     if scores_are_probabilities:

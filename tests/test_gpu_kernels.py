@@ -1,0 +1,297 @@
+"""GPU parity tests of the individual HIP kernels, called through the C ABI (ctypes).
+
+* conv / pool / resize / input conversion: floating point -> compared with a plain PyTorch fp32 CPU reference of
+  the same op on the same bf16-rounded operands (tolerance = bf16 output rounding + fp32 accumulation order).
+* compaction / decode / refinement / NMS / border filter: compared bit-exactly with the CPU oracle and with the
+  golden vectors generated from the reference.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    return torch.device('cuda:0')
+
+
+def _pad32(c):
+    return (c + 31) // 32 * 32
+
+
+def to_nhwc_bf16(x, cpad=None):
+    """NCHW fp32 -> NHWC bf16 with zero-padded channels."""
+    n, c, h, w = x.shape
+    cpad = cpad or _pad32(c)
+    out = torch.zeros(n, h, w, cpad, dtype=torch.bfloat16, device=x.device)
+    out[..., :c] = x.permute(0, 2, 3, 1).to(torch.bfloat16)
+    return out.contiguous()
+
+
+def from_nhwc(y, c):
+    return y[..., :c].permute(0, 3, 1, 2).float()
+
+
+def run_conv(dev, *, n, h, w, cin, cout, k, stride=1, groups=1, bias=True, bn=True, act='relu', cin1=0, up0=False,
+             up1=False, res=False, res_up=False, out_f32=False, act_scale=3., seed=0):
+    """Builds a one-conv plan, runs cpn_conv2d, returns (got, ref) as fp32 NCHW CPU tensors."""
+    from celldetection_amd import _lib, graph
+    g = torch.Generator().manual_seed(seed)
+    P = graph.Plan()
+    hin, win = h, w
+    s0 = P.tensor(cin, 2 if up0 else 1)
+    s1 = P.tensor(cin1, 2 if up1 else 1) if cin1 else None
+    r = P.tensor(cout, (2 if res_up else 1) * stride) if res else None
+    P.conv(s0, cout, k, w='c.', bn='b.' if bn else None, bias=bias, stride=stride, groups=groups, act=act,
+           act_scale=act_scale, src1=s1, up0=up0, up1=up1, res=r, res_up=res_up,
+           out_index=_lib.OUT_SCORES if out_f32 else None)
+    sd = {}
+    for key, shape, kind in P.entries:
+        if key.endswith('running_var'):
+            sd[key] = torch.rand(shape, generator=g) + .5
+        elif key.endswith('num_batches_tracked'):
+            sd[key] = torch.zeros((), dtype=torch.long)
+        elif len(shape) == 4:
+            sd[key] = torch.randn(shape, generator=g) / np.sqrt(np.prod(shape[1:]))
+        else:
+            sd[key] = torch.randn(shape, generator=g) * .5 + (1. if key.endswith('b.weight') else 0.)
+    tens, ops, wblob, bblob = graph.pack(P, sd, dev)
+    op = ops[0]
+
+    def mk(c, hh, ww):
+        return (torch.randn(n, c, hh, ww, generator=g)).to(torch.bfloat16).float()
+
+    x0 = mk(cin, hin // 2 if up0 else hin, win // 2 if up0 else win)
+    x1 = mk(cin1, hin // 2 if up1 else hin, win // 2 if up1 else win) if cin1 else None
+    ho, wo = (hin + 2 * (k // 2) - k) // stride + 1, (win + 2 * (k // 2) - k) // stride + 1
+    xr = mk(cout, ho // 2 if res_up else ho, wo // 2 if res_up else wo) if res else None
+    d0 = to_nhwc_bf16(x0.to(dev))
+    d1 = to_nhwc_bf16(x1.to(dev)) if cin1 else None
+    dr = to_nhwc_bf16(xr.to(dev)) if res else None
+    lib = _lib.load()
+    if out_f32:
+        dst = torch.full((n, cout, ho, wo), float('nan'), dtype=torch.float32, device=dev)
+        dstride = 0
+    else:
+        dst = torch.full((n, ho, wo, _pad32(cout)), float('nan'), dtype=torch.bfloat16, device=dev)
+        dstride = _pad32(cout)
+    _lib.check(lib.cpn_conv2d(op, _lib.ptr(d0), d0.shape[-1], _lib.ptr(d1), 0 if d1 is None else d1.shape[-1],
+                              _lib.ptr(dr), 0 if dr is None else dr.shape[-1], _lib.ptr(dst), dstride, n, hin, win,
+                              _lib.ptr(wblob), _lib.ptr(bblob), _lib.stream_ptr()), 'conv2d')
+    torch.cuda.synchronize()
+    got = dst.cpu() if out_f32 else from_nhwc(dst.cpu(), cout)
+    # ---- reference: fp32 conv on the same bf16-rounded operands with the folded weights
+    wf, bf = graph._fold(sd, P.ops[0])
+    wf = wf.float().to(torch.bfloat16).float()
+    xin = F.interpolate(x0, scale_factor=2, mode='nearest') if up0 else x0
+    if cin1:
+        xin = torch.cat((xin, F.interpolate(x1, scale_factor=2, mode='nearest') if up1 else x1), 1)
+    ref = F.conv2d(xin, wf, bf.float(), stride, k // 2, 1, groups)
+    if res:
+        ref = ref + (F.interpolate(xr, scale_factor=2, mode='nearest') if res_up else xr)
+    if act == 'relu':
+        ref = F.relu(ref)
+    elif act == 'sigmoid':
+        ref = torch.sigmoid(ref)
+    elif act == 'tanh_scaled':
+        ref = torch.tanh(ref) * act_scale
+    return got, ref, out_f32
+
+
+CONV_CASES = {
+    '1x1_64_64': dict(n=2, h=32, w=32, cin=64, cout=64, k=1),
+    '1x1_flat_narrow': dict(n=4, h=16, w=16, cin=128, cout=256, k=1, act='none'),
+    '1x1_res': dict(n=1, h=32, w=64, cin=96, cout=128, k=1, res=True),
+    '1x1_s2': dict(n=2, h=32, w=32, cin=64, cout=128, k=1, stride=2, act='none'),
+    '3x3_64_64': dict(n=2, h=32, w=32, cin=64, cout=64, k=3),
+    '3x3_odd_channels': dict(n=1, h=32, w=64, cin=8, cout=24, k=3),
+    '3x3_256_big_tile': dict(n=1, h=64, w=64, cin=64, cout=256, k=3),
+    '3x3_s2': dict(n=2, h=64, w=64, cin=32, cout=64, k=3, stride=2),
+    '3x3_grouped_cpg8': dict(n=1, h=32, w=32, cin=256, cout=256, k=3, groups=32),
+    '3x3_grouped_cpg64_s2': dict(n=1, h=32, w=32, cin=128, cout=128, k=3, groups=2, stride=2),
+    '3x3_grouped_cpg1': dict(n=1, h=32, w=32, cin=32, cout=32, k=3, groups=32),
+    '3x3_concat_up': dict(n=2, h=32, w=32, cin=64, cout=64, k=3, cin1=128, up1=True),
+    '3x3_concat_up_pad': dict(n=1, h=32, w=32, cin=8, cout=16, k=3, cin1=16, up1=True),
+    '3x3_bridge_up0': dict(n=1, h=64, w=64, cin=64, cout=64, k=3, up0=True, bias=False),
+    '1x1_fpn_lateral': dict(n=2, h=32, w=32, cin=64, cout=256, k=1, res=True, res_up=True, bn=False, act='none'),
+    '7x7_head': dict(n=1, h=32, w=64, cin=64, cout=64, k=7),
+    '7x7_head_256': dict(n=1, h=32, w=32, cin=256, cout=256, k=7),
+    '7x7_stem_s2': dict(n=2, h=64, w=64, cin=3, cout=64, k=7, stride=2, bias=False),
+    'final_sigmoid': dict(n=2, h=32, w=32, cin=64, cout=1, k=1, bn=False, act='sigmoid', out_f32=True),
+    'final_tanh': dict(n=1, h=64, w=32, cin=64, cout=2, k=1, bn=False, act='tanh_scaled', out_f32=True),
+    'final_fourier': dict(n=1, h=32, w=32, cin=128, cout=20, k=1, bn=False, act='none', out_f32=True),
+}
+
+
+@pytest.mark.parametrize('name', list(CONV_CASES))
+def test_conv(dev, name):
+    got, ref, f32 = run_conv(dev, **CONV_CASES[name])
+    assert got.shape == ref.shape
+    assert torch.isfinite(got).all(), f'{name}: non-finite outputs ({(~torch.isfinite(got)).sum().item()})'
+    err = (got - ref).abs()
+    scale = ref.abs().max().item() + 1e-6
+    tol = (2e-3 if f32 else 1e-2) * max(scale, 1.)  # bf16 output rounding: 2^-9 relative
+    bad = (err > tol + (0 if f32 else 8e-3) * ref.abs()).sum().item()
+    print(f'{name}: max abs err {err.max().item():.3e} (ref max {scale:.3e}), mean {err.mean().item():.3e}, bad {bad}')
+    assert bad == 0, f'{name}: {bad} / {err.numel()} elements off; max abs err {err.max().item():.4e}, ref max {scale:.3e}'
+
+
+def test_maxpool_bilinear_input(dev):
+    from celldetection_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 40, 32, 64, generator=g).to(torch.bfloat16).float()
+    d = to_nhwc_bf16(x.to(dev), 64)
+    for k, s, p in ((3, 2, 1), (2, 2, 0)):
+        ho, wo = (32 + 2 * p - k) // s + 1, (64 + 2 * p - k) // s + 1
+        out = torch.empty(2, ho, wo, 64, dtype=torch.bfloat16, device=dev)
+        _lib.check(lib.cpn_maxpool2d(_lib.ptr(d), _lib.ptr(out), 2, 32, 64, 64, k, s, p, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        ref = F.max_pool2d(x, k, s, p)
+        assert torch.equal(from_nhwc(out.cpu(), 40), ref), f'maxpool {k}/{s}/{p}'
+    out = torch.empty(2, 64, 128, 64, dtype=torch.bfloat16, device=dev)
+    _lib.check(lib.cpn_resize_bilinear(_lib.ptr(d), _lib.ptr(out), 2, 32, 64, 64, 128, 64, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    ref = F.interpolate(x, (64, 128), mode='bilinear', align_corners=False)
+    err = (from_nhwc(out.cpu(), 40) - ref).abs().max().item()
+    assert err < 2e-2, f'bilinear max err {err}'
+    # input conversion + range flag
+    xin = torch.rand(2, 3, 32, 64, generator=g)
+    for dtype in (0, 1):
+        src = xin.to(dev) if dtype == 0 else (xin * 255).to(torch.uint8).to(dev)
+        out = torch.full((2, 32, 64, 32), 7., dtype=torch.bfloat16, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(lib.cpn_convert_input(_lib.ptr(src.contiguous()), dtype, _lib.ptr(out), 2, 3, 32, 64, 32,
+                                         _lib.ptr(flag), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        exp = xin if dtype == 0 else (xin * 255).to(torch.uint8).float() / 255
+        assert torch.equal(from_nhwc(out.cpu(), 3), exp.to(torch.bfloat16).float())
+        assert out[..., 3:].abs().max().item() == 0 and flag.item() == 0
+    bad = xin.clone()
+    bad[1, 2, 5, 5] = 1.5
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(lib.cpn_convert_input(_lib.ptr(bad.to(dev)), 0, _lib.ptr(out), 2, 3, 32, 64, 32, _lib.ptr(flag),
+                                     _lib.stream_ptr()))
+    assert flag.item() == 1
+
+
+# ------------------------------------------------------------------------------------------------------------
+# decode / NMS: bit-exact vs oracle + golden
+# ------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def gops():
+    return np.load(os.path.join(G, 'ops.npz'))
+
+
+@pytest.mark.parametrize('tag,samples', [('a', 32), ('b', 128), ('c', 7), ('d', 64)])
+def test_fouriers2contours_golden(dev, gops, tag, samples):
+    from celldetection_amd import ops
+    out, _ = ops.fouriers2contours(torch.as_tensor(gops[f'f2c_{tag}_fourier']).to(dev),
+                                   torch.as_tensor(gops[f'f2c_{tag}_loc']).to(dev), samples=samples)
+    np.testing.assert_array_equal(out.cpu().numpy(), gops[f'f2c_{tag}_out'])
+
+
+def test_local_refinement_golden(dev, gops):
+    from celldetection_amd import ops
+    for iters in (1, 4):
+        out = ops.local_refinement(torch.as_tensor(gops['refine_in']).to(dev), torch.as_tensor(gops['refine_map']).to(dev),
+                                   iters, torch.as_tensor(gops['refine_b']).to(dev))
+        np.testing.assert_array_equal(out.cpu().numpy(), gops[f'refine_out_{iters}'])
+
+
+@pytest.mark.parametrize('thr', [.2, .5, 0.])
+def test_nms_golden(dev, gops, thr):
+    from celldetection_amd import ops
+    keep = ops.nms(torch.as_tensor(gops['nms_boxes']).to(dev), torch.as_tensor(gops['nms_scores']).to(dev), thr)
+    np.testing.assert_array_equal(keep.cpu().numpy(), gops[f'nms_keep_{thr}'])
+
+
+def test_nmsi_golden(dev, gops):
+    from celldetection_amd import ops
+    b, s = torch.as_tensor(gops['nms_boxes']).to(dev), torch.as_tensor(gops['nms_scores']).to(dev)
+    keep = ops.batched_box_nmsi([b], [s], .2, batch_size=128)[0]
+    np.testing.assert_array_equal(keep.cpu().numpy(), gops['nmsi_chunked_keep'])
+    keeps = ops.batched_box_nmsi([b, b[:50], b[:0]], [s, s[:50], s[:0]], .2)
+    np.testing.assert_array_equal(keeps[0].cpu().numpy(), gops['nms_keep_0.2'])
+    np.testing.assert_array_equal(keeps[1].cpu().numpy(), gops['nmsi_plain_keep'])
+    assert keeps[2].numel() == 0
+
+
+def test_border_golden(dev, gops):
+    from celldetection_amd import ops
+    con = torch.as_tensor(gops['border_in']).to(dev)
+    flags = [(True, True, True, True), (False, True, False, True), (True, False, True, False)]
+    for i, (top, right, bottom, left) in enumerate(flags):
+        keep = ops.remove_border_contours(con, (48, 64), 4, top=top, right=right, bottom=bottom, left=left,
+                                          offsets=torch.as_tensor(gops['border_offsets']))
+        np.testing.assert_array_equal(keep.cpu().numpy(), gops[f'border_keep_{i}'])
+    keep = ops.filter_contours_by_stitching_rule(con, (48, 64), torch.as_tensor(gops['stitch_overlaps']),
+                                                 offsets=torch.as_tensor(gops['border_offsets']).to(dev))
+    np.testing.assert_array_equal(keep.cpu().numpy(), gops['stitch_keep'])
+
+
+@pytest.mark.parametrize('P,nseg', [(1, 1), (63, 1), (64, 1), (65, 2), (1000, 3), (5000, 4), (20000, 1)])
+def test_nms_random_vs_oracle(dev, P, nseg):
+    """Random boxes with many overlaps / ties / degenerate boxes; segmented NMS vs per-segment oracle."""
+    import cpn_oracle as orc
+    from celldetection_amd import ops
+    rng = np.random.default_rng(P)
+    xy = rng.uniform(0, 200 if P > 2000 else 60, (P, 2)).astype(np.float32)
+    wh = rng.uniform(0, 20, (P, 2)).astype(np.float32)
+    boxes = np.concatenate((xy, xy + wh), 1)
+    boxes[::17, 2:] = boxes[::17, :2]  # zero-area
+    scores = rng.random(P).astype(np.float32)
+    scores[::5] = scores[0]  # ties
+    cuts = sorted(rng.integers(0, P + 1, nseg - 1).tolist())
+    offs = [0] + cuts + [P]
+    bl = [torch.as_tensor(boxes[offs[i]:offs[i + 1]]).to(dev) for i in range(nseg)]
+    sl = [torch.as_tensor(scores[offs[i]:offs[i + 1]]).to(dev) for i in range(nseg)]
+    keeps = ops.batched_box_nmsi(bl, sl, .3)
+    for i in range(nseg):
+        exp = orc.nms(boxes[offs[i]:offs[i + 1]], scores[offs[i]:offs[i + 1]], .3)
+        np.testing.assert_array_equal(keeps[i].cpu().numpy(), exp, err_msg=f'segment {i}')
+
+
+@pytest.mark.parametrize('shape,density', [((2, 32, 48), .1), ((3, 17, 23), .5), ((1, 64, 64), 0.), ((2, 16, 16), 1.),
+                                           ((16, 256, 256), .02)])
+def test_compact_and_decode_vs_oracle(dev, shape, density):
+    """Synthetic head maps -> HIP compaction + fused decode (+offsets) == oracle post-processing, bit-exact."""
+    import cpn_oracle as orc
+    from celldetection_amd import ops
+    n, h, w = shape
+    H, W = 2 * h, 2 * w
+    g = torch.Generator().manual_seed(h * w)
+    order, samples = 6, 33
+    scores = torch.rand(n, 1, h, w, generator=g)
+    thr = 1. - density if density > 0 else 2.
+    if density >= 1.:
+        thr = -1.
+    loc = torch.randn(n, 2, h, w, generator=g)
+    fourier = torch.randn(n, 4 * order, h, w, generator=g) * 4
+    ref = (torch.rand(n, 2, H, W, generator=g) * 2 - 1) * 3
+    offsets = torch.randint(-50, 5000, (n, 2), generator=g)
+    idx, counts, _ = ops.compact_scores(scores.to(dev), thr)
+    flat = ops.decode_proposals(idx, scores.to(dev), loc.to(dev), fourier.to(dev), ref.to(dev), size=(H, W),
+                                order=order - 1, samples=samples, iterations=3, offsets=offsets)
+    exp = orc.cpn_postprocess(scores, loc, ref, fourier, input_size=(H, W), order=order - 1, samples=samples,
+                              score_thresh=thr, refinement_iterations=3, nms=False, offsets=offsets.numpy(),
+                              scores_are_probabilities=True)
+    assert counts == [len(e) for e in exp['scores']]
+    for k in ('contours', 'boxes', 'scores', 'locations', 'fourier', 'contour_proposals'):
+        np.testing.assert_array_equal(flat[k].cpu().numpy(), np.concatenate(exp[k]), err_msg=k)
+    # no refinement: proposals alias clamped contours
+    flat = ops.decode_proposals(idx, scores.to(dev), loc.to(dev), fourier.to(dev), None, size=(H, W), order=order,
+                                samples=samples, iterations=0)
+    exp = orc.cpn_postprocess(scores, loc, None, fourier, input_size=(H, W), order=order, samples=samples,
+                              score_thresh=thr, refinement_iterations=0, nms=False, scores_are_probabilities=True)
+    for k in ('contours', 'boxes', 'contour_proposals'):
+        np.testing.assert_array_equal(flat[k].cpu().numpy(), np.concatenate(exp[k]), err_msg='norefine ' + k)

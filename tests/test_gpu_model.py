@@ -1,0 +1,155 @@
+"""GPU parity tests of the whole path (through libcpn_hip.so) against golden vectors from the reference.
+
+Stage-wise parity (SURVEY section 7 "hard parts"):
+  (a) conv stack (bf16 MFMA) vs the reference's fp32 head maps: tolerance (bf16 activations/weights);
+  (b) post-processing on the REFERENCE's head maps: index sets bit-exact, coordinates within 1e-4;
+  (c) end-to-end: detections matched by IoU against the reference's (match rate).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from model_specs import MODEL_SPECS
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+KEYS = ('contours', 'boxes', 'scores', 'classes', 'locations', 'fourier', 'contour_proposals')
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    return torch.device('cuda:0')
+
+
+def build(name, dev, fixture=None):
+    import celldetection_amd as cda
+    from celldetection_amd.synth import synth_state_dict
+    spec = MODEL_SPECS[name]
+    g = np.load(os.path.join(G, fixture or f'model_{name}.npz'))
+    model = getattr(cda.models, spec['cls'])(**spec['kwargs'])
+    assert list(model.state_dict().keys()) == [str(k) for k in g['sd_keys']]
+    overrides = {k[len('override.'):]: torch.as_tensor(g[k]) for k in g.files if k.startswith('override.')}
+    model.load_state_dict(synth_state_dict(model.state_dict(), seed=int(g['seed']) if 'seed' in g.files else 0,
+                                           overrides=overrides))
+    return model.to(dev), g
+
+
+def check_exact(prefix, y, g, n):
+    for k in KEYS:
+        for i in range(n):
+            exp, got = g[f'{prefix}.{k}.{i}'], y[k][i].cpu().numpy()
+            assert got.shape == exp.shape, (prefix, k, i, got.shape, exp.shape)
+            if k == 'classes':
+                np.testing.assert_array_equal(got, exp)
+            else:
+                np.testing.assert_allclose(got, exp, rtol=0, atol=1e-4, err_msg=f'{prefix}.{k}.{i}')
+
+
+@pytest.mark.parametrize('name', list(MODEL_SPECS))
+def test_postprocess_on_reference_head_maps(dev, name):
+    """(b): decode -> refinement -> boxes -> NMS on the reference's fp32 head maps is exact."""
+    model, g = build(name, dev)
+    x = g['x']
+    n, size = x.shape[0], tuple(x.shape[-2:])
+    maps = [torch.sigmoid(torch.as_tensor(g['core.scores'])).to(dev), torch.as_tensor(g['core.locations']).to(dev),
+            torch.as_tensor(g['core.refinement']).to(dev), torch.as_tensor(g['core.fourier']).to(dev)]
+    check_exact('nms', model.postprocess(*maps, size), g, n)
+    check_exact('nonms', model.postprocess(*maps, size, nms=False), g, n)
+    check_exact('offs', model.postprocess(*maps, size, offsets=torch.as_tensor(g['offsets'])), g, n)
+    y = model.postprocess(*maps, size, scores_upper_bound=torch.as_tensor(g['scores_upper_bound']).to(dev),
+                          scores_lower_bound=torch.as_tensor(g['scores_lower_bound']).to(dev))
+    for i in range(n):  # bilinear mask resize runs in torch on the GPU: counts must agree, values to 1e-4
+        assert abs(len(y['scores'][i]) - len(g[f'bounds.scores.{i}'])) <= 1
+    if name == 'CpnU22':
+        model.samples, model.refinement_iterations, model.score_thresh, model.nms_thresh = 17, 2, .7, .5
+        check_exact('attr', model.postprocess(*maps, size), g, n)
+        model.order = 3
+        check_exact('attr_order3', model.postprocess(*maps, size), g, n)
+
+
+@pytest.mark.parametrize('name', list(MODEL_SPECS))
+def test_conv_stack_vs_reference_maps(dev, name):
+    """(a): bf16 MFMA conv stack vs the reference's fp32 maps (and implicitly vs the oracle, pinned to them)."""
+    model, g = build(name, dev)
+    x = torch.as_tensor(g['x']).to(dev)
+    s, l, r, f = [t.cpu() for t in model.core_forward(x)]
+    torch.cuda.synchronize()
+    exp = dict(scores=torch.sigmoid(torch.as_tensor(g['core.scores'])), locations=torch.as_tensor(g['core.locations']),
+               refinement=torch.as_tensor(g['core.refinement']), fourier=torch.as_tensor(g['core.fourier']))
+    report = {}
+    for key, got in (('scores', s), ('locations', l), ('refinement', r), ('fourier', f)):
+        e = exp[key]
+        assert got.shape == e.shape
+        assert torch.isfinite(got).all(), key
+        err = (got - e).abs()
+        # relative L2 error of the map; bf16 (8 mantissa bits) through O(10..100) layers
+        rel = (err.norm() / (e.norm() + 1e-12)).item()
+        report[key] = (rel, err.max().item(), e.abs().max().item())
+    print(name, {k: f'relL2 {v[0]:.3e} max {v[1]:.3e} (ref max {v[2]:.2e})' for k, v in report.items()})
+    for key, (rel, mx, ref_mx) in report.items():
+        assert rel < 6e-2, f'{name} {key}: relative L2 error {rel:.3e}'
+
+
+def _iou_match_rate(boxes_a, boxes_b, thr=.5):
+    if len(boxes_a) == 0 or len(boxes_b) == 0:
+        return 1. if len(boxes_a) == len(boxes_b) else 0.
+    a, b = torch.as_tensor(boxes_a), torch.as_tensor(boxes_b)
+    lt = torch.max(a[:, None, :2], b[None, :, :2])
+    rb = torch.min(a[:, None, 2:], b[None, :, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    area = lambda t: (t[:, 2] - t[:, 0]) * (t[:, 3] - t[:, 1])
+    iou = inter / (area(a)[:, None] + area(b)[None] - inter + 1e-9)
+    return float(((iou.max(1).values > thr).float().mean() + (iou.max(0).values > thr).float().mean()) / 2)
+
+
+@pytest.mark.parametrize('name', list(MODEL_SPECS))
+def test_end_to_end_match_rate(dev, name):
+    """(c): full HIP forward vs the reference's detections (bf16 => IoU-matched, not bit-exact)."""
+    model, g = build(name, dev)
+    x = torch.as_tensor(g['x']).to(dev)
+    y = model(x, nms=False)
+    rates = []
+    for i in range(x.shape[0]):
+        rates.append(_iou_match_rate(y['boxes'][i].cpu().numpy(), g[f'nonms.boxes.{i}']))
+        n_ref, n_got = len(g[f'nonms.scores.{i}']), len(y['scores'][i])
+        assert abs(n_ref - n_got) <= max(3, 0.25 * n_ref), f'{name}[{i}]: proposals {n_got} vs reference {n_ref}'
+    print(name, 'proposal IoU>0.5 match rates', rates)
+    assert min(rates) > .7, rates
+    y = model(x)  # with NMS: output contract
+    assert list(y.keys()) == ['contours', 'boxes', 'scores', 'classes', 'locations', 'fourier', 'contour_proposals',
+                              'box_uncertainties']
+    assert y['box_uncertainties'] is None and len(y['contours']) == x.shape[0]
+    s = MODEL_SPECS[name]['cpn_kwargs']['samples']
+    assert y['contours'][0].shape[1:] == (s, 2) and y['classes'][0].dtype == torch.int64
+
+
+def test_input_range_assert_and_uint8(dev):
+    model, g = build('CpnU22', dev)
+    x = torch.as_tensor(g['x']).to(dev)
+    bad = x.clone()
+    bad[0, 0, 0, 0] = 1.5
+    with pytest.raises(AssertionError, match='Inputs should be in interval'):
+        model(bad)
+    with pytest.raises(RuntimeError):
+        model(x.cpu())
+    u8 = (x * 255).to(torch.uint8)
+    a = model.core_forward(u8)
+    b = model.core_forward(u8.float() / 255)
+    for p, q in zip(a, b):
+        assert torch.equal(p, q)
+
+
+def test_fetchable_model_roundtrip(dev, tmp_path):
+    import celldetection_amd as cda
+    model, g = build('CpnU22', dev)
+    f = cda.save_fetchable_model(model, str(tmp_path / 'tiny_CpnU22'))
+    m2 = cda.load_model(f, map_location=dev)
+    assert type(m2).__name__ == 'CpnU22' and m2.hparams['backbone_kwargs'] == model.hparams['backbone_kwargs']
+    x = torch.as_tensor(g['x']).to(dev)
+    for p, q in zip(model.core_forward(x), m2.core_forward(x)):
+        assert torch.equal(p, q)
