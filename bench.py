@@ -49,7 +49,9 @@ def cpu_baseline(sd, tile, seconds_budget=20.):
     """Oracle (torch-CPU fp32 restatement, oracle/cpn_oracle.py) timed on this host's cores on a bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import cpn_oracle as orc
-    cores = os.cpu_count() or 1
+    # one tile does not scale past a few dozen oneDNN threads (256 threads measured 100x slower than 32 on the
+    # 256-core GPU host): use 32 threads and report that number as `cores`
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     x = torch.rand(1, 3, tile, tile, generator=torch.Generator().manual_seed(2))
     sd_cpu = {k: v.detach().cpu() for k, v in sd.items()}
