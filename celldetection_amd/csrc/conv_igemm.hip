@@ -13,10 +13,14 @@
 //     D[cout][pixel] orientation so that every lane owns 4 consecutive output channels of one pixel
 //     (8-byte NHWC bf16 stores, 128-byte coalesced NCHW fp32 plane stores for the head outputs);
 //   * K loop = (32-channel chunk) x (filter tap).  The input halo tile of a chunk is staged ONCE into LDS and
-//     re-read for every tap (49x reuse for the 7x7 heads), weights stream through a double-buffered LDS slab;
-//     global->register prefetch of step s+1 is issued before the MFMAs of step s (one barrier per step);
-//   * LDS records are 64 B of data + 16 B pad (80 B): ds_read_b128 fragment reads are bank-conflict free for
-//     stride-1 convs (4 LDS cycles per wave instruction, checked against the per-instruction lane groups);
+//     re-read for every tap (49x reuse for the 7x7 heads); weights stream through a double-buffered LDS slab;
+//   * all staging is LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass).  One pipeline step
+//     covers TWO K items (two taps, or two chunks of a 1x1 conv): the DMA of step s+1 is issued right after the
+//     barrier that opens step s and is waited for (vmcnt(0)) only at the top of step s+1, i.e. it has a whole
+//     32-MFMA-per-wave step to land;
+//   * LDS records are un-padded 64 B (32 bf16); the 16-byte part index is XOR-swizzled with (record>>2)&3 --
+//     applied on the DMA *source* address and on the ds_read address (LDS-DMA destinations are lane-linear) --
+//     which makes the ds_read_b128 fragment reads bank-conflict free for stride-1 convs at any tap offset;
 //   * grouped convs (ResNeXt cardinality 32) run as independent dense "bundles" (grid.z) of >=32 channels with
 //     block-diagonal packed weights.
 #include "cpn_kernels.h"
@@ -28,9 +32,11 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
-constexpr int PS = 80;   // LDS bytes per 32-channel record (pixel or weight row): 64 B data + 16 B pad
+constexpr int REC = 64;  // LDS bytes per 32-channel record (pixel or weight row)
 constexpr int TW = 32;   // output tile width in pixels (= one MFMA column fragment)
-constexpr int HREG = 4;  // halo prefetch iterations held in registers
+constexpr int HREG = 5;  // halo DMA instructions per wave whose source offsets are kept in registers
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4];  // source of zero padding for the halo DMA
 
 __device__ __forceinline__ unsigned int f32_to_bf16_bits(float f) {
     unsigned int u = __float_as_uint(f);
@@ -40,20 +46,46 @@ __device__ __forceinline__ unsigned int f32_to_bf16_bits(float f) {
 }
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned int b) { return __uint_as_float(b << 16); }
 
+__device__ __forceinline__ void dma16(const void *gsrc, unsigned char *lds_wave_base) {
+    // 64 lanes x 16 B -> LDS [lds_wave_base + lane*16]; the LDS base must be wave-uniform
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) gsrc,
+                                     (__attribute__((address_space(3))) void *) lds_wave_base, 16, 0, 0);
+}
+
 template <int TH, int BN, int WM, int WN>
 struct Cfg {
     static constexpr int WAVES_M = TH / WM;
     static constexpr int WAVES_N = BN / (32 * WN);
     static constexpr int NWAVES = WAVES_M * WAVES_N;
     static constexpr int THREADS = 64 * NWAVES;
-    static constexpr int W_PARTS = BN * 4;  // 16-byte parts of one weight slab tile
-    static constexpr int W_ITERS = (W_PARTS + THREADS - 1) / THREADS;
+    static constexpr int W_INSTR_ITEM = BN / 16;                   // 1-KiB DMA instructions per weight item slab
+    static constexpr int W_INSTR_WAVE = 2 * W_INSTR_ITEM / NWAVES;  // per wave per step (two items)
     static_assert(TH % WM == 0 && BN % (32 * WN) == 0, "bad tile");
+    static_assert((2 * W_INSTR_ITEM) % NWAVES == 0, "weight DMA must divide evenly over the waves");
 };
 
-struct HaloGeom {
-    int HH, HWp, hpix, parts;
+struct HaloGeo {
+    int n, iy0, ix0, Hin, Win, Hs0, Ws0, Hs1, Ws1, up0, up1, c0_stride, c1_stride, HWp, hparts;
 };
+
+// source element offsets (src0 / src1 variants; -1 = zero padding) of this lane's 16 B of halo DMA instruction q:
+// lane -> (pixel, 16-B slot); the slot holds channel part (slot ^ ((pixel>>2)&3)) of the pixel record
+__device__ __forceinline__ void halo_src_offsets(const HaloGeo &G, int q, int lane, int &o0, int &o1) {
+    const int idx = (q << 6) + lane;
+    const int pix = idx >> 2;
+    const int part = (idx & 3) ^ ((pix >> 2) & 3);
+    const int hy = pix / G.HWp, hx = pix - hy * G.HWp;
+    const int iy = G.iy0 + hy, ix = G.ix0 + hx;
+    const bool valid = (idx < G.hparts) && iy >= 0 && iy < G.Hin && ix >= 0 && ix < G.Win;
+    o0 = -1;
+    o1 = -1;
+    if (valid) {
+        const int y0 = G.up0 ? (iy >> 1) : iy, x0 = G.up0 ? (ix >> 1) : ix;
+        const int y1 = G.up1 ? (iy >> 1) : iy, x1 = G.up1 ? (ix >> 1) : ix;
+        o0 = ((G.n * G.Hs0 + y0) * G.Ws0 + x0) * G.c0_stride + part * 8;
+        o1 = ((G.n * G.Hs1 + y1) * G.Ws1 + x1) * G.c1_stride + part * 8;
+    }
+}
 
 template <int TH, int BN, int WM, int WN>
 __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igemm_kernel(const ConvArgs a) {
@@ -79,101 +111,95 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     const int g = blockIdx.z;        // bundle
 
     const int s = a.stride;
+    const int KW = a.KW;
     const int HH = (TH - 1) * s + a.KH;
-    const int HWp = (TW - 1) * s + a.KW;
-    const int hpix = HH * HWp;
-    const int hparts = hpix * 4;
-    const int halo_bytes = hpix * PS;
+    const int HWp = (TW - 1) * s + KW;
+    const int hparts = HH * HWp * 4;
+    const int hinstr = (hparts + 63) >> 6;  // 1-KiB DMA instructions per halo tile
+    const int halo_buf = hinstr << 10;
     const int nchunks = a.cin_b >> 5;
-    const int ntaps = a.KH * a.KW;
-    const int nsteps = nchunks * ntaps;
-    const int nhalo_buf = nchunks > 1 ? 2 : 1;
+    const int ntaps = a.KH * KW;
+    const bool pointwise = ntaps == 1;
+    const int nhb = pointwise ? 4 : (nchunks > 1 ? 2 : 1);  // halo ring size (chunk c lives in buffer c % nhb)
+    const int spc = (ntaps + 1) >> 1;                       // steps per chunk (ntaps > 1)
+    const int nsteps = pointwise ? ((nchunks + 1) >> 1) : nchunks * spc;
+    const int cout_b = a.cout_b;
+    const int cin0 = g * a.cin_b;
+    const int c0_used = a.c0_used;
     unsigned char *const ldsA = smem;
-    unsigned char *const ldsW = smem + nhalo_buf * halo_bytes;
-    constexpr int WBUF = BN * PS;
+    unsigned char *const ldsW = smem + nhb * halo_buf;
+    constexpr int WITEM = BN * REC;   // one item's weight slab tile
+    constexpr int WBUF = 2 * WITEM;   // one step's weights
 
-    const int iy0 = oy0 * s - a.pad, ix0 = ox0 * s - a.pad;
+    HaloGeo G;
+    G.n = n; G.iy0 = oy0 * s - a.pad; G.ix0 = ox0 * s - a.pad; G.Hin = a.Hin; G.Win = a.Win;
+    G.up0 = a.up0; G.up1 = a.up1;
+    G.Hs0 = a.up0 ? (a.Hin >> 1) : a.Hin; G.Ws0 = a.up0 ? (a.Win >> 1) : a.Win;
+    G.Hs1 = a.up1 ? (a.Hin >> 1) : a.Hin; G.Ws1 = a.up1 ? (a.Win >> 1) : a.Win;
+    G.c0_stride = a.c0_stride; G.c1_stride = a.c1_stride; G.HWp = HWp; G.hparts = hparts;
 
-    // ---- per-thread halo geometry (source pixel offsets in elements, -1 = zero padding), fixed over chunks
-    const int Hs0 = a.up0 ? (a.Hin >> 1) : a.Hin, Ws0 = a.up0 ? (a.Win >> 1) : a.Win;
-    const int Hs1 = a.up1 ? (a.Hin >> 1) : a.Hin, Ws1 = a.up1 ? (a.Win >> 1) : a.Win;
-    auto src_offsets = [&](int idx, int &o0, int &o1, int &lds_off) {
-        const int pix = idx >> 2, part = idx & 3;
-        const int hy = pix / HWp, hx = pix - hy * HWp;
-        const int iy = iy0 + hy, ix = ix0 + hx;
-        const bool valid = (idx < hparts) && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-        lds_off = pix * PS + part * 16;
-        if (valid) {
-            const int y0 = a.up0 ? (iy >> 1) : iy, x0 = a.up0 ? (ix >> 1) : ix;
-            const int y1 = a.up1 ? (iy >> 1) : iy, x1 = a.up1 ? (ix >> 1) : ix;
-            o0 = ((n * Hs0 + y0) * Ws0 + x0) * a.c0_stride + part * 8;
-            o1 = ((n * Hs1 + y1) * Ws1 + x1) * a.c1_stride + part * 8;
-        } else {
-            o0 = -1;
-            o1 = -1;
-        }
-    };
-    int h_o0[HREG], h_o1[HREG], h_lds[HREG];
+    // halo DMA instruction q (0..hinstr) is issued by wave q % NWAVES; offsets of the first HREG kept in registers
+    int h_o0[HREG], h_o1[HREG];
 #pragma unroll
-    for (int it = 0; it < HREG; ++it) src_offsets(tid + it * C::THREADS, h_o0[it], h_o1[it], h_lds[it]);
+    for (int it = 0; it < HREG; ++it) halo_src_offsets(G, wave + it * C::NWAVES, lane, h_o0[it], h_o1[it]);
 
     const unsigned short *const src0 = (const unsigned short *) a.src0;
     const unsigned short *const src1 = (const unsigned short *) a.src1;
-    const unsigned char *const wbase_g =
-            (const unsigned char *) a.weights + (size_t) g * nchunks * ntaps * a.cout_b * 64;
+    const unsigned char *const wbase_g = (const unsigned char *) a.weights + (size_t) g * nchunks * ntaps * cout_b * REC;
+    const unsigned char *const zero_src = (const unsigned char *) g_zero16;
 
-    u32x4 hreg[HREG];
-    u32x4 wreg[C::W_ITERS];
+    // weight DMA: instruction q = wave + it*NWAVES of a step covers item k = q / W_INSTR_ITEM, rows qi*16..+15 of
+    // the BN tile; lane -> (row, swizzled 16-B part); rows past cout_b read row 0 (their outputs are never stored)
+    int w_lane_off[C::W_INSTR_WAVE];
+#pragma unroll
+    for (int it = 0; it < C::W_INSTR_WAVE; ++it) {
+        const int q = wave + it * C::NWAVES;
+        const int qi = q % C::W_INSTR_ITEM;
+        const int r = qi * 16 + (lane >> 2);
+        const int part = (lane & 3) ^ ((r >> 2) & 3);
+        w_lane_off[it] = ((n0 + r < cout_b) ? r : 0) * REC + part * 16;
+    }
+    const size_t item_bytes = (size_t) cout_b * REC;
+    const unsigned char *const wbase_n0 = wbase_g + (size_t) n0 * REC;
+    const int nhb_mask = nhb - 1;
 
-    // issue the global loads of a chunk's halo (register part)
-    auto halo_issue = [&](int c) {
-        const int cin = g * a.cin_b + c * 32;
-        const bool from0 = cin < a.c0_used;
-        const unsigned short *base = from0 ? src0 + cin : src1 + (cin - a.c0_used);
-#pragma unroll
-        for (int it = 0; it < HREG; ++it) {
-            const int off = from0 ? h_o0[it] : h_o1[it];
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (off >= 0) v = *(const u32x4 *) (base + off);
-            hreg[it] = v;
-        }
-    };
-    auto halo_commit = [&](int c) {
-        unsigned char *dstb = ldsA + (nhalo_buf == 2 ? (c & 1) * halo_bytes : 0);
-#pragma unroll
-        for (int it = 0; it < HREG; ++it)
-            if (tid + it * C::THREADS < hparts) *(u32x4 *) (dstb + h_lds[it]) = hreg[it];
-        // remainder (halo larger than HREG*THREADS parts): synchronous load+store
-        const int cin = g * a.cin_b + c * 32;
-        const bool from0 = cin < a.c0_used;
-        const unsigned short *base = from0 ? src0 + cin : src1 + (cin - a.c0_used);
-        for (int idx = tid + HREG * C::THREADS; idx < hparts; idx += C::THREADS) {
-            int o0, o1, l;
-            src_offsets(idx, o0, o1, l);
-            const int off = from0 ? o0 : o1;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (off >= 0) v = *(const u32x4 *) (base + off);
-            *(u32x4 *) (dstb + l) = v;
-        }
-    };
-    auto w_issue = [&](int step) {
-        const unsigned char *slab = wbase_g + ((size_t) step * a.cout_b + n0) * 64;
-#pragma unroll
-        for (int it = 0; it < C::W_ITERS; ++it) {
-            const int idx = tid + it * C::THREADS;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (idx < C::W_PARTS && n0 + (idx >> 2) < a.cout_b) v = *(const u32x4 *) (slab + (size_t) idx * 16);
-            wreg[it] = v;
-        }
-    };
-    auto w_commit = [&](int step) {
-        unsigned char *dstb = ldsW + (step & 1) * WBUF;
-#pragma unroll
-        for (int it = 0; it < C::W_ITERS; ++it) {
-            const int idx = tid + it * C::THREADS;
-            if (idx < C::W_PARTS) *(u32x4 *) (dstb + (idx >> 2) * PS + (idx & 3) * 16) = wreg[it];
-        }
-    };
+#define HALO_DMA(CHUNK)                                                                                        \
+    {                                                                                                          \
+        const int c_ = (CHUNK);                                                                                \
+        const int cin_ = cin0 + c_ * 32;                                                                       \
+        const bool from0_ = cin_ < c0_used;                                                                    \
+        const unsigned short *base_ = from0_ ? src0 + cin_ : src1 + (cin_ - c0_used);                          \
+        unsigned char *dstb_ = ldsA + (c_ & nhb_mask) * halo_buf;                                              \
+        _Pragma("unroll") for (int it = 0; it < HREG; ++it) {                                                  \
+            const int q_ = wave + it * C::NWAVES;                                                              \
+            if (q_ < hinstr) {                                                                                 \
+                const int off_ = from0_ ? h_o0[it] : h_o1[it];                                                 \
+                const void *gsrc_ = off_ >= 0 ? (const void *) (base_ + off_) : (const void *) zero_src;       \
+                dma16(gsrc_, dstb_ + (q_ << 10));                                                              \
+            }                                                                                                  \
+        }                                                                                                      \
+        for (int q_ = wave + HREG * C::NWAVES; q_ < hinstr; q_ += C::NWAVES) {                                 \
+            int o0_, o1_;                                                                                      \
+            halo_src_offsets(G, q_, lane, o0_, o1_);                                                           \
+            const int off_ = from0_ ? o0_ : o1_;                                                               \
+            const void *gsrc_ = off_ >= 0 ? (const void *) (base_ + off_) : (const void *) zero_src;           \
+            dma16(gsrc_, dstb_ + (q_ << 10));                                                                  \
+        }                                                                                                      \
+    }
+
+    // weights of a step whose first item has flattened index IDX0 (TWO: the step has a second item) -> buffer BUF
+#define W_DMA(IDX0, TWO, BUF)                                                                                  \
+    {                                                                                                          \
+        const unsigned char *slab0_ = wbase_n0 + (size_t) (IDX0) * item_bytes;                                 \
+        unsigned char *dstb_ = ldsW + (BUF) * WBUF;                                                            \
+        _Pragma("unroll") for (int it = 0; it < C::W_INSTR_WAVE; ++it) {                                       \
+            const int q_ = wave + it * C::NWAVES;                                                              \
+            const int k_ = q_ / C::W_INSTR_ITEM;                                                               \
+            const int qi_ = q_ % C::W_INSTR_ITEM;                                                              \
+            if (k_ == 0 || (TWO))                                                                              \
+                dma16(slab0_ + (k_ ? item_bytes : 0) + w_lane_off[it], dstb_ + k_ * WITEM + (qi_ << 10));      \
+        }                                                                                                      \
+    }
 
     // ---- accumulators
     f32x16 acc[WN][WM];
@@ -185,50 +211,96 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
             for (int r = 0; r < 16; ++r) acc[j][f][r] = 0.f;
 
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int w_lane = (wave_n * WN * 32 + l31) * PS + lhi * 16;
-    const int p_lane = (wave_m * WM * s * HWp + l31 * s) * PS + lhi * 16;
-    const int p_frag_stride = s * HWp * PS;
+    // weight fragment: row = wave_n*WN*32 + j*32 + l31 -> (row>>2)&3 == (l31>>2)&3 is lane-constant
+    const int wq = (l31 >> 2) & 3;
+    const int w_lane0 = (wave_n * WN * 32 + l31) * REC + ((lhi ^ wq) << 4);        // kh = 0: part = lhi
+    const int w_lane1 = (wave_n * WN * 32 + l31) * REC + (((2 + lhi) ^ wq) << 4);  // kh = 1: part = 2 + lhi
+    const int p_lane = wave_m * WM * s * HWp + l31 * s;  // pixel index of this lane's column in fragment 0, tap 0
+    const int p_frag_stride = s * HWp;
 
-    // ---- prologue
-    halo_issue(0);
-    w_issue(0);
-    halo_commit(0);
-    w_commit(0);
-    __syncthreads();
-
-    int c = 0, t = 0, ky = 0, kx = 0;
-    for (int step = 0; step < nsteps; ++step) {
-        const int nstep = step + 1;
-        const bool has_next = nstep < nsteps;
-        const bool new_chunk = has_next && (t + 1 == ntaps);
-        if (has_next) w_issue(nstep);
-        if (new_chunk) halo_issue(c + 1);
-
-        const unsigned char *A = ldsA + (nhalo_buf == 2 ? (c & 1) * halo_bytes : 0) + (ky * HWp + kx) * PS + p_lane;
-        const unsigned char *Wb = ldsW + (step & 1) * WBUF + w_lane;
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh) {
-            bf16x8 wf[WN], pf[WM];
-#pragma unroll
-            for (int j = 0; j < WN; ++j) wf[j] = *(const bf16x8 *) (Wb + j * 32 * PS + kh * 32);
-#pragma unroll
-            for (int f = 0; f < WM; ++f) pf[f] = *(const bf16x8 *) (A + f * p_frag_stride + kh * 32);
-#pragma unroll
-            for (int j = 0; j < WN; ++j)
-#pragma unroll
-                for (int f = 0; f < WM; ++f)
-                    acc[j][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], pf[f], acc[j][f], 0, 0, 0);
-        }
-
-        if (has_next) w_commit(nstep);
-        if (new_chunk) halo_commit(c + 1);
-        __syncthreads();
-        // advance (c, t)
-        ++t;
-        ++kx;
-        if (kx == a.KW) { kx = 0; ++ky; }
-        if (t == ntaps) { t = 0; ky = 0; kx = 0; ++c; }
+    // one K item: chunk buffer A_, tap pixel offset TAPOFF, weights WB
+#define COMPUTE_ITEM(ABUF, TAPOFF, WB)                                                                         \
+    {                                                                                                          \
+        const unsigned char *A_ = (ABUF);                                                                      \
+        const unsigned char *Wb_ = (WB);                                                                       \
+        const int pt_ = p_lane + (TAPOFF);                                                                     \
+        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh) {                                                     \
+            bf16x8 wf[WN], pf[WM];                                                                             \
+            _Pragma("unroll") for (int j = 0; j < WN; ++j)                                                     \
+                wf[j] = *(const bf16x8 *) (Wb_ + (kh ? w_lane1 : w_lane0) + j * 32 * REC);                     \
+            _Pragma("unroll") for (int f = 0; f < WM; ++f) {                                                   \
+                const int p_ = pt_ + f * p_frag_stride;                                                        \
+                pf[f] = *(const bf16x8 *) (A_ + p_ * REC + ((((kh << 1) | lhi) ^ ((p_ >> 2) & 3)) << 4));      \
+            }                                                                                                  \
+            _Pragma("unroll") for (int j = 0; j < WN; ++j)                                                     \
+                _Pragma("unroll") for (int f = 0; f < WM; ++f)                                                 \
+                    acc[j][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], pf[f], acc[j][f], 0, 0, 0);     \
+        }                                                                                                      \
     }
+
+    // ---- pipeline state (wave-uniform scalars; no divisions inside the loop)
+    int c = 0;                    // chunk of item 0 of the current step
+    int t0 = 0, ky0 = 0, kx0 = 0; // tap of item 0 (non-pointwise)
+    int idx0 = 0;                 // flattened (chunk*ntaps + tap) index of item 0
+    // the two waves that share a SIMD (w, w + NWAVES/2) take complementary orders: one issues the next step's DMA
+    // before its MFMAs, the other between its two items -> the matrix pipe is fed while the partner issues
+    const bool issue_first = wave >= (C::NWAVES / 2);
+
+    // ---- prologue: stage step 0 (and the halo tiles it needs)
+    HALO_DMA(0);
+    if (pointwise && nchunks > 1) HALO_DMA(1);
+    {
+        const bool two0 = pointwise ? (nchunks > 1) : (ntaps > 1);
+        W_DMA(0, two0, 0);
+    }
+
+    for (int st = 0; st < nsteps; ++st) {
+        // (1) my DMA for this step has landed; (2) everybody's has, and everybody finished reading step st-1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const bool two = pointwise ? (c + 1 < nchunks) : (t0 + 1 < ntaps);
+        // item 1 of this step / item 0 of the next step
+        int c1 = c, ky1 = ky0, kx1 = kx0 + 1;
+        if (pointwise) { c1 = c + 1; kx1 = 0; }
+        else if (kx1 == KW) { kx1 = 0; ky1 = ky0 + 1; }
+        int cn = c, tn = t0 + 2, kyn = ky1, kxn = kx1 + 1;
+        if (pointwise) { cn = c + 2; tn = 0; kxn = 0; }
+        else {
+            if (kxn == KW) { kxn = 0; kyn = ky1 + 1; }
+            if (tn >= ntaps) { tn = 0; kyn = 0; kxn = 0; cn = c + 1; }
+        }
+        const int idxn = idx0 + (two ? 2 : 1);
+        const bool has_next = st + 1 < nsteps;
+        const bool two_n = pointwise ? (cn + 1 < nchunks) : (tn + 1 < ntaps);
+        const bool halo_ahead = !pointwise && t0 == 0 && c + 1 < nchunks;
+
+#define ISSUE_NEXT()                                                                                           \
+    {                                                                                                          \
+        if (has_next) {                                                                                        \
+            if (pointwise) {                                                                                   \
+                HALO_DMA(cn);                                                                                  \
+                if (two_n) HALO_DMA(cn + 1);                                                                   \
+            }                                                                                                  \
+            W_DMA(idxn, two_n, (st + 1) & 1);                                                                  \
+        }                                                                                                      \
+        if (halo_ahead) HALO_DMA(c + 1); /* next chunk's halo tile, a whole chunk ahead */                     \
+    }
+
+        const unsigned char *Wb = ldsW + (st & 1) * WBUF;
+        const unsigned char *A0 = ldsA + (c & nhb_mask) * halo_buf;
+        if (issue_first) ISSUE_NEXT();
+        COMPUTE_ITEM(A0, ky0 * HWp + kx0, Wb);
+        if (!issue_first) ISSUE_NEXT();
+        if (two) {
+            const unsigned char *A1 = ldsA + (c1 & nhb_mask) * halo_buf;
+            COMPUTE_ITEM(A1, ky1 * HWp + kx1, Wb + WITEM);
+        }
+#undef ISSUE_NEXT
+        c = cn; t0 = tn; ky0 = kyn; kx0 = kxn; idx0 = idxn;
+    }
+#undef HALO_DMA
+#undef W_DMA
+#undef COMPUTE_ITEM
 
     // ---- epilogue
     const int ox = ox0 + l31;
@@ -290,25 +362,30 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
 // host side: tile selection + launch
 // ---------------------------------------------------------------------------------------------------------
 struct TileChoice {
-    int TH, BN, WM, WN;
+    int TH, BN;
 };
 
 static size_t lds_bytes(const ConvArgs &a, int TH, int BN) {
     const int HH = (TH - 1) * a.stride + a.KH, HWp = (TW - 1) * a.stride + a.KW;
     const int nchunks = a.cin_b / 32;
-    return (size_t) (nchunks > 1 ? 2 : 1) * HH * HWp * PS + 2 * (size_t) BN * PS;
+    const int ntaps = a.KH * a.KW;
+    const size_t halo_buf = (size_t) ((HH * HWp * 4 + 63) / 64) * 1024;
+    const int nhb = ntaps == 1 ? 4 : (nchunks > 1 ? 2 : 1);
+    return nhb * halo_buf + 2 * 2 * (size_t) BN * REC;
 }
+
+constexpr size_t LDS_MAX = 160 * 1024;
 
 template <int TH, int BN, int WM, int WN>
 static int launch_cfg(const ConvArgs &a, hipStream_t stream) {
     using C = Cfg<TH, BN, WM, WN>;
     const size_t lds = lds_bytes(a, TH, BN);
-    static size_t max_set = 0;
+    static bool attr_set = false;
     auto kern = conv_igemm_kernel<TH, BN, WM, WN>;
-    if (lds > max_set) {
-        hipError_t e = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_MAX);
         if (e != hipSuccess) return (int) e;
-        max_set = 160 * 1024;
+        attr_set = true;
     }
     const int tiles_x = (a.Wout + TW - 1) / TW, tiles_y = (a.Hout + TH - 1) / TH;
     dim3 grid((unsigned) (tiles_x * tiles_y * a.N), (unsigned) ((a.cout_b + BN - 1) / BN), (unsigned) a.bundles);
@@ -322,21 +399,19 @@ static TileChoice choose_tile(const ConvArgs &a) {
     auto blocks = [&](int th, int bn) {
         return (long) ((a.Wout + TW - 1) / TW) * ((a.Hout + th - 1) / th) * a.N * ((a.cout_b + bn - 1) / bn) * a.bundles;
     };
-    const size_t LDS_MAX = 160 * 1024;
     if (lds_bytes(a, 8, BN) > LDS_MAX || a.Hout < 8) TH = 4;
     // prefer >= 2 workgroups per CU worth of blocks: shrink the tile while the grid is small
     if (TH == 8 && blocks(8, BN) < 512) TH = 4;
     if (blocks(TH, BN) < 512 && BN > 128) BN = 128;
     if (blocks(TH, BN) < 512 && BN > 64) BN = 64;
     while (lds_bytes(a, TH, BN) > LDS_MAX && BN > 32) BN >>= 1;
-    TileChoice c{TH, BN, 0, 0};
-    return c;
+    return TileChoice{TH, BN};
 }
 
 int launch_conv(const ConvArgs &a, hipStream_t stream) {
     if (a.cin_b % 32 || a.cout_b % 32 || a.c0_used % 32) return (int) hipErrorInvalidValue;
     const TileChoice c = choose_tile(a);
-    if (lds_bytes(a, c.TH, c.BN) > 160 * 1024) return (int) hipErrorInvalidValue;
+    if (lds_bytes(a, c.TH, c.BN) > LDS_MAX) return (int) hipErrorInvalidValue;
     if (c.TH == 8) {
         switch (c.BN) {
             case 256: return launch_cfg<8, 256, 4, 2>(a, stream);

@@ -1,0 +1,58 @@
+"""Condenses rocprofv3 CSV output (kernel stats / kernel trace / counter collection) into a small text summary
+that can be committed under profiles/.  Usage: python tools/summarize_rocprof.py <rocprof output dir> [<dir> ...]"""
+import csv
+import glob
+import os
+import re
+import sys
+from collections import defaultdict
+
+csv.field_size_limit(1 << 30)
+
+
+def short(name):
+    name = re.sub(r'^void ', '', name)
+    m = re.match(r'(?:cpn::|\(anonymous namespace\)::)?(\w+)(<[^>]*>)?', name)
+    if m and ('cpn' in name or 'anonymous' in name):
+        return m.group(1) + (m.group(2) or '')
+    return name[:70]
+
+
+def summarize(d):
+    files = glob.glob(os.path.join(d, '**', '*.csv'), recursive=True)
+    print(f'== {d}: {len(files)} csv files')
+    for f in sorted(files):
+        base = os.path.basename(f)
+        if 'kernel_stats' in base:
+            print(f'-- {base} (per-kernel totals, top 25 by time)')
+            rows = list(csv.DictReader(open(f)))
+            rows.sort(key=lambda r: -float(r.get('TotalDurationNs', 0) or 0))
+            tot = sum(float(r.get('TotalDurationNs', 0) or 0) for r in rows) or 1.
+            print(f'{"kernel":70s} {"calls":>7s} {"total_ms":>10s} {"avg_us":>10s} {"min_us":>9s} {"max_us":>9s} {"%":>6s}')
+            for r in rows[:25]:
+                print(f'{short(r["Name"]):70s} {int(float(r["Calls"])):7d} {float(r["TotalDurationNs"]) / 1e6:10.3f} '
+                      f'{float(r["AverageNs"]) / 1e3:10.2f} {float(r["MinNs"]) / 1e3:9.2f} {float(r["MaxNs"]) / 1e3:9.2f} '
+                      f'{100 * float(r["TotalDurationNs"]) / tot:6.2f}')
+        elif 'counter_collection' in base:
+            print(f'-- {base} (counter sums per kernel)')
+            agg = defaultdict(lambda: defaultdict(float))
+            disp = defaultdict(set)
+            for r in csv.DictReader(open(f)):
+                k = short(r['Kernel_Name'])
+                agg[k][r['Counter_Name']] += float(r['Counter_Value'])
+                disp[k].add(r['Dispatch_Id'])
+            names = sorted({c for v in agg.values() for c in v})
+            print(f'{"kernel":70s} {"dispatches":>10s} ' + ' '.join(f'{c + "/dispatch":>28s}' for c in names))
+            for k in sorted(agg, key=lambda k: -sum(agg[k].values())):
+                n = len(disp[k])
+                print(f'{k:70s} {n:10d} ' + ' '.join(f'{agg[k].get(c, 0.) / n:28.1f}' for c in names))
+            tot = {c: sum(v.get(c, 0.) for v in agg.values()) for c in names}
+            print('TOTAL over all dispatches: ' + ', '.join(f'{c}={tot[c]:.4g}' for c in names))
+        elif 'kernel_trace' in base:
+            n = sum(1 for _ in open(f)) - 1
+            print(f'-- {base}: {n} dispatches')
+
+
+if __name__ == '__main__':
+    for d_ in sys.argv[1:]:
+        summarize(d_)
