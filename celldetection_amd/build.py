@@ -49,7 +49,8 @@ def build(force=False, verbose=True):
         o = os.path.join(objdir, src.replace('.hip', '.o'))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [_hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-c', s, '-o', o] + extra
+            cmd = [_hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-c', s, '-o', o] + extra + \
+                  os.environ.get('CPN_HIPCC_FLAGS', '').split()
             if verbose:
                 print(' '.join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))

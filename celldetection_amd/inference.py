@@ -1,0 +1,158 @@
+"""Tiled large-slide CPN inference, sharded over the GPUs of one node.
+
+Mirrors the tiling loop of the reference script (celldetection_scripts/cpn_inference.py:311-429, ``apply_model``):
+``get_tiling_slices`` -> per-tile ``CPN.forward(offsets=...)`` -> ``remove_border_contours`` (+ optional stitching
+rule) -> concatenate -> gather over ranks -> ONE global NMS over all detections of the slide.
+
+MI355X-first differences (same results, different mechanics):
+  * the slide stays resident in HBM as uint8; tiles are cropped on the device and converted to bf16 NHWC by the
+    input kernel (no per-batch H2D copy, no DataLoader workers);
+  * tiles are independent units: rank r processes tiles r, r+W, r+2W, ... (strided, like Lightning's distributed
+    sampler in the reference) with NO data-path collective;
+  * the only exchange is ONE packed variable-length all-gather (counts, then a padded [max_count, D] float32 payload
+    of ~0.6 KB per detection) over RCCL/xGMI instead of the reference's per-key sequential send/recv to rank 0
+    (cpn_inference.py:257-308); the global NMS then runs redundantly on every rank (the payload is KB..MB:
+    latency-bound, so ring/all-reduce bandwidth considerations do not apply).
+"""
+from collections import OrderedDict
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+import torch
+
+from .util import get_tiling_slices
+
+__all__ = ['shard_tiles', 'pack_detections', 'unpack_detections', 'gather_detections', 'tiled_inference', 'KEYS']
+
+KEYS = ('contours', 'boxes', 'scores', 'classes', 'locations', 'fourier', 'contour_proposals')
+
+
+def shard_tiles(num_tiles: int, rank: int, world_size: int) -> List[int]:
+    """Strided tile -> rank assignment (every tile exactly once)."""
+    return list(range(rank, num_tiles, world_size))
+
+
+def pack_detections(d: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """dict of [K, ...] tensors -> one float32 [K, D] struct-of-rows buffer (classes stored as float, exact)."""
+    k = d['scores'].shape[0]
+    cols = [d[key].reshape(k, -1).to(torch.float32) for key in KEYS]
+    return torch.cat(cols, 1) if k else torch.zeros((0, sum(c.shape[1] for c in cols)), dtype=torch.float32,
+                                                    device=d['scores'].device)
+
+
+def unpack_detections(buf: torch.Tensor, samples: int, order: int) -> 'OrderedDict[str, torch.Tensor]':
+    k = buf.shape[0]
+    widths = dict(contours=samples * 2, boxes=4, scores=1, classes=1, locations=2, fourier=order * 4,
+                  contour_proposals=samples * 2)
+    shapes = dict(contours=(k, samples, 2), boxes=(k, 4), scores=(k,), classes=(k,), locations=(k, 2),
+                  fourier=(k, order, 4), contour_proposals=(k, samples, 2))
+    out, o = OrderedDict(), 0
+    for key in KEYS:
+        t = buf[:, o:o + widths[key]].reshape(shapes[key])
+        out[key] = t.to(torch.int64) if key == 'classes' else t
+        o += widths[key]
+    return out
+
+
+def gather_detections(buf: torch.Tensor, group=None) -> torch.Tensor:
+    """Variable-length all-gather of per-rank [K_r, D] buffers -> [sum K_r, D] in rank order (on every rank).
+    Two collectives: all_gather of the counts, all_gather of the payload padded to the maximum count."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return buf
+    world = dist.get_world_size(group)
+    if world == 1:
+        return buf
+    count = torch.tensor([buf.shape[0]], dtype=torch.int64, device=buf.device)
+    counts = [torch.zeros_like(count) for _ in range(world)]
+    dist.all_gather(counts, count, group=group)
+    counts = [int(c.item()) for c in counts]
+    mx = max(counts)
+    if mx == 0:
+        return buf
+    padded = torch.zeros((mx, buf.shape[1]), dtype=buf.dtype, device=buf.device)
+    padded[:buf.shape[0]] = buf
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded.contiguous(), group=group)
+    return torch.cat([p[:c] for p, c in zip(parts, counts)], 0)
+
+
+def _default_ops():
+    from . import ops
+    return ops.remove_border_contours, ops.filter_contours_by_stitching_rule, ops.nms
+
+
+@torch.no_grad()
+def tiled_inference(model, img: torch.Tensor, crop_size=(1024, 1024), strides=(768, 768), batch_size: int = 8,
+                    border_removal: int = 4, stitching_rule: str = 'nms', rank: Optional[int] = None,
+                    world_size: Optional[int] = None, group=None, nms_thresh: Optional[float] = None,
+                    forward_fn: Optional[Callable] = None, ops_fns=None):
+    """Slide-level CPN inference.
+
+    Args:
+        model: ``celldetection_amd.models.CPN`` (on the GPU of this rank).
+        img: slide as Tensor[C, H, W] or [1, C, H, W], uint8 or float in [0, 1], ideally already on the device.
+        crop_size, strides: tiling (celldetection_scripts/cpn_inference.py:451-452 defaults 1024 / 768).
+        batch_size: tiles per forward.
+        border_removal: contours touching the outer ``border_removal`` px of a tile side that has a neighbouring
+            tile are dropped (cpn_inference.py:370-380).
+        stitching_rule: 'nms' (global NMS) and/or 'ex_br' (cpn_inference.py:382-388,405-408).
+        rank, world_size, group: tile sharding; default = torch.distributed state (single process if uninitialised).
+        forward_fn / ops_fns: injection points used by the CPU (gloo) tests of the sharding/gather logic.
+
+    Returns:
+        OrderedDict of flat tensors (contours [K,S,2], boxes [K,4], scores [K], classes [K], locations [K,2],
+        fourier [K,O,4], contour_proposals [K,S,2]) in global slide coordinates, identical on every rank.
+    """
+    import torch.distributed as dist
+    if world_size is None:
+        world_size = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    if rank is None:
+        rank = dist.get_rank(group) if (dist.is_available() and dist.is_initialized()) else 0
+    remove_border, stitch_filter, nms_fn = ops_fns if ops_fns is not None else _default_ops()
+    if img.ndim == 4:
+        assert img.shape[0] == 1, 'one slide at a time'
+        img = img[0]
+    H, W = img.shape[-2:]
+    crop_size = (crop_size,) * 2 if np.isscalar(crop_size) else tuple(crop_size)
+    strides = (strides,) * 2 if np.isscalar(strides) else tuple(strides)
+    slices, overlaps, shape = get_tiling_slices((H, W), crop_size, strides, return_overlaps=True)
+    slices, overlaps = list(slices), list(overlaps)
+    h_tiles, w_tiles = shape
+    mine = shard_tiles(len(slices), rank, world_size)
+    fwd = forward_fn if forward_fn is not None else (lambda x, offsets: model(x, offsets=offsets))
+    nms_thresh = model.nms_thresh if nms_thresh is None else nms_thresh
+    rules = stitching_rule.split(',')
+    coll: Dict[str, List[torch.Tensor]] = {k: [] for k in KEYS}
+    samples = order = None
+    for b0 in range(0, len(mine), batch_size):
+        idxs = mine[b0:b0 + batch_size]
+        tiles = torch.stack([img[(...,) + slices[i]] for i in idxs])  # cropped on the device
+        offs = torch.tensor([[slices[i][1].start, slices[i][0].start] for i in idxs], dtype=torch.int64)
+        y = fwd(tiles, offs)
+        for n, i in enumerate(idxs):
+            h_i, w_i = np.unravel_index(i, shape)
+            con = y['contours'][n]
+            size = tuple(tiles.shape[-2:])
+            keep = remove_border(con, size, border_removal, top=h_i > 0, right=w_i < (w_tiles - 1),
+                                 bottom=h_i < (h_tiles - 1), left=w_i > 0, offsets=-offs[n])
+            if 'ex_br' in rules:
+                keep = stitch_filter(con, size, torch.as_tensor(overlaps[i]), rule='ex_br',
+                                     offsets=-offs[n].to(con.device)) & keep
+            for k in KEYS:
+                coll[k].append(y[k][n][keep])
+            samples, order = con.shape[1], y['fourier'][n].shape[1]
+    if samples is None:  # this rank had no tiles: shapes from the model
+        samples, order = model.samples, min(model.order, model.core.order)
+    dev = img.device
+    local = OrderedDict()
+    shapes = dict(contours=(0, samples, 2), boxes=(0, 4), scores=(0,), classes=(0,), locations=(0, 2),
+                  fourier=(0, order, 4), contour_proposals=(0, samples, 2))
+    for k in KEYS:
+        local[k] = torch.cat(coll[k]) if coll[k] else torch.zeros(shapes[k], device=dev)
+    buf = gather_detections(pack_detections(local), group=group)
+    res = unpack_detections(buf, samples, order)
+    if 'nms' in rules and res['scores'].shape[0]:
+        keep = nms_fn(res['boxes'], res['scores'], nms_thresh)
+        res = OrderedDict((k, v[keep]) for k, v in res.items())
+    return res

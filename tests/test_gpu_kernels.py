@@ -123,6 +123,8 @@ CONV_CASES = {
     '3x3_concat_up_pad': dict(n=1, h=32, w=32, cin=8, cout=16, k=3, cin1=16, up1=True),
     '3x3_bridge_up0': dict(n=1, h=64, w=64, cin=64, cout=64, k=3, up0=True, bias=False),
     '1x1_fpn_lateral': dict(n=2, h=32, w=32, cin=64, cout=256, k=1, res=True, res_up=True, bn=False, act='none'),
+    '3x3_c64_th16_tile': dict(n=4, h=256, w=256, cin=64, cout=64, k=3),
+    '7x7_c64_th16_tile': dict(n=4, h=256, w=256, cin=64, cout=64, k=7, seed=3),
     '7x7_head': dict(n=1, h=32, w=64, cin=64, cout=64, k=7),
     '7x7_head_256': dict(n=1, h=32, w=32, cin=256, cout=256, k=7),
     '7x7_stem_s2': dict(n=2, h=64, w=64, cin=3, cout=64, k=7, stride=2, bias=False),

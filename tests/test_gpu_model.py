@@ -153,3 +153,35 @@ def test_fetchable_model_roundtrip(dev, tmp_path):
     x = torch.as_tensor(g['x']).to(dev)
     for p, q in zip(model.core_forward(x), m2.core_forward(x)):
         assert torch.equal(p, q)
+
+
+def test_tiled_inference_stitching(dev):
+    """Slide-level loop (tiling -> forward(offsets) -> border removal -> global NMS) on the GPU:
+    (1) exact agreement with the oracle's stitching applied to the SAME per-tile GPU detections,
+    (2) IoU match against the reference's final detections of the golden stitch fixture."""
+    import cpn_oracle as orc
+    from celldetection_amd import inference
+    model, g = build('CpnU22', dev, fixture='stitch.npz')
+    img = torch.as_tensor(g['img']).to(dev)
+    crop, stride, border = tuple(int(i) for i in g['crop']), tuple(int(i) for i in g['stride']), int(g['border'])
+    res = inference.tiled_inference(model, img, crop, stride, batch_size=4, border_removal=border)
+    # (1) oracle stitching of the per-tile GPU outputs
+    slices, overlaps, shape = orc.get_tiling_slices(tuple(img.shape[-2:]), crop, stride)
+    coll = {}
+    for idx, ((h0, h1), (w0, w1)) in enumerate(slices):
+        offs = torch.tensor([[w0, h0]])
+        y = model(img[..., h0:h1, w0:w1], offsets=offs)
+        h_i, w_i = np.unravel_index(idx, shape)
+        con = y['contours'][0].cpu().numpy()
+        keep = orc.remove_border_contours(con, crop, border, top=h_i > 0, right=w_i < shape[1] - 1,
+                                          bottom=h_i < shape[0] - 1, left=w_i > 0, offsets=-offs[0].numpy().astype(np.float32))
+        for k in inference.KEYS:
+            v = y[k][0].cpu().numpy()[keep]
+            coll[k] = np.concatenate((coll[k], v)) if k in coll else v
+    keep = orc.nms(coll['boxes'], coll['scores'], model.nms_thresh)
+    for k in inference.KEYS:
+        np.testing.assert_array_equal(res[k].cpu().numpy(), coll[k][keep], err_msg=k)
+    # (2) vs the reference (bf16 conv stack => matched, not identical)
+    rate = _iou_match_rate(res['boxes'].cpu().numpy(), g['final.boxes'])
+    print('stitch: detections', len(res['scores']), 'reference', len(g['final.scores']), 'match rate', rate)
+    assert rate > .7

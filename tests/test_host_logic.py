@@ -1,0 +1,132 @@
+"""CPU tests of the host-side mirror: state-dict compatibility, tiling tables, weight packing layout, C-ABI surface,
+loud failure without a GPU.  No compute call goes through the HIP library here."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import celldetection_amd as cda
+from celldetection_amd import _lib, graph
+from model_specs import MODEL_SPECS, ref_template_state_dict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, 'tests', 'golden')
+
+
+@pytest.mark.parametrize('name', list(MODEL_SPECS))
+def test_state_dict_keys_match_reference(name):
+    spec = MODEL_SPECS[name]
+    model = getattr(cda.models, spec['cls'])(**spec['kwargs'])
+    ref = ref_template_state_dict(name)
+    mine = model.state_dict()
+    assert list(mine.keys()) == list(ref.keys())
+    for k in ref:
+        assert tuple(mine[k].shape) == tuple(ref[k].shape), k
+        assert mine[k].dtype == ref[k].dtype, k
+
+
+def test_full_size_models_param_counts_and_flops():
+    # parameters and per-tile conv GFLOP of the BASELINE configs
+    for cls, params, size, gflop in (('CpnU22', 31.57, 256, 201.67), ('CpnResNeXt101UNet', 224.64, 512, 2392.83),
+                                     ('CpnResNet18FPN', 27.24, 512, 2118.5), ('CpnResNet50FPN', 40.31, 512, 2145.3)):
+        plan = graph.build_plan(cls[3:], 3)
+        n = sum(int(np.prod(s)) for _, s, kind in plan.entries if kind == 'param') / 1e6
+        assert abs(n - params) < 0.01, (cls, n)
+        assert abs(graph.reference_flops(plan, size, size) / 1e9 - gflop) < 0.1 * (1 if 'FPN' not in cls else 1), cls
+
+
+def test_tiling_tables_match_reference():
+    t = np.load(os.path.join(G, 'tiling.npz'))
+    for tag in 'abcdef':
+        slices, overlaps, shape = cda.get_tiling_slices(tuple(int(i) for i in t[f'{tag}_size']),
+                                                        tuple(int(i) for i in t[f'{tag}_crop']),
+                                                        tuple(int(i) for i in t[f'{tag}_stride']), return_overlaps=True)
+        sl = np.array([[[s.start, s.stop] for s in item] for item in slices])
+        np.testing.assert_array_equal(sl, t[f'{tag}_slices'])
+        np.testing.assert_array_equal(np.array([[list(o) for o in item] for item in overlaps]), t[f'{tag}_overlaps'])
+        np.testing.assert_array_equal(np.array(shape), t[f'{tag}_shape'])
+
+
+def test_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'cpn_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(cpn_[a-z0-9_]+)\s*\(', hdr))
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    lib = _lib.load()  # resolves every symbol (raises otherwise); no GPU needed
+    assert lib.cpn_abi_version() == _lib.ABI_VERSION
+    assert lib.cpn_nms_workspace_bytes(1000, 1000, 1) > 1000 * 16 * 8
+
+
+def test_no_cpu_fallback():
+    model = cda.models.CpnU22(3, backbone_kwargs={'backbone_kwargs': {'base_channels': 8}})
+    with pytest.raises(RuntimeError, match='GPU'):
+        model(torch.rand(1, 3, 64, 64))
+    with pytest.raises(RuntimeError):
+        cda.ops.nms(torch.rand(4, 4), torch.rand(4), .5)
+    with pytest.raises(NotImplementedError):
+        model.train()
+
+
+def test_fetchable_model_file_format(tmp_path):
+    model = cda.models.CpnResNet18FPN(3, order=4, samples=16, backbone_kwargs={
+        'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}})
+    model.score_thresh = .5  # updated attribute -> 'updated_kwargs' (celldetection/util/util.py:527-542)
+    f = cda.save_fetchable_model(model, str(tmp_path / 'm'))
+    raw = torch.load(f, weights_only=False)
+    assert set(raw) >= {'cd.__version__', 'cd.models', 'state_dict'}
+    assert raw['cd.models']['model'] == 'CpnResNet18FPN' and raw['cd.models']['updated_kwargs'] == {'score_thresh': .5}
+    m2 = cda.load_model(f)
+    assert m2.score_thresh == .5 and m2.samples == 16 and m2.order == 4
+    for (k1, v1), (k2, v2) in zip(model.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    with pytest.raises(FileNotFoundError):
+        cda.fetch_model('ginoro')  # offline: the hosted checkpoint is not available
+
+
+def _emulate_packed_conv(op_desc, wblob, bblob, x0, x1):
+    """Numerically emulates what the HIP kernel computes from the PACKED blobs (layout check on the CPU):
+    weights [bundle][chunk][tap][cout_b][32], virtual concat [src0 padded | src1 padded], bias per output channel."""
+    k, s, pad = op_desc.kh, op_desc.stride, op_desc.pad
+    B, cin_b, cout_b = op_desc.bundles, op_desc.cin_b, op_desc.cout_b
+    xin = x0 if x1 is None else torch.cat((x0, x1), 1)
+    w = wblob[op_desc.weight_offset // 2: op_desc.weight_offset // 2 + B * cin_b * k * k * cout_b].float()
+    w = w.reshape(B, cin_b // 32, k * k, cout_b, 32).permute(0, 3, 1, 4, 2).reshape(B * cout_b, cin_b, k, k)
+    b = bblob[op_desc.bias_offset: op_desc.bias_offset + B * cout_b]
+    return F.conv2d(xin[:, :B * cin_b], w, b, s, pad, 1, B)
+
+
+@pytest.mark.parametrize('cfg', [dict(cin=8, cout=24, k=3), dict(cin=64, cout=64, k=3, groups=32),
+                                 dict(cin=256, cout=256, k=3, groups=32, stride=2),
+                                 dict(cin=128, cout=128, k=3, groups=2), dict(cin=40, cout=48, k=1, cin1=20),
+                                 dict(cin=96, cout=96, k=3, groups=4)])
+def test_weight_packing_layout(cfg):
+    g = torch.Generator().manual_seed(0)
+    cin, cout, k = cfg['cin'], cfg['cout'], cfg['k']
+    groups, stride, cin1 = cfg.get('groups', 1), cfg.get('stride', 1), cfg.get('cin1', 0)
+    P = graph.Plan()
+    s0 = P.tensor(cin, 1)
+    s1 = P.tensor(cin1, 1) if cin1 else None
+    P.conv(s0, cout, k, w='c.', bn='b.', bias=True, stride=stride, groups=groups, src1=s1)
+    sd = {}
+    for key, shape, kind in P.entries:
+        sd[key] = (torch.rand(shape, generator=g) + .5) if key.endswith(('running_var', 'b.weight')) else \
+            torch.randn(shape, generator=g) * .3
+    tens, ops, wblob, bblob = graph.pack(P, sd, 'cpu')
+    p32 = lambda c: (c + 31) // 32 * 32
+    x0 = torch.zeros(1, p32(cin), 12, 12)
+    x0[:, :cin] = torch.randn(1, cin, 12, 12, generator=g)
+    x1 = None
+    if cin1:
+        x1 = torch.zeros(1, p32(cin1), 12, 12)
+        x1[:, :cin1] = torch.randn(1, cin1, 12, 12, generator=g)
+    got = _emulate_packed_conv(ops[0], wblob, bblob, x0, x1)[:, :cout]
+    wf, bf = graph._fold(sd, P.ops[0])
+    xin = x0[:, :cin] if not cin1 else torch.cat((x0[:, :cin], x1[:, :cin1]), 1)
+    ref = F.conv2d(xin, wf.float(), bf.float(), stride, k // 2, 1, groups)
+    # packed weights are bf16: compare against the bf16-rounded folded weights
+    ref_bf = F.conv2d(xin, wf.float().to(torch.bfloat16).float(), bf.float(), stride, k // 2, 1, groups)
+    assert torch.allclose(got, ref_bf, atol=1e-4, rtol=1e-4)
+    assert (got - ref).abs().max() < 0.1
