@@ -28,6 +28,8 @@
 //     k-half is an XOR 32 on it, and the pipeline state is tracked incrementally (no divisions in the loop);
 //   * grouped convs (ResNeXt cardinality 32) run as independent dense "bundles" (grid.z) of >=32 channels with
 //     block-diagonal packed weights.
+#include <algorithm>
+
 #include "cpn_kernels.h"
 
 namespace cpn {
@@ -39,7 +41,6 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 constexpr int REC = 64;  // LDS bytes per 32-channel record (pixel or weight row)
 constexpr int TW = 32;   // output tile width in pixels (= one MFMA column fragment)
-constexpr int HREG = 5;  // halo DMA instructions per wave whose source offsets are kept in registers
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4];  // source of zero padding for the halo DMA
 
@@ -101,6 +102,73 @@ __device__ __forceinline__ void halo_src_offsets(const HaloGeo &G, int q, int la
     }
 }
 
+// ---- hand-counted LDS fragment reads ----------------------------------------------------------------------------
+// hipcc (ROCm 7.2) emits `s_waitcnt lgkmcnt(0)` in front of every MFMA group of this kernel (it stops counting DS
+// returns once LDS-DMA is in the function), which serialises "prefetch next fragments -> MFMA current fragments".
+// The fragment reads are therefore inline asm (invisible to the compiler's counters) and every MFMA group is
+// preceded by OUR counted wait, which names the fragment registers as "+v" so that no use can be scheduled above it.
+template <int IMM>
+__device__ __forceinline__ void ds_read16(bf16x8 &d, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(IMM));
+}
+template <int N, int WN, int WM>
+__device__ __forceinline__ void wait_frags(bf16x8 (&w)[WN], bf16x8 (&p)[WM]) {
+    static_assert((WN == 2 && (WM == 4 || WM == 2 || WM == 1)) || (WN == 1 && (WM == 2 || WM == 1)), "frag shape");
+    if constexpr (WN == 2 && WM == 4)
+        asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(w[0]), "+v"(w[1]), "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]) : "n"(N));
+    else if constexpr (WN == 2 && WM == 2)
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(w[0]), "+v"(w[1]), "+v"(p[0]), "+v"(p[1]) : "n"(N));
+    else if constexpr (WN == 2 && WM == 1)
+        asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(w[0]), "+v"(w[1]), "+v"(p[0]) : "n"(N));
+    else if constexpr (WN == 1 && WM == 2)
+        asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(w[0]), "+v"(p[0]), "+v"(p[1]) : "n"(N));
+    else
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(w[0]), "+v"(p[0]) : "n"(N));
+}
+// step boundary: all my DMA landed + all my LDS reads returned (fragment set named "+v" as above)
+template <int WN, int WM>
+__device__ __forceinline__ void wait_all(bf16x8 (&w)[WN], bf16x8 (&p)[WM]) {
+    if constexpr (WN == 2 && WM == 4)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]) :: "memory");
+    else if constexpr (WN == 2 && WM == 2)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(p[0]), "+v"(p[1]) :: "memory");
+    else if constexpr (WN == 2 && WM == 1)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(p[0]) :: "memory");
+    else if constexpr (WN == 1 && WM == 2)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(w[0]), "+v"(p[0]), "+v"(p[1]) :: "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(w[0]), "+v"(p[0]) :: "memory");
+}
+template <int WN, int WM, int FRAG_STRIDE>
+__device__ __forceinline__ void load_frags(bf16x8 (&w)[WN], bf16x8 (&p)[WM], unsigned paddr, unsigned waddr) {
+    ds_read16<0>(w[0], waddr);
+    if constexpr (WN > 1) ds_read16<32 * REC>(w[1], waddr);
+    ds_read16<0>(p[0], paddr);
+    if constexpr (WM > 1) ds_read16<FRAG_STRIDE>(p[1], paddr);
+    if constexpr (WM > 2) {
+        ds_read16<2 * FRAG_STRIDE>(p[2], paddr);
+        ds_read16<3 * FRAG_STRIDE>(p[3], paddr);
+    }
+}
+
+struct ItemState {  // one K item = (32-channel chunk c, filter tap (ky, kx)); wave-uniform scalars
+    int c, ky, kx;
+};
+// the item that follows I in the flattened (chunk-major, tap-minor) K order; no divisions
+__device__ __forceinline__ ItemState next_item(const ItemState I, int KH, int KW) {
+    ItemState N = I;
+    N.kx = I.kx + 1;
+    if (N.kx == KW) {
+        N.kx = 0;
+        N.ky = I.ky + 1;
+        if (N.ky == KH) {
+            N.ky = 0;
+            N.c = I.c + 1;
+        }
+    }
+    return N;
+}
+
 template <int TH, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igemm_kernel(const ConvArgs a) {
     using C = Cfg<TH, BN, WM, WN>;
@@ -134,10 +202,11 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     const int halo_buf = hinstr << 10;
     const int nchunks = a.cin_b >> 5;
     const int ntaps = KH * KW;
-    const int nhb = PW ? 4 : (nchunks > 1 ? 2 : 1);   // halo ring size (chunk c lives in buffer c & (nhb-1))
+    const bool pw = ntaps == 1;                        // one item per chunk (1x1, any stride): PW-style halo schedule
+    const int nhb = pw ? 4 : (nchunks > 1 ? 2 : 1);   // halo ring size (chunk c lives in buffer c & (nhb-1))
     const int nhb_mask = nhb - 1;
-    const int spc = (ntaps + 1) >> 1;                 // steps per chunk (KxK)
-    const int nsteps = PW ? ((nchunks + 1) >> 1) : nchunks * spc;
+    const int nitems = nchunks * ntaps;               // flattened K items; a pipeline step covers two of them
+    const int nsteps = (nitems + 1) >> 1;             // (only the very last step may hold a single item)
     const int cout_b = a.cout_b;
     const int cin0 = g * a.cin_b;
     const int c0_used = a.c0_used;
@@ -152,29 +221,46 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     G.Hs1 = a.up1 ? (a.Hin >> 1) : a.Hin; G.Ws1 = a.up1 ? (a.Win >> 1) : a.Win;
     G.c0_stride = a.c0_stride; G.c1_stride = a.c1_stride; G.HH = HH; G.HWreal = (TW - 1) * S + KW;
 
-    // halo DMA instruction q (0..hinstr) is issued by wave q % NWAVES; offsets of the first HREG kept in registers
-    int h_o0[HREG], h_o1[HREG];
-#pragma unroll
-    for (int it = 0; it < HREG; ++it) halo_src_offsets<PITCH>(G, wave + it * C::NWAVES, lane, h_o0[it], h_o1[it]);
-
+    // halo DMA instruction q (0..hinstr) is issued by wave q % NWAVES; the source offsets are recomputed per issue
+    // (a few VALU per 1-KiB DMA; keeping them in registers cost 10 VGPRs of a kernel that sits at the 256 limit)
     const unsigned short *const src0 = (const unsigned short *) a.src0;
     const unsigned short *const src1 = (const unsigned short *) a.src1;
     const unsigned char *const zero_src = (const unsigned char *) g_zero16;
 
     // weight DMA: instruction q = wave + it*NWAVES of a step covers item k = q / W_INSTR_ITEM, rows qi*16..+15 of
-    // the BN tile; lane -> (row, swizzled 16-B part); rows past cout_b read row 0 (their outputs are never stored)
-    unsigned w_lane_off[C::W_INSTR_WAVE];
+    // the BN tile; lane -> (row, swizzled 16-B part).  Everything that does not change from step to step is
+    // computed once (the loop is instruction-issue bound): item selector, LDS destination, per-lane source offset
+    // (rows past cout_b read row 0 -- their outputs are never stored).
+    const unsigned w_dma_lane = (unsigned) ((lane >> 2) * REC + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));
+    bool w_k[C::W_INSTR_WAVE];
+    int w_m0[C::W_INSTR_WAVE];
+    unsigned w_voff[C::W_INSTR_WAVE];
 #pragma unroll
     for (int it = 0; it < C::W_INSTR_WAVE; ++it) {
         const int q = wave + it * C::NWAVES;
-        const int qi = q % C::W_INSTR_ITEM;
-        const int r = qi * 16 + (lane >> 2);
-        const int part = (lane & 3) ^ ((r >> 2) & 3);
-        w_lane_off[it] = (unsigned) (((n0 + r < cout_b) ? r : 0) * REC + part * 16);
+        const int k = q / C::W_INSTR_ITEM, qi = q % C::W_INSTR_ITEM;
+        w_k[it] = k != 0;
+        w_m0[it] = ldsW_off + k * WITEM + (qi << 10);
+        w_voff[it] = (n0 + qi * 16 + (lane >> 2) < cout_b) ? (unsigned) (qi << 10) + w_dma_lane
+                                                           : (w_dma_lane & 63u);
     }
     const size_t item_bytes = (size_t) cout_b * REC;
-    const unsigned char *const wbase_n0 =
-            (const unsigned char *) a.weights + ((size_t) g * nchunks * ntaps * cout_b + n0) * REC;
+    // slab of the first item of the NEXT step to be staged (steps are staged in order, two items each)
+    const unsigned char *wptr = (const unsigned char *) a.weights + ((size_t) g * nchunks * ntaps * cout_b + n0) * REC;
+
+    // 1x1 fast path of the activation-tile DMA: single full-resolution source -> per-lane offsets are loop constants;
+    // out-of-image lanes are masked off (their LDS bytes stay stale: they only feed output pixels never stored)
+    constexpr int A_INSTR_WAVE = PW ? (TH * 2 + C::NWAVES - 1) / C::NWAVES : 1;
+    const bool pw_fast = PW && a.src1 == nullptr && !a.up0;
+    unsigned a_voff[A_INSTR_WAVE];
+    bool a_ok[A_INSTR_WAVE];
+#pragma unroll
+    for (int it = 0; it < A_INSTR_WAVE; ++it) {
+        int o0 = -1, o1 = -1;
+        if (PW) halo_src_offsets<PITCH>(G, wave + it * C::NWAVES, lane, o0, o1);
+        a_ok[it] = o0 >= 0 && (wave + it * C::NWAVES) < hinstr;
+        a_voff[it] = (unsigned) (o0 < 0 ? 0 : o0) * 2u;
+    }
 
 #define HALO_DMA(CHUNK)                                                                                        \
     {                                                                                                          \
@@ -183,15 +269,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
         const bool from0_ = cin_ < c0_used;                                                                    \
         const unsigned short *base_ = from0_ ? src0 + cin_ : src1 + (cin_ - c0_used);                          \
         unsigned char *dstb_ = smem + (c_ & nhb_mask) * halo_buf;                                              \
-        _Pragma("unroll") for (int it = 0; it < HREG; ++it) {                                                  \
-            const int q_ = wave + it * C::NWAVES;                                                              \
-            if (q_ < hinstr) {                                                                                 \
-                const int off_ = from0_ ? h_o0[it] : h_o1[it];                                                 \
-                const void *gsrc_ = off_ >= 0 ? (const void *) (base_ + off_) : (const void *) zero_src;       \
-                dma16(gsrc_, dstb_ + (q_ << 10));                                                              \
-            }                                                                                                  \
-        }                                                                                                      \
-        for (int q_ = wave + HREG * C::NWAVES; q_ < hinstr; q_ += C::NWAVES) {                                 \
+        for (int q_ = wave; q_ < hinstr; q_ += C::NWAVES) {                                                    \
             int o0_, o1_;                                                                                      \
             halo_src_offsets<PITCH>(G, q_, lane, o0_, o1_);                                                    \
             const int off_ = from0_ ? o0_ : o1_;                                                               \
@@ -200,19 +278,22 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
         }                                                                                                      \
     }
 
-    // weights of a step whose first item has flattened index IDX0 (TWO: the step has a second item) -> buffer BUF
-#define W_DMA(IDX0, TWO, BUF)                                                                                  \
+#define PW_HALO_DMA(CHUNK)                                                                                     \
     {                                                                                                          \
-        const unsigned char *slab0_ = wbase_n0 + (size_t) (IDX0) * item_bytes;                                 \
-        const unsigned char *slab1_ = slab0_ + item_bytes;                                                     \
-        unsigned char *dstb_ = smem + ldsW_off + (BUF) * WBUF;                                                 \
-        _Pragma("unroll") for (int it = 0; it < C::W_INSTR_WAVE; ++it) {                                       \
-            const int q_ = wave + it * C::NWAVES;                                                              \
-            const int k_ = q_ / C::W_INSTR_ITEM;                                                               \
-            const int qi_ = q_ % C::W_INSTR_ITEM;                                                              \
-            if (k_ == 0 || (TWO))                                                                              \
-                dma16((k_ ? slab1_ : slab0_) + w_lane_off[it], dstb_ + k_ * WITEM + (qi_ << 10));              \
-        }                                                                                                      \
+        const int c_ = (CHUNK);                                                                                \
+        const unsigned char *base_ = (const unsigned char *) (src0 + cin0 + c_ * 32);                          \
+        unsigned char *dstb_ = smem + (c_ & nhb_mask) * halo_buf;                                              \
+        _Pragma("unroll") for (int it = 0; it < A_INSTR_WAVE; ++it)                                            \
+            if (a_ok[it]) dma16(base_ + a_voff[it], dstb_ + ((wave + it * C::NWAVES) << 10));                  \
+    }
+
+    // stages the weights of the next step in order (TWO: it has a second item) into weight buffer BUF
+#define W_DMA(TWO, BUF)                                                                                        \
+    {                                                                                                          \
+        const unsigned char *s0_ = wptr, *s1_ = wptr + item_bytes;                                             \
+        _Pragma("unroll") for (int it = 0; it < C::W_INSTR_WAVE; ++it)                                         \
+            if (!w_k[it] || (TWO)) dma16((w_k[it] ? s1_ : s0_) + w_voff[it], smem + w_m0[it] + (BUF) * WBUF);  \
+        wptr += 2 * item_bytes;                                                                                \
     }
 
     // ---- accumulators
@@ -232,141 +313,216 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     const int row_wave = wave_m * WM * S;                  // halo row of fragment 0 for tap row 0
     constexpr int FRAG_STRIDE = S * PITCH * REC;           // bytes between the halo rows of consecutive fragments
 
-    // one K item: halo buffer byte offset ABUF, tap (KY, KX), weight tile byte offset WOFF.
-    // (A variant that issued the fragment reads of both items of a step up front measured 15 % slower: the
-    // 24 x 8 waves ds_read_b128 burst right after the barrier delays every wave's first MFMA.)
-#ifdef CPN_SETPRIO
-#define CPN_PRIO(x) __builtin_amdgcn_s_setprio(x)
+    // ---- software-pipelined main loop -------------------------------------------------------------------------
+    // A step has up to four MFMA groups (item x k-half), each WN + WM fragments and WN*WM MFMAs.  Two fragment
+    // register sets alternate (A: groups 0,2; B: groups 1,3): the ds_reads of group g+1 are issued BEFORE the MFMAs
+    // of group g, so LDS latency hides behind the matrix pipe (ablation: the non-MFMA skeleton of the un-pipelined
+    // loop cost 2.97 ms of the 5.33 ms of a 7x7 head conv and did not overlap with the MFMAs).  The step boundary
+    // (vmcnt(0) + barrier + DMA issue for step s+2 + first fragment reads of step s+1) sits between the loads and
+    // the MFMAs of the LAST group of step s, whose operands are already in registers.
+    // tuning experiments (profiles/): -DCPN_EXP_NOWDMA / -DCPN_EXP_NOHDMA skip the steady-state weight / halo DMA,
+    // -DCPN_EXP_NOMFMA keeps the fragment reads alive but issues no MFMA (results are wrong in all three)
+#ifdef CPN_EXP_NOWDMA
+#define CPN_EXP_W(x)
 #else
-#define CPN_PRIO(x)
+#define CPN_EXP_W(x) x
 #endif
-#define COMPUTE_ITEM(ABUF, KY, KX, WOFF)                                                                       \
+#ifdef CPN_EXP_NOHDMA
+#define CPN_EXP_H(x)
+#else
+#define CPN_EXP_H(x) x
+#endif
+#ifdef CPN_EXP_NOMFMA
+#define CPN_EXP_MMA(ACC, A, B) asm volatile("" ::"v"(A), "v"(B))
+#else
+#define CPN_EXP_MMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, ACC, 0, 0, 0)
+#endif
+
+    // byte address (within smem) of this lane's k-half-0 pixel / weight fragment of an item
+#define ITEM_PADDR(C_, KY_, KX_)                                                                               \
+    ((unsigned) (((C_) & nhb_mask) * halo_buf + (row_wave + (KY_)) * (PITCH * REC)) +                          \
+     (unsigned) ((x_lane + (KX_)) * REC) + (unsigned) ((lhi ^ (((x_lane + (KX_)) >> 2) & 3)) << 4))
+    const unsigned lds0 = (unsigned) (size_t) (__attribute__((address_space(3))) unsigned char *) smem;
+#define LOAD_GROUP(WF, PF, PADDR, WADDR) load_frags<WN, WM, FRAG_STRIDE>(WF, PF, lds0 + (PADDR), lds0 + (WADDR))
+    // MFMAs of a group whose reads were followed by PENDING younger ds_reads (the next group's prefetch)
+#define MMA_GROUP(WF, PF, PENDING)                                                                             \
     {                                                                                                          \
-        const int vx_ = x_lane + (KX);                                                                         \
-        const unsigned pa0_ = (unsigned) ((ABUF) + (row_wave + (KY)) * (PITCH * REC)) + (unsigned) (vx_ * REC) + \
-                              (unsigned) ((lhi ^ ((vx_ >> 2) & 3)) << 4);                                      \
-        const unsigned wa0_ = (unsigned) (WOFF) + w_lane;                                                      \
-        _Pragma("unroll") for (int kh = 0; kh < 2; ++kh) {                                                     \
-            const unsigned pa_ = kh ? (pa0_ ^ 32u) : pa0_;                                                     \
-            const unsigned wa_ = kh ? (wa0_ ^ 32u) : wa0_;                                                     \
-            bf16x8 wf[WN], pf[WM];                                                                             \
-            _Pragma("unroll") for (int j = 0; j < WN; ++j) wf[j] = *(const bf16x8 *) (smem + wa_ + j * 32 * REC); \
-            _Pragma("unroll") for (int f = 0; f < WM; ++f) pf[f] = *(const bf16x8 *) (smem + pa_ + f * FRAG_STRIDE); \
-            CPN_PRIO(1);                                                                                       \
-            _Pragma("unroll") for (int j = 0; j < WN; ++j)                                                     \
-                _Pragma("unroll") for (int f = 0; f < WM; ++f)                                                 \
-                    acc[j][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], pf[f], acc[j][f], 0, 0, 0);     \
-            CPN_PRIO(0);                                                                                       \
-        }                                                                                                      \
+        wait_frags<PENDING, WN, WM>(WF, PF);                                                                   \
+        _Pragma("unroll") for (int j = 0; j < WN; ++j)                                                         \
+            _Pragma("unroll") for (int f = 0; f < WM; ++f) CPN_EXP_MMA(acc[j][f], WF[j], PF[f]);               \
     }
-
-    // ---- pipeline state (wave-uniform scalars; no divisions inside the loop)
-    int c = 0;                     // chunk of item 0 of the current step
-    int t0 = 0, ky0 = 0, kx0 = 0;  // tap of item 0 (KxK)
-    int idx0 = 0;                  // flattened (chunk*ntaps + tap) index of item 0
-    // the two waves that share a SIMD (w, w + NWAVES/2) take complementary orders: one issues the next step's DMA
-    // before its MFMAs, the other between its two items -> the matrix pipe is fed while the partner issues
-    const bool issue_first = wave >= (C::NWAVES / 2);
-
-    // ---- prologue: stage step 0 (and the halo tiles it needs)
-    HALO_DMA(0);
-    if (PW && nchunks > 1) HALO_DMA(1);
-    {
-        const bool two0 = PW ? (nchunks > 1) : (ntaps > 1);
-        W_DMA(0, two0, 0);
-    }
-
-    for (int st = 0; st < nsteps; ++st) {
-        // (1) my DMA for this step has landed; (2) everybody's has, and everybody finished reading step st-1
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const bool two = PW ? (c + 1 < nchunks) : (t0 + 1 < ntaps);
-        // item 1 of this step / item 0 of the next step
-        int c1 = c, ky1 = ky0, kx1 = kx0 + 1;
-        int cn = c, tn = t0 + 2, kyn = 0, kxn = 0;
-        if (PW) {
-            c1 = c + 1; kx1 = 0; cn = c + 2; tn = 0;
-        } else {
-            if (kx1 == KW) { kx1 = 0; ky1 = ky0 + 1; }
-            kyn = ky1; kxn = kx1 + 1;
-            if (kxn == KW) { kxn = 0; kyn = ky1 + 1; }
-            if (tn >= ntaps) { tn = 0; kyn = 0; kxn = 0; cn = c + 1; }
-        }
-        const int idxn = idx0 + (two ? 2 : 1);
-        const bool has_next = st + 1 < nsteps;
-        const bool two_n = PW ? (cn + 1 < nchunks) : (tn + 1 < ntaps);
-        const bool halo_ahead = !PW && t0 == 0 && c + 1 < nchunks;
-
-#define ISSUE_NEXT()                                                                                           \
+    // DMA issued at the transition INTO step ST1 (first item IA, flattened index 2*ST1): the weights of step
+    // ST1+1 and the halo tiles that step ST1+1 (1x1) / the next chunk (KxK) will need
+#define ISSUE_AT_TRANSITION(IA, ST1, CHUNK_CHANGED)                                                            \
     {                                                                                                          \
-        if (has_next) {                                                                                        \
-            if (PW) {                                                                                          \
-                HALO_DMA(cn);                                                                                  \
-                if (two_n) HALO_DMA(cn + 1);                                                                   \
+        const int idx2_ = 2 * (ST1) + 2; /* first item of step ST1+1 */                                        \
+        if (idx2_ < nitems) {                                                                                  \
+            const bool two_nn_ = idx2_ + 1 < nitems;                                                           \
+            if (pw_fast) {                                                                                     \
+                CPN_EXP_H(PW_HALO_DMA(idx2_));                                                                 \
+                if (two_nn_) CPN_EXP_H(PW_HALO_DMA(idx2_ + 1));                                                \
+            } else if (pw) {                                                                                   \
+                CPN_EXP_H(HALO_DMA(idx2_));                                                                    \
+                if (two_nn_) CPN_EXP_H(HALO_DMA(idx2_ + 1));                                                   \
             }                                                                                                  \
-            W_DMA(idxn, two_n, (st + 1) & 1);                                                                  \
+            CPN_EXP_W(W_DMA(two_nn_, ((ST1) + 1) & 1));                                                        \
         }                                                                                                      \
-        if (halo_ahead) HALO_DMA(c + 1); /* next chunk's halo tile, a whole chunk ahead */                     \
+        /* KxK: every chunk before IA.c is completely consumed -> its ring buffer can take chunk IA.c+1 */     \
+        if (!pw && (CHUNK_CHANGED) && (IA).c + 1 < nchunks) CPN_EXP_H(HALO_DMA((IA).c + 1));                   \
     }
 
-        const int wb = ldsW_off + (st & 1) * WBUF;
-        if (issue_first) ISSUE_NEXT();
-        COMPUTE_ITEM((c & nhb_mask) * halo_buf, ky0, kx0, wb);
-        if (!issue_first) ISSUE_NEXT();
-        if (two) COMPUTE_ITEM((c1 & nhb_mask) * halo_buf, ky1, kx1, wb + WITEM);
-#undef ISSUE_NEXT
-        c = cn; t0 = tn; ky0 = kyn; kx0 = kxn; idx0 = idxn;
+    ItemState i0{0, 0, 0};                 // first item of the current step
+    ItemState i1 = next_item(i0, KH, KW);  // second item of the current step
+
+    // ---- prologue: stage step 0, open it, stage step 1, first fragment reads
+    HALO_DMA(0);
+    if (pw && nchunks > 1) HALO_DMA(1);
+    W_DMA(nitems > 1, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    ISSUE_AT_TRANSITION(i0, 0, true);
+
+    bf16x8 wA[WN], pA[WM], wB[WN], pB[WM];
+    constexpr int NF = WN + WM;  // ds_reads per group
+    unsigned pa = ITEM_PADDR(i0.c, i0.ky, i0.kx);
+    unsigned wa = (unsigned) ldsW_off + w_lane;
+    LOAD_GROUP(wA, pA, pa, wa);
+
+    // every step that is followed by another step holds two items: the loop body is branch-free with respect to
+    // the accumulators and fragment sets (conditional MFMA groups made hipcc rename/spill accumulators)
+    for (int st = 0; st + 1 < nsteps; ++st) {
+        LOAD_GROUP(wB, pB, pa ^ 32u, wa ^ 32u);      // item 0, k-half 1
+        MMA_GROUP(wA, pA, NF);                        // item 0, k-half 0
+        pa = ITEM_PADDR(i1.c, i1.ky, i1.kx);
+        wa += WITEM;
+        LOAD_GROUP(wA, pA, pa, wa);                   // item 1, k-half 0
+        MMA_GROUP(wB, pB, NF);                        // item 0, k-half 1
+        LOAD_GROUP(wB, pB, pa ^ 32u, wa ^ 32u);      // item 1, k-half 1
+        MMA_GROUP(wA, pA, NF);                        // item 1, k-half 0
+        const ItemState n0i = next_item(i1, KH, KW);  // first item of step st+1
+        // step boundary: my DMA for step st+1 has landed and all my LDS reads of step st are complete ...
+        wait_all<WN, WM>(wB, pB);
+        __builtin_amdgcn_s_barrier();                 // ... and so have everybody else's
+        ISSUE_AT_TRANSITION(n0i, st + 1, n0i.c != i0.c);  // stage step st+2 (its buffers were last read in step st)
+        pa = ITEM_PADDR(n0i.c, n0i.ky, n0i.kx);
+        wa = (unsigned) (ldsW_off + ((st + 1) & 1) * WBUF) + w_lane;
+        LOAD_GROUP(wA, pA, pa, wa);                   // first group of step st+1
+        MMA_GROUP(wB, pB, NF);                        // last group of step st (operands already in registers)
+        wait_frags<0, WN, WM>(wA, pA);                // nothing is in flight across the loop back-edge
+        i0 = n0i;
+        i1 = next_item(n0i, KH, KW);
     }
+    // last step: two items unless the item count is odd
+    LOAD_GROUP(wB, pB, pa ^ 32u, wa ^ 32u);
+    MMA_GROUP(wA, pA, NF);
+    if (!(nitems & 1)) {
+        pa = ITEM_PADDR(i1.c, i1.ky, i1.kx);
+        wa += WITEM;
+        LOAD_GROUP(wA, pA, pa, wa);
+        MMA_GROUP(wB, pB, NF);
+        LOAD_GROUP(wB, pB, pa ^ 32u, wa ^ 32u);
+        MMA_GROUP(wA, pA, NF);
+    }
+    MMA_GROUP(wB, pB, 0);
 #undef HALO_DMA
+#undef PW_HALO_DMA
 #undef W_DMA
-#undef COMPUTE_ITEM
-#undef CPN_PRIO
+#undef LOAD_GROUP
+#undef MMA_GROUP
+#undef ISSUE_AT_TRANSITION
+#undef ITEM_PADDR
 
     // ---- epilogue
-    const int ox = ox0 + l31;
+#ifdef CPN_EXP_NOEPI
+    if (a.N < 0)
+#endif
+    if (a.out_mode == OUT_BF16_NHWC) {
+        // NHWC bf16 output through a per-wave fp32 LDS staging tile: the MFMA D layout gives every lane 4 channels of
+        // 16 different pixels (8-byte pieces of sixteen 128-B lines: measured 20-70 % of the run time of the 1x1 /
+        // 3x3 layers); after the transpose a lane owns 8 consecutive channels of one pixel, a wave instruction
+        // writes whole 64/128-B channel runs with 16-B stores, and the residual is read the same way.
+        constexpr int CW = WN * 32;                  // channels per wave
+        constexpr int SPITCH = CW * 4 + 16;          // staging row pitch in bytes (fp32 + pad: conflict-free b128)
+        constexpr int LPP = CW / 8;                  // lanes per pixel in the store pass (8 channels each)
+        constexpr int PPI = 64 / LPP;                // pixels per store instruction
+        __syncthreads();                             // every wave is done reading the main-loop LDS buffers
+        unsigned char *stg = smem + wave * (32 * SPITCH);
+        const int part = lane % LPP, prow = lane / LPP;
+        const int cob = n0 + wave_n * CW + part * 8;  // first of this lane's 8 channels within the bundle
+        const bool ch_ok = cob < cout_b;
+        const int co = g * cout_b + cob;
+        float bias8[8];
 #pragma unroll
-    for (int f = 0; f < WM; ++f) {
-        const int oy = oy0 + wave_m * WM + f;
-        if (oy >= a.Hout || ox >= a.Wout) continue;
-        const size_t pix = ((size_t) n * a.Hout + oy) * a.Wout + ox;
-        size_t rpix = pix;
-        if (a.res_up) rpix = ((size_t) n * (a.Hout >> 1) + (oy >> 1)) * (a.Wout >> 1) + (ox >> 1);
+        for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+        if (a.bias && ch_ok) {
+            const float4 b0 = *(const float4 *) (a.bias + co), b1 = *(const float4 *) (a.bias + co + 4);
+            bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
+            bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+        }
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
+        for (int f = 0; f < WM; ++f) {
+            const int oy = oy0 + wave_m * WM + f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int co_b = n0 + wave_n * WN * 32 + j * 32 + 8 * q + 4 * lhi;  // channel within bundle
-                if (co_b >= a.cout_b) continue;
-                const int co = g * a.cout_b + co_b;  // global output channel
-                float v[4];
+            for (int j = 0; j < WN; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[j][f][q * 4 + e];
-                if (a.bias) {
-                    const float4 b = *(const float4 *) (a.bias + co);
-                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                for (int q = 0; q < 4; ++q) {
+                    float4 v;
+                    v.x = acc[j][f][q * 4 + 0]; v.y = acc[j][f][q * 4 + 1];
+                    v.z = acc[j][f][q * 4 + 2]; v.w = acc[j][f][q * 4 + 3];
+                    *(float4 *) (stg + l31 * SPITCH + (j * 32 + 8 * q + 4 * lhi) * 4) = v;
                 }
-                if (a.out_mode == OUT_BF16_NHWC) {
-                    if (a.res) {
-                        const u32x2 r = *(const u32x2 *) ((const unsigned short *) a.res + rpix * a.res_stride + co);
-                        v[0] += bf16_bits_to_f32(r.x & 0xffffu);
-                        v[1] += bf16_bits_to_f32(r.x >> 16);
-                        v[2] += bf16_bits_to_f32(r.y & 0xffffu);
-                        v[3] += bf16_bits_to_f32(r.y >> 16);
-                    }
-                    if (a.act == ACT_RELU) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            for (int it = 0; it < 32 / PPI; ++it) {
+                const int p = it * PPI + prow;
+                const int ox = ox0 + p;
+                const float4 v0 = *(const float4 *) (stg + p * SPITCH + part * 32);
+                const float4 v1 = *(const float4 *) (stg + p * SPITCH + part * 32 + 16);
+                if (!(ch_ok && oy < a.Hout && ox < a.Wout)) continue;
+                float v[8] = {v0.x + bias8[0], v0.y + bias8[1], v0.z + bias8[2], v0.w + bias8[3],
+                              v1.x + bias8[4], v1.y + bias8[5], v1.z + bias8[6], v1.w + bias8[7]};
+                const size_t pix = ((size_t) n * a.Hout + oy) * a.Wout + ox;
+                if (a.res) {
+                    size_t rpix = pix;
+                    if (a.res_up) rpix = ((size_t) n * (a.Hout >> 1) + (oy >> 1)) * (a.Wout >> 1) + (ox >> 1);
+                    const u32x4 r = *(const u32x4 *) ((const unsigned short *) a.res + rpix * a.res_stride + co);
+                    const unsigned rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] += bf16_bits_to_f32(rr[e] & 0xffffu);
+                        v[2 * e + 1] += bf16_bits_to_f32(rr[e] >> 16);
                     }
-                    u32x2 o;
-                    o.x = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
-                    o.y = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
-                    *(u32x2 *) ((unsigned short *) a.dst + pix * a.dst_stride + a.dst_coff + co) = o;
-                } else {
+                }
+                if (a.act == ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                u32x4 o;
+                o.x = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
+                o.y = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
+                o.z = f32_to_bf16_bits(v[4]) | (f32_to_bf16_bits(v[5]) << 16);
+                o.w = f32_to_bf16_bits(v[6]) | (f32_to_bf16_bits(v[7]) << 16);
+                *(u32x4 *) ((unsigned short *) a.dst + pix * a.dst_stride + a.dst_coff + co) = o;
+            }
+        }
+    } else {
+        // fp32 NCHW planes (head outputs): lanes 0..31 are 32 consecutive x -> 128-B coalesced plane stores
+        const int ox = ox0 + l31;
+#pragma unroll
+        for (int f = 0; f < WM; ++f) {
+            const int oy = oy0 + wave_m * WM + f;
+            if (oy >= a.Hout || ox >= a.Wout) continue;
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co_b = n0 + wave_n * WN * 32 + j * 32 + 8 * q + 4 * lhi;  // channel within bundle
+                    if (co_b >= cout_b) continue;
+                    const int co = g * cout_b + co_b;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int ce = co + e;
                         if (ce >= a.cout_real) continue;
-                        float x = v[e];
+                        float x = acc[j][f][q * 4 + e] + (a.bias ? a.bias[ce] : 0.f);
                         if (a.act == ACT_RELU) x = fmaxf(x, 0.f);
                         else if (a.act == ACT_SIGMOID) x = 1.f / (1.f + expf(-x));
                         else if (a.act == ACT_TANH_SCALED) x = tanhf(x) * a.act_scale;
@@ -397,16 +553,19 @@ static size_t lds_bytes(const ConvArgs &a, int TH, int BN) {
     const int HH = (TH - 1) * S + a.KH;
     const int nchunks = a.cin_b / 32;
     const size_t halo_buf = (size_t) ((HH * pitch * 4 + 63) / 64) * 1024;
-    const int nhb = mode == MODE_PW ? 4 : (nchunks > 1 ? 2 : 1);
+    const int nhb = (a.KH * a.KW == 1) ? 4 : (nchunks > 1 ? 2 : 1);
     return nhb * halo_buf + 2 * 2 * (size_t) BN * REC;
 }
+
+// the epilogue's per-wave fp32 staging tiles (32 pixels x (WN*32 channels + pad)) reuse the main-loop LDS
+static size_t staging_bytes(int nwaves, int WN) { return (size_t) nwaves * 32 * (WN * 32 * 4 + 16); }
 
 constexpr size_t LDS_MAX = 160 * 1024;
 
 template <int TH, int BN, int WM, int WN, int MODE>
 static int launch_mode(const ConvArgs &a, hipStream_t stream) {
     using C = Cfg<TH, BN, WM, WN>;
-    const size_t lds = lds_bytes(a, TH, BN);
+    const size_t lds = std::max(lds_bytes(a, TH, BN), staging_bytes(C::NWAVES, WN));
     static bool attr_set = false;
     auto kern = conv_igemm_kernel<TH, BN, WM, WN, MODE>;
     if (!attr_set) {
