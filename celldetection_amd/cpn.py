@@ -271,11 +271,20 @@ class CPN(nn.Module):
             offs.append(offs[-1] + c)
         flat['classes'] = torch.ones((offs[-1],), dtype=torch.int64, device=scores.device)
         keys = ('contours', 'boxes', 'scores', 'classes', 'locations', 'fourier', 'contour_proposals')
+        if nms and max(counts + [0]) <= ops.NMS_BATCH_SIZE and offs[-1] > 0:
+            # one segmented NMS over all images + ONE gather per output key (instead of N x 7 small index kernels)
+            keep, kc = ops._nms_segments(flat['boxes'], flat['scores'], offs, self.nms_thresh)
+            sel = torch.cat([keep[offs[i]:offs[i] + kc[i]] for i in range(n)])
+            flat = {k: flat[k].index_select(0, sel) for k in keys}  # cpn.py:53-60
+            offs = [0]
+            for c in kc:
+                offs.append(offs[-1] + c)
+            nms = False
         outputs = OrderedDict((k, [flat[k][offs[i]:offs[i + 1]] for i in range(n)]) for k in keys)  # cpn.py:42-50
         outputs['box_uncertainties'] = None
-        if nms:
+        if nms:  # > NMS_BATCH_SIZE proposals in one image: the reference's chunked procedure (ops/cpn.py:212-224)
             keep = ops.batched_box_nmsi(outputs['boxes'], outputs['scores'], self.nms_thresh)
-            for k in keys:  # cpn.py:53-60
+            for k in keys:
                 outputs[k] = [v[kp] for v, kp in zip(outputs[k], keep)]
         return outputs
 

@@ -79,7 +79,7 @@ struct Cfg {
 };
 
 struct HaloGeo {
-    int n, iy0, ix0, Hin, Win, Hs0, Ws0, Hs1, Ws1, up0, up1, c0_stride, c1_stride, HH, HWreal;
+    int n, iy0, ix0, sub, Hin, Win, Hs0, Ws0, Hs1, Ws1, up0, up1, c0_stride, c1_stride, HH, HWreal;
 };
 
 // source element offsets (src0 / src1 variants; -1 = zero padding) of this lane's 16 B of halo DMA instruction q:
@@ -90,7 +90,7 @@ __device__ __forceinline__ void halo_src_offsets(const HaloGeo &G, int q, int la
     const int pix = idx >> 2;
     const int part = (idx & 3) ^ ((pix >> 2) & 3);
     const int hy = pix / PITCH, hx = pix - hy * PITCH;
-    const int iy = G.iy0 + hy, ix = G.ix0 + hx;
+    const int iy = G.iy0 + hy * G.sub, ix = G.ix0 + hx * G.sub;  // sub > 1: strided 1x1 conv (tile = outputs)
     const bool valid = hy < G.HH && hx < G.HWreal && iy >= 0 && iy < G.Hin && ix >= 0 && ix < G.Win;
     o0 = -1;
     o1 = -1;
@@ -215,7 +215,9 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     const int ldsW_off = nhb * halo_buf;
 
     HaloGeo G;
-    G.n = n; G.iy0 = oy0 * S - a.pad; G.ix0 = ox0 * S - a.pad; G.Hin = a.Hin; G.Win = a.Win;
+    G.sub = PW ? a.stride : 1;
+    G.n = n; G.iy0 = oy0 * (PW ? a.stride : S) - a.pad; G.ix0 = ox0 * (PW ? a.stride : S) - a.pad;
+    G.Hin = a.Hin; G.Win = a.Win;
     G.up0 = a.up0; G.up1 = a.up1;
     G.Hs0 = a.up0 ? (a.Hin >> 1) : a.Hin; G.Ws0 = a.up0 ? (a.Win >> 1) : a.Win;
     G.Hs1 = a.up1 ? (a.Hin >> 1) : a.Hin; G.Ws1 = a.up1 ? (a.Win >> 1) : a.Win;
@@ -542,8 +544,8 @@ struct TileChoice {
 };
 
 static int conv_mode(const ConvArgs &a) {
-    if (a.stride == 2) return MODE_S2;
-    return (a.KH == 1 && a.KW == 1) ? MODE_PW : MODE_S1;
+    if (a.KH == 1 && a.KW == 1 && a.pad == 0) return MODE_PW;  // incl. strided 1x1: the tile gathers only its outputs
+    return a.stride == 2 ? MODE_S2 : MODE_S1;
 }
 
 static size_t lds_bytes(const ConvArgs &a, int TH, int BN) {

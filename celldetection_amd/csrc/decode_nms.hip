@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const unsigned long long 
             }
             if (valid && ((kb >> lane) & 1ull)) {
                 const long posn = nkeep + __popcll(kb & ((1ull << lane) - 1ull));
-                keep[s0 + posn] = (int64_t) vals[s0 + row] - (int64_t) s0;
+                keep[s0 + posn] = (int64_t) vals[s0 + row];  // index into the concatenated input
             }
             nkeep += __popcll(kb);
             if (lane == 0) sh_keep = kb;

@@ -76,7 +76,7 @@ def local_refinement(contours: Tensor, refinement: Tensor, num_loops: int, b: Te
 
 
 def _nms_segments(boxes: Tensor, scores: Tensor, seg_offsets: List[int], thresh: float):
-    """-> (keep int64 [P] (per segment, relative indices written from the segment start), keep_counts list)."""
+    """-> (keep int64 [P] (per segment: global indices, written from the segment start), keep_counts list)."""
     lib = _lib.load()
     P = int(boxes.shape[0])
     nseg = len(seg_offsets) - 1
@@ -125,7 +125,7 @@ def batched_box_nmsi(boxes: List[Tensor], scores: List[Tensor], iou_threshold: f
             keep, counts = _nms_segments(torch.cat([boxes[i] for i in small]), torch.cat([scores[i] for i in small]),
                                          offs, iou_threshold)
             for j, i in enumerate(small):
-                keeps[i] = keep[offs[j]:offs[j] + counts[j]]
+                keeps[i] = keep[offs[j]:offs[j] + counts[j]] - offs[j]
         else:
             for i in small:
                 keeps[i] = torch.empty((0,), dtype=torch.int64, device=boxes[i].device)

@@ -148,8 +148,9 @@ int cpn_local_refinement(float *contours /* in/out [P,S,2] */, const int32_t *ba
  * order, suppress iff inter/(area_i+area_j-inter) > thresh (NaN never suppresses), output = kept indices in that
  * order.  Segmented: boxes/scores hold `nseg` consecutive segments (images) [seg_offsets[s], seg_offsets[s+1]);
  * segments are independent.  seg_offsets_host: host int64[nseg+1]; seg_offsets_dev: same values on the device.
- * keep (int64 [P], device): for each segment the kept indices (relative to the segment start) are written from
- * position seg_offsets[s]; keep_counts (int32 [nseg], device) receives the number kept per segment.
+ * keep (int64 [P], device): for each segment the kept indices (GLOBAL indices into boxes/scores, i.e. segment start
+ * + index within the segment; descending score) are written from position seg_offsets[s]; keep_counts
+ * (int32 [nseg], device) receives the number kept per segment.
  * ---------------------------------------------------------------------------------------------------------- */
 int64_t cpn_nms_workspace_bytes(int64_t P, int64_t max_segment, int32_t nseg);
 int cpn_nms(const float *boxes, const float *scores, int64_t P, const int64_t *seg_offsets_host,
