@@ -10,7 +10,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libcpn_hip.so')
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OP_INPUT, OP_CONV, OP_MAXPOOL, OP_BILINEAR = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH_SCALED = 0, 1, 2, 3
@@ -28,7 +28,9 @@ class OpDesc(Structure):
                 ('bundles', c_int32), ('cin_b', c_int32), ('cout_b', c_int32),
                 ('weight_offset', c_int64), ('bias_offset', c_int64),
                 ('act', c_int32), ('act_scale', c_float), ('out_index', c_int32), ('cout_real', c_int32),
-                ('dst_coff', c_int32), ('in_channels', c_int32)]
+                ('dst_coff', c_int32), ('in_channels', c_int32),
+                ('fuse_weight_offset', c_int64), ('fuse_bias_offset', c_int64), ('fuse_cout', c_int32),
+                ('fuse_act', c_int32), ('fuse_act_scale', c_float), ('reserved_', c_int32)]
 
 
 # every symbol include/cpn_hip.h declares: (name, restype, argtypes)

@@ -506,6 +506,67 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
                 *(u32x4 *) ((unsigned short *) a.dst + pix * a.dst_stride + a.dst_coff + co) = o;
             }
         }
+    } else if (a.out_mode == OUT_FUSED_HEAD) {
+      if constexpr (TH % C::NWAVES == 0) {
+        // fused ReadOut tail (needs BN == cout_b): stage relu(conv + bias) as bf16 [pixel][channel] in LDS (16-B slot
+        // index XOR f(pixel): conflict-free MFMA B-operand reads), then D2[32][32 px] = W2[32][BN] x X[BN][32 px]
+        constexpr int SPR = BN / 8;                        // 16-B slots per pixel row
+        constexpr int SW = SPR >= 16 ? 16 : SPR;           // swizzle period
+        constexpr int PSH = SPR >= 16 ? 0 : (SPR == 8 ? 1 : 2);
+        constexpr int RPW = TH / C::NWAVES;                // pixel rows per wave in the second GEMM
+        __syncthreads();
+#pragma unroll
+        for (int f = 0; f < WM; ++f) {
+            const int p = (wave_m * WM + f) * 32 + l31;
+            const int fp = (p >> PSH) & (SW - 1);
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int cb = wave_n * WN * 32 + j * 32 + 8 * q + 4 * lhi;  // channel within the block (n0 == 0)
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[j][f][q * 4 + e] + (a.bias ? a.bias[g * cout_b + cb + e] : 0.f);
+                        if (a.act == ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    u32x2 o;
+                    o.x = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
+                    o.y = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
+                    const int slot = cb >> 3;
+                    *(u32x2 *) (smem + p * (BN * 2) + ((slot ^ fp) << 4) + lhi * 8) = o;
+                }
+        }
+        __syncthreads();
+        const unsigned char *w2 = (const unsigned char *) a.fuse_w + l31 * (BN * 2) + lhi * 16;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int row = wave * RPW + r;
+            const int p = row * 32 + l31;
+            const int fp = (p >> PSH) & (SW - 1);
+            f32x16 acc2;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < BN / 16; ++ks) {
+                const bf16x8 wv = *(const bf16x8 *) (w2 + ks * 32);
+                const bf16x8 xv = *(const bf16x8 *) (smem + p * (BN * 2) + (((ks * 2 + lhi) ^ fp) << 4));
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, xv, acc2, 0, 0, 0);
+            }
+            const int oy = oy0 + row, ox = ox0 + l31;
+            if (oy >= a.Hout || ox >= a.Wout) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int c2 = (e & 3) + 8 * (e >> 2) + 4 * lhi;
+                if (c2 >= a.fuse_cout) continue;
+                float x = acc2[e] + (a.fuse_b ? a.fuse_b[c2] : 0.f);
+                if (a.fuse_act == ACT_RELU) x = fmaxf(x, 0.f);
+                else if (a.fuse_act == ACT_SIGMOID) x = 1.f / (1.f + expf(-x));
+                else if (a.fuse_act == ACT_TANH_SCALED) x = tanhf(x) * a.fuse_scale;
+                ((float *) a.dst)[(((size_t) n * a.fuse_cout + c2) * a.Hout + oy) * a.Wout + ox] = x;
+            }
+        }
+      }
     } else {
         // fp32 NCHW planes (head outputs): lanes 0..31 are 32 consecutive x -> 128-B coalesced plane stores
         const int ox = ox0 + l31;
@@ -567,7 +628,8 @@ constexpr size_t LDS_MAX = 160 * 1024;
 template <int TH, int BN, int WM, int WN, int MODE>
 static int launch_mode(const ConvArgs &a, hipStream_t stream) {
     using C = Cfg<TH, BN, WM, WN>;
-    const size_t lds = std::max(lds_bytes(a, TH, BN), staging_bytes(C::NWAVES, WN));
+    size_t lds = std::max(lds_bytes(a, TH, BN), staging_bytes(C::NWAVES, WN));
+    if (a.out_mode == OUT_FUSED_HEAD) lds = std::max(lds, (size_t) TH * 32 * BN * 2);
     static bool attr_set = false;
     auto kern = conv_igemm_kernel<TH, BN, WM, WN, MODE>;
     if (!attr_set) {
@@ -612,7 +674,13 @@ int launch_conv(const ConvArgs &a, hipStream_t stream) {
     if (a.cin_b % 32 || a.cout_b % 32 || a.c0_used % 32) return (int) hipErrorInvalidValue;
     if (a.stride != 1 && a.stride != 2) return (int) hipErrorInvalidValue;
     if ((a.stride == 1 && a.KW > 17) || (a.stride == 2 && a.KW > 18)) return (int) hipErrorInvalidValue;
-    const TileChoice c = choose_tile(a);
+    TileChoice c = choose_tile(a);
+    if (a.out_mode == OUT_FUSED_HEAD) {  // the block must own all output channels; TH multiple of the wave count
+        if (a.bundles != 1 || (a.cout_b != 256 && a.cout_b != 128 && a.cout_b != 64 && a.cout_b != 32))
+            return (int) hipErrorInvalidValue;
+        c.BN = a.cout_b;
+        c.TH = (a.cout_b == 64 && c.TH == 16) ? 16 : 8;
+    }
     if (lds_bytes(a, c.TH, c.BN) > LDS_MAX) return (int) hipErrorInvalidValue;
     if (c.TH == 16) return launch_cfg<16, 64, 2, 2>(a, stream);
     if (c.TH == 8) {

@@ -115,7 +115,12 @@ static int build_conv_args(const cpn_plan *p, const cpn_op_desc &o, int N, int H
     a.bias = (p && o.bias_offset >= 0) ? p->bias + o.bias_offset : nullptr;
     a.res = res; a.res_stride = rs; a.res_up = o.res_up;
     a.act = o.act; a.act_scale = o.act_scale;
-    a.out_mode = o.dst >= 0 ? OUT_BF16_NHWC : OUT_F32_NCHW;
+    a.out_mode = o.dst >= 0 ? OUT_BF16_NHWC : (o.fuse_cout > 0 ? OUT_FUSED_HEAD : OUT_F32_NCHW);
+    if (o.fuse_cout > 0) {
+        a.fuse_w = p ? p->weights + o.fuse_weight_offset : nullptr;
+        a.fuse_b = (p && o.fuse_bias_offset >= 0) ? p->bias + o.fuse_bias_offset : nullptr;
+        a.fuse_cout = o.fuse_cout; a.fuse_act = o.fuse_act; a.fuse_scale = o.fuse_act_scale;
+    }
     a.dst = dst; a.dst_stride = ds; a.dst_coff = o.dst_coff;
     a.cout_real = o.cout_real;
     if (o.cin_b <= 0 || o.cin_b % 32 || o.cout_b <= 0 || o.cout_b % 32 || o.c0_used % 32 || o.bundles < 1)
@@ -290,8 +295,12 @@ int cpn_conv2d(const cpn_op_desc *op, const void *src0, int32_t c0_stride, const
     int rc = build_conv_args(nullptr, *op, N, 0, 0, a, src0, c0_stride, src1, c1_stride, res, res_stride, dst,
                              dst_stride, Hin, Win);
     if (rc) return rc;
-    a.weights = weights;
-    a.bias = bias;
+    a.weights = (const unsigned char *) weights + op->weight_offset;
+    a.bias = (bias && op->bias_offset >= 0) ? bias + op->bias_offset : nullptr;
+    if (op->fuse_cout > 0) {
+        a.fuse_w = (const unsigned char *) weights + op->fuse_weight_offset;
+        a.fuse_b = (bias && op->fuse_bias_offset >= 0) ? bias + op->fuse_bias_offset : nullptr;
+    }
     return check_hip((hipError_t) launch_conv(a, (hipStream_t) stream), "cpn_conv2d");
 }
 

@@ -9,7 +9,7 @@ namespace cpn {
 // ---------------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution (NHWC bf16 activations, packed bf16 weights, fp32 accumulate on MFMA)
 // ---------------------------------------------------------------------------------------------------------
-enum OutMode : int { OUT_BF16_NHWC = 0, OUT_F32_NCHW = 1 };
+enum OutMode : int { OUT_BF16_NHWC = 0, OUT_F32_NCHW = 1, OUT_FUSED_HEAD = 2 };
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_TANH_SCALED = 3 };
 
 struct ConvArgs {
@@ -35,6 +35,13 @@ struct ConvArgs {
     void *dst;
     int dst_stride, dst_coff;   // OUT_BF16_NHWC: channel stride / channel offset of the destination buffer
     int cout_real;              // OUT_F32_NCHW: number of real output channels (planes written)
+    // OUT_FUSED_HEAD (ReadOut head: kxk conv -> BN -> ReLU -> 1x1 conv -> activation in ONE kernel): the block's
+    // act(conv + bias) tile is rounded to bf16 in LDS and multiplied by the [32][cout_b] bf16 matrix fuse_w
+    // (rows >= fuse_cout are zero); result + fuse_b -> fuse_act -> fp32 NCHW planes in dst (cout_real = fuse_cout)
+    const void *fuse_w;
+    const float *fuse_b;
+    int fuse_cout, fuse_act;
+    float fuse_scale;
 };
 
 // picks a tile configuration and launches; returns hipError_t as int

@@ -51,7 +51,7 @@ class Plan:
         return len(self.tensors) - 1
 
     def conv(self, src0, cout, k, *, w, bn=None, bias=False, stride=1, pad=None, groups=1, act='none', act_scale=0.,
-             src1=None, up0=False, up1=False, res=None, res_up=False, out_index=None):
+             src1=None, up0=False, up1=False, res=None, res_up=False, out_index=None, fuse=None):
         """Adds conv(+BN)(+residual)(+act); returns the destination tensor id (None for external outputs)."""
         pad = k // 2 if pad is None else pad
         t0 = self.tensors[src0]
@@ -65,9 +65,11 @@ class Plan:
         self.conv_keys(w, cout, cin // groups, k, bias)
         if bn is not None:
             self.bn_keys(bn, cout)
+        if fuse is not None:  # fused ReadOut tail: final 1x1 conv (bias) applied to this conv's activated output
+            self.conv_keys(fuse['w'], fuse['cout'], cout, 1, True)
         self.ops.append(dict(op='conv', src0=src0, src1=src1, res=res, dst=dst, up0=up0, up1=up1, res_up=res_up, k=k,
                              stride=stride, pad=pad, groups=groups, cin=cin, cout=cout, w=w, bn=bn, bias=bias, act=act,
-                             act_scale=act_scale, out_index=out_index))
+                             act_scale=act_scale, out_index=out_index, fuse=fuse))
         return dst
 
     def maxpool(self, src, k, stride, pad):
@@ -255,6 +257,8 @@ def _fpn(P, feats, channels, prefix, fpn_channels):
 # full CPN
 # ---------------------------------------------------------------------------------------------------------------------
 
+FUSE_READOUT = True  # fuse the ReadOut tail (1x1 conv + activation) into the kxk head conv kernel
+
 BACKBONES = {}
 for _k in _RESNETS:
     BACKBONES[f'{_k}UNet'] = ('unet', _k)
@@ -264,6 +268,11 @@ BACKBONES['U22'] = ('unet', 'U22')
 
 def _readout(P, x, cmid, cout, prefix, act, act_scale, out_index, k=7):
     """ReadOut (commons.py:461-511): conv kxk(bias) -> BN -> ReLU -> Dropout2d(eval: identity) -> conv 1x1(bias)."""
+    if FUSE_READOUT and _pad32(cmid) in (32, 64, 128, 256) and cout <= 32:
+        # one kernel: conv kxk + BN + ReLU -> (bf16, LDS) -> 1x1 conv + final activation -> fp32 NCHW head map
+        P.conv(x, cmid, k, w=prefix + 'block.0.', bn=prefix + 'block.1.', bias=True, act='relu', out_index=out_index,
+               fuse=dict(w=prefix + 'block.4.', cout=cout, act=act, act_scale=act_scale))
+        return
     t = P.conv(x, cmid, k, w=prefix + 'block.0.', bn=prefix + 'block.1.', bias=True, act='relu')
     P.conv(t, cout, 1, w=prefix + 'block.4.', bias=True, act=act, act_scale=act_scale, out_index=out_index)
 
@@ -421,6 +430,8 @@ def pack(plan: Plan, state_dict, device):
         d.act, d.act_scale = _ACT[op['act']], float(op['act_scale'])
         d.out_index = -1 if op['out_index'] is None else op['out_index']
         d.cout_real = cout
+        d.fuse_weight_offset = d.fuse_bias_offset = -1
+        d.fuse_cout = 0
         woff += wparts[-1].numel() * 2
         boff += bparts[-1].numel()
         # keep blob offsets 16-byte aligned
@@ -428,6 +439,21 @@ def pack(plan: Plan, state_dict, device):
         if padw:
             wparts.append(torch.zeros(padw, dtype=torch.bfloat16))
             woff += padw * 2
+        if op.get('fuse'):
+            fz = op['fuse']
+            w2 = state_dict[fz['w'] + 'weight'].detach().double().cpu().reshape(fz['cout'], cout)
+            b2 = state_dict[fz['w'] + 'bias'].detach().double().cpu()
+            W2 = torch.zeros(32, coutp, dtype=torch.float64)
+            W2[:fz['cout'], :cout] = w2
+            B2 = torch.zeros(32, dtype=torch.float64)
+            B2[:fz['cout']] = b2
+            wparts.append(W2.reshape(-1).to(torch.bfloat16))
+            bparts.append(B2.to(torch.float32))
+            d.fuse_weight_offset, d.fuse_bias_offset = woff, boff
+            d.fuse_cout, d.fuse_act, d.fuse_act_scale = fz['cout'], _ACT[fz['act']], float(fz['act_scale'])
+            d.cout_real = fz['cout']
+            woff += wparts[-1].numel() * 2
+            boff += bparts[-1].numel()
     wblob = torch.cat(wparts).to(device)
     bblob = torch.cat(bparts).to(device)
     return tens, ops, wblob, bblob
@@ -447,4 +473,6 @@ def reference_flops(plan: Plan, H, W):
         if 'inner_blocks' in op['w'] and '.unet.' in op['w']:
             f *= 4
         total += f
+        if op.get('fuse'):
+            total += 2. * ho * wo * op['fuse']['cout'] * op['cout']
     return total

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CPN_ABI_VERSION 1
+#define CPN_ABI_VERSION 2
 
 #define CPN_E_INVALID (-1)
 #define CPN_E_UNSUPPORTED (-2)
@@ -66,6 +66,13 @@ typedef struct {
     int32_t cout_real;        /* dst == -1: real number of output channels                                    */
     int32_t dst_coff;         /* channel offset inside dst                                                    */
     int32_t in_channels;      /* CPN_OP_INPUT: real input channels                                            */
+    /* fused ReadOut tail (dst == -1 and fuse_cout > 0): conv -> act -> bf16 -> 1x1 conv [32][cout_b] bf16 at
+     * fuse_weight_offset (+ fuse_bias_offset, -1 = none) -> fuse_act -> fp32 NCHW output `out_index` with fuse_cout
+     * channels; requires bundles == 1 and cout_b in {32, 64, 128, 256} */
+    int64_t fuse_weight_offset, fuse_bias_offset;
+    int32_t fuse_cout, fuse_act;
+    float fuse_act_scale;
+    int32_t reserved_;
 } cpn_op_desc;
 
 typedef struct cpn_plan cpn_plan;

@@ -42,7 +42,7 @@ def from_nhwc(y, c):
 
 
 def run_conv(dev, *, n, h, w, cin, cout, k, stride=1, groups=1, bias=True, bn=True, act='relu', cin1=0, up0=False,
-             up1=False, res=False, res_up=False, out_f32=False, act_scale=3., seed=0):
+             up1=False, res=False, res_up=False, out_f32=False, act_scale=3., seed=0, fuse_cout=0, fuse_act='none'):
     """Builds a one-conv plan, runs cpn_conv2d, returns (got, ref) as fp32 NCHW CPU tensors."""
     from celldetection_amd import _lib, graph
     g = torch.Generator().manual_seed(seed)
@@ -53,7 +53,9 @@ def run_conv(dev, *, n, h, w, cin, cout, k, stride=1, groups=1, bias=True, bn=Tr
     r = P.tensor(cout, (2 if res_up else 1) * stride) if res else None
     P.conv(s0, cout, k, w='c.', bn='b.' if bn else None, bias=bias, stride=stride, groups=groups, act=act,
            act_scale=act_scale, src1=s1, up0=up0, up1=up1, res=r, res_up=res_up,
-           out_index=_lib.OUT_SCORES if out_f32 else None)
+           out_index=_lib.OUT_SCORES if (out_f32 or fuse_cout) else None,
+           fuse=dict(w='f.', cout=fuse_cout, act=fuse_act, act_scale=act_scale) if fuse_cout else None)
+    out_f32 = out_f32 or bool(fuse_cout)
     sd = {}
     for key, shape, kind in P.entries:
         if key.endswith('running_var'):
@@ -79,7 +81,7 @@ def run_conv(dev, *, n, h, w, cin, cout, k, stride=1, groups=1, bias=True, bn=Tr
     dr = to_nhwc_bf16(xr.to(dev)) if res else None
     lib = _lib.load()
     if out_f32:
-        dst = torch.full((n, cout, ho, wo), float('nan'), dtype=torch.float32, device=dev)
+        dst = torch.full((n, fuse_cout or cout, ho, wo), float('nan'), dtype=torch.float32, device=dev)
         dstride = 0
     else:
         dst = torch.full((n, ho, wo, _pad32(cout)), float('nan'), dtype=torch.bfloat16, device=dev)
@@ -104,6 +106,13 @@ def run_conv(dev, *, n, h, w, cin, cout, k, stride=1, groups=1, bias=True, bn=Tr
         ref = torch.sigmoid(ref)
     elif act == 'tanh_scaled':
         ref = torch.tanh(ref) * act_scale
+    if fuse_cout:  # fused ReadOut tail: bf16-rounded activations x bf16-rounded 1x1 weights, fp32 accumulate
+        w2 = sd['f.weight'].to(torch.bfloat16).float()
+        ref = F.conv2d(ref.to(torch.bfloat16).float(), w2, sd['f.bias'])
+        if fuse_act == 'sigmoid':
+            ref = torch.sigmoid(ref)
+        elif fuse_act == 'tanh_scaled':
+            ref = torch.tanh(ref) * act_scale
     return got, ref, out_f32
 
 
@@ -128,6 +137,11 @@ CONV_CASES = {
     '7x7_head': dict(n=1, h=32, w=64, cin=64, cout=64, k=7),
     '7x7_head_256': dict(n=1, h=32, w=32, cin=256, cout=256, k=7),
     '7x7_stem_s2': dict(n=2, h=64, w=64, cin=3, cout=64, k=7, stride=2, bias=False),
+    'fused_head_256': dict(n=1, h=32, w=64, cin=64, cout=256, k=7, fuse_cout=20, fuse_act='none'),
+    'fused_head_128_sigmoid': dict(n=2, h=32, w=32, cin=32, cout=128, k=3, fuse_cout=1, fuse_act='sigmoid'),
+    'fused_head_64_tanh_th16': dict(n=4, h=256, w=256, cin=64, cout=64, k=7, fuse_cout=2, fuse_act='tanh_scaled', seed=5),
+    'fused_head_64_tanh': dict(n=1, h=32, w=32, cin=64, cout=64, k=7, fuse_cout=2, fuse_act='tanh_scaled'),
+    'fused_head_small': dict(n=1, h=32, w=64, cin=8, cout=8, k=7, fuse_cout=20, fuse_act='none'),
     'final_sigmoid': dict(n=2, h=32, w=32, cin=64, cout=1, k=1, bn=False, act='sigmoid', out_f32=True),
     'final_tanh': dict(n=1, h=64, w=32, cin=64, cout=2, k=1, bn=False, act='tanh_scaled', out_f32=True),
     'final_fourier': dict(n=1, h=32, w=32, cin=128, cout=20, k=1, bn=False, act='none', out_f32=True),
@@ -144,7 +158,11 @@ def test_conv(dev, name):
     tol = (2e-3 if f32 else 1e-2) * max(scale, 1.)  # bf16 output rounding: 2^-9 relative
     bad = (err > tol + (0 if f32 else 8e-3) * ref.abs()).sum().item()
     print(f'{name}: max abs err {err.max().item():.3e} (ref max {scale:.3e}), mean {err.mean().item():.3e}, bad {bad}')
-    assert bad == 0, f'{name}: {bad} / {err.numel()} elements off; max abs err {err.max().item():.4e}, ref max {scale:.3e}'
+    # fused heads round the intermediate activation to bf16: a value that sits on a rounding boundary may round the
+    # other way than in the reference (different fp32 summation order) -> allow <= 1e-4 of the outputs up to 5e-2
+    allowed = int(1e-4 * err.numel()) if name.startswith('fused_head') else 0
+    assert bad <= allowed and err.max().item() < (5e-2 * max(scale, 1.) if allowed else float('inf')), \
+        f'{name}: {bad} / {err.numel()} elements off; max abs err {err.max().item():.4e}, ref max {scale:.3e}'
 
 
 def test_maxpool_bilinear_input(dev):
