@@ -10,7 +10,8 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libcpn_hip.so')
 
-ABI_VERSION = 2
+ABI_VERSION = 3
+PRECISION_BF16, PRECISION_F32 = 0, 1
 
 OP_INPUT, OP_CONV, OP_MAXPOOL, OP_BILINEAR = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH_SCALED = 0, 1, 2, 3
@@ -38,7 +39,7 @@ _SIGNATURES = [
     ('cpn_last_error', c_char_p, []),
     ('cpn_abi_version', ctypes.c_int, []),
     ('cpn_plan_create', ctypes.c_int, [POINTER(c_void_p), POINTER(TensorDesc), c_int32, POINTER(OpDesc), c_int32,
-                                       c_void_p, c_size_t, c_void_p, c_size_t]),
+                                       c_void_p, c_size_t, c_void_p, c_size_t, c_int32]),
     ('cpn_plan_destroy', None, [c_void_p]),
     ('cpn_plan_workspace_bytes', c_int64, [c_void_p, c_int32, c_int32, c_int32]),
     ('cpn_plan_executed_flops', c_double, [c_void_p, c_int32, c_int32, c_int32]),

@@ -18,6 +18,7 @@ SOURCES = {
     # file: extra flags
     'conv_igemm.hip': [],
     'misc_kernels.hip': [],
+    'conv_f32.hip': [],
     # decode/NMS must reproduce the reference's fp32 operation order bit-for-bit: no FMA contraction
     'decode_nms.hip': ['-ffp-contract=off'],
     'cpn_abi.hip': [],

@@ -62,14 +62,16 @@ def _register(root: nn.Module, key: str, shape, kind: str):
 class _Engine:
     """Packed weights + native plan for one device."""
 
-    def __init__(self, plan: graph.Plan, state_dict, device):
+    def __init__(self, plan: graph.Plan, state_dict, device, precision: str = 'bf16'):
         lib = _lib.load()
         self.device = device
-        self.tens, self.ops_desc, self.wblob, self.bblob = graph.pack(plan, state_dict, device)
+        self.precision = precision
+        self.tens, self.ops_desc, self.wblob, self.bblob = graph.pack(plan, state_dict, device, precision)
         handle = c_void_p()
         _lib.check(lib.cpn_plan_create(handle, self.tens, len(self.tens), self.ops_desc, len(self.ops_desc),
-                                       _lib.ptr(self.wblob), self.wblob.numel() * 2, _lib.ptr(self.bblob),
-                                       self.bblob.numel()), 'plan_create')
+                                       _lib.ptr(self.wblob), self.wblob.numel() * self.wblob.element_size(),
+                                       _lib.ptr(self.bblob), self.bblob.numel(),
+                                       _lib.PRECISION_F32 if precision == 'fp32' else _lib.PRECISION_BF16), 'plan_create')
         self.handle = handle
         self.plan = plan
         self._ws = None
@@ -178,6 +180,11 @@ class CPN(nn.Module):
         self.certainty_thresh = certainty_thresh
         self.uncertainty_nms = uncertainty_nms
         self._backbone_name = backbone
+        self._plan_kwargs = dict(backbone=backbone, in_channels=in_channels, order=order,
+                                 score_channels=self.score_channels, refinement=refinement,
+                                 refinement_margin=refinement_margin, refinement_buckets=refinement_buckets,
+                                 order_weights=bool(order_weights), backbone_kwargs=backbone_kwargs)
+        self.precision = 'bf16'  # 'bf16' (MFMA performance path) | 'fp32' (verification path, ~100x slower)
         self._plan = graph.build_plan(backbone, in_channels, order=order, score_channels=self.score_channels,
                                       refinement=refinement, refinement_margin=refinement_margin,
                                       refinement_buckets=refinement_buckets, order_weights=bool(order_weights),
@@ -221,8 +228,11 @@ class CPN(nn.Module):
         if device.type != 'cuda':
             raise RuntimeError('celldetection_amd runs on the MI355X (HIP) only: move the model and inputs to a GPU. '
                                'There is no CPU fallback in the product path.')
-        if self._engine is None or self._engine.device != device:
-            self._engine = _Engine(self._plan, self.state_dict(), device)
+        if self.precision not in ('bf16', 'fp32'):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        if self._engine is None or self._engine.device != device or self._engine.precision != self.precision:
+            plan = self._plan if self.precision == 'bf16' else graph.build_plan(**self._plan_kwargs, fuse_readout=False)
+            self._engine = _Engine(plan, self.state_dict(), device, self.precision)
         return self._engine
 
     def order_weights_device(self):

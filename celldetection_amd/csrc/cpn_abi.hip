@@ -44,13 +44,14 @@ struct cpn_plan {
     size_t weight_bytes = 0;
     const float *bias = nullptr;
     size_t bias_count = 0;
+    int precision = 0;  // CPN_PRECISION_BF16 / CPN_PRECISION_F32
     std::map<std::tuple<int, int, int>, cpn::ShapePlan> shape_plans;
 };
 
 namespace cpn {
 
-static int64_t tensor_bytes(const cpn_tensor_desc &t, int N, int H, int W) {
-    const int64_t b = (int64_t) N * (H / t.down) * (W / t.down) * t.channels * 2;
+static int64_t tensor_bytes(const cpn_tensor_desc &t, int N, int H, int W, int elem = 2) {
+    const int64_t b = (int64_t) N * (H / t.down) * (W / t.down) * t.channels * elem;
     return (b + 255) / 256 * 256;
 }
 
@@ -75,12 +76,13 @@ static const ShapePlan &get_shape_plan(cpn_plan *p, int N, int H, int W) {
     std::sort(order.begin(), order.end(), [&](int a, int b) { return def[a] < def[b]; });
     std::vector<int> placed;
     for (int t : order) {
-        const int64_t sz = tensor_bytes(p->tensors[t], N, H, W);
+        const int elem = p->precision == CPN_PRECISION_F32 ? 4 : 2;
+        const int64_t sz = tensor_bytes(p->tensors[t], N, H, W, elem);
         // candidate offsets: 0 and the end of every conflicting placed tensor; take the lowest that fits
         std::vector<std::pair<int64_t, int64_t>> busy;  // [begin, end) of live-overlapping tensors
         for (int q : placed)
             if (!(last[q] < def[t] || last[t] < def[q]))
-                busy.emplace_back(sp.offsets[q], sp.offsets[q] + tensor_bytes(p->tensors[q], N, H, W));
+                busy.emplace_back(sp.offsets[q], sp.offsets[q] + tensor_bytes(p->tensors[q], N, H, W, elem));
         std::sort(busy.begin(), busy.end());
         int64_t off = 0;
         for (auto &b : busy) {
@@ -151,7 +153,10 @@ const char *cpn_last_error(void) { return g_last_error.c_str(); }
 int cpn_abi_version(void) { return CPN_ABI_VERSION; }
 
 int cpn_plan_create(cpn_plan **plan, const cpn_tensor_desc *tensors, int32_t n_tensors, const cpn_op_desc *ops,
-                    int32_t n_ops, const void *weights, size_t weight_bytes, const float *bias, size_t bias_count) {
+                    int32_t n_ops, const void *weights, size_t weight_bytes, const float *bias, size_t bias_count,
+                    int32_t precision) {
+    if (precision != CPN_PRECISION_BF16 && precision != CPN_PRECISION_F32)
+        return fail(CPN_E_INVALID, "cpn_plan_create: unknown precision");
     if (!plan || !tensors || !ops || n_tensors <= 0 || n_ops <= 0) return fail(CPN_E_INVALID, "cpn_plan_create: null/empty");
     cpn_plan *p = new cpn_plan();
     p->tensors.assign(tensors, tensors + n_tensors);
@@ -160,6 +165,7 @@ int cpn_plan_create(cpn_plan **plan, const cpn_tensor_desc *tensors, int32_t n_t
     p->weight_bytes = weight_bytes;
     p->bias = bias;
     p->bias_count = bias_count;
+    p->precision = precision;
     for (const auto &t : p->tensors)
         if (t.channels <= 0 || t.channels % 32 || t.down < 1 || (t.down & (t.down - 1)) || t.down > 32) {
             delete p;
@@ -172,7 +178,11 @@ int cpn_plan_create(cpn_plan **plan, const cpn_tensor_desc *tensors, int32_t n_t
                 return fail(CPN_E_INVALID, "cpn_plan_create: tensor id out of range");
             }
         if (o.op == CPN_OP_CONV) {
-            const size_t wbytes = (size_t) o.bundles * o.cin_b * o.kh * o.kw * o.cout_b * 2;
+            const size_t wbytes = (size_t) o.bundles * o.cin_b * o.kh * o.kw * o.cout_b * (precision == CPN_PRECISION_F32 ? 4 : 2);
+            if (precision == CPN_PRECISION_F32 && o.fuse_cout > 0) {
+                delete p;
+                return fail(CPN_E_INVALID, "cpn_plan_create: fused heads are a bf16-only feature");
+            }
             if (o.weight_offset < 0 || (size_t) o.weight_offset + wbytes > weight_bytes ||
                 (o.bias_offset >= 0 && (size_t) o.bias_offset + (size_t) o.bundles * o.cout_b > bias_count)) {
                 delete p;
@@ -201,6 +211,7 @@ static int run_or_count(cpn_plan *plan, const void *input, int32_t in_dtype, int
         return fail(CPN_E_INVALID, "cpn_plan_run: H and W must be positive multiples of 32");
     const ShapePlan &sp = get_shape_plan(plan, N, H, W);
     if (!flops && sp.total > workspace_bytes) return fail(CPN_E_WORKSPACE, "cpn_plan_run: workspace too small");
+    const bool f32 = plan->precision == CPN_PRECISION_F32;
     char *ws = (char *) workspace;
     auto tptr = [&](int t) -> void * { return t >= 0 ? (void *) (ws + sp.offsets[t]) : nullptr; };
     auto tch = [&](int t) -> int { return t >= 0 ? plan->tensors[t].channels : 0; };
@@ -212,21 +223,21 @@ static int run_or_count(cpn_plan *plan, const void *input, int32_t in_dtype, int
             case CPN_OP_INPUT: {
                 if (flops) break;
                 InputArgs a{input, tptr(o.dst), N, o.in_channels, H, W, tch(o.dst), in_dtype, range_flag};
-                rc = check_hip((hipError_t) launch_input(a, st), "input kernel");
+                rc = check_hip((hipError_t) (f32 ? launch_input_f32(a, st) : launch_input(a, st)), "input kernel");
                 break;
             }
             case CPN_OP_MAXPOOL: {
                 if (flops) break;
                 const int din = plan->tensors[o.src0].down, dout = plan->tensors[o.dst].down;
                 PoolArgs a{tptr(o.src0), tptr(o.dst), N, H / din, W / din, H / dout, W / dout, tch(o.src0), o.kh, o.stride, o.pad};
-                rc = check_hip((hipError_t) launch_maxpool(a, st), "maxpool kernel");
+                rc = check_hip((hipError_t) (f32 ? launch_maxpool_f32(a, st) : launch_maxpool(a, st)), "maxpool kernel");
                 break;
             }
             case CPN_OP_BILINEAR: {
                 if (flops) break;
                 const int din = plan->tensors[o.src0].down, dout = plan->tensors[o.dst].down;
                 ResizeArgs a{tptr(o.src0), tptr(o.dst), N, H / din, W / din, H / dout, W / dout, tch(o.src0)};
-                rc = check_hip((hipError_t) launch_bilinear(a, st), "bilinear kernel");
+                rc = check_hip((hipError_t) (f32 ? launch_bilinear_f32(a, st) : launch_bilinear(a, st)), "bilinear kernel");
                 break;
             }
             case CPN_OP_CONV: {
@@ -245,7 +256,7 @@ static int run_or_count(cpn_plan *plan, const void *input, int32_t in_dtype, int
                 if (op_flops) op_flops[i] = conv_executed_flops(a);
                 if (flops) { *flops += conv_executed_flops(a); break; }
                 if (!dst) return fail(CPN_E_INVALID, "cpn_plan_run: missing external output buffer");
-                rc = check_hip((hipError_t) launch_conv(a, st), "conv kernel");
+                rc = check_hip((hipError_t) (f32 ? launch_conv_f32(a, st) : launch_conv(a, st)), "conv kernel");
                 break;
             }
             default: return fail(CPN_E_INVALID, "cpn_plan_run: unknown op");

@@ -70,4 +70,11 @@ struct InputArgs {
 };
 int launch_input(const InputArgs &a, hipStream_t stream);
 
+// fp32 verification path (csrc/conv_f32.hip): same argument structs, fp32 NHWC activations, weights
+// [bundle][kh*kw][cin_b][cout_b] fp32
+int launch_conv_f32(const ConvArgs &a, hipStream_t stream);
+int launch_input_f32(const InputArgs &a, hipStream_t stream);
+int launch_maxpool_f32(const PoolArgs &a, hipStream_t stream);
+int launch_bilinear_f32(const ResizeArgs &a, hipStream_t stream);
+
 }  // namespace cpn

@@ -266,9 +266,9 @@ for _k in _RESNETS:
 BACKBONES['U22'] = ('unet', 'U22')
 
 
-def _readout(P, x, cmid, cout, prefix, act, act_scale, out_index, k=7):
+def _readout(P, x, cmid, cout, prefix, act, act_scale, out_index, k=7, fuse=True):
     """ReadOut (commons.py:461-511): conv kxk(bias) -> BN -> ReLU -> Dropout2d(eval: identity) -> conv 1x1(bias)."""
-    if FUSE_READOUT and _pad32(cmid) in (32, 64, 128, 256) and cout <= 32:
+    if fuse and FUSE_READOUT and _pad32(cmid) in (32, 64, 128, 256) and cout <= 32:
         # one kernel: conv kxk + BN + ReLU -> (bf16, LDS) -> 1x1 conv + final activation -> fp32 NCHW head map
         P.conv(x, cmid, k, w=prefix + 'block.0.', bn=prefix + 'block.1.', bias=True, act='relu', out_index=out_index,
                fuse=dict(w=prefix + 'block.4.', cout=cout, act=act, act_scale=act_scale))
@@ -279,7 +279,7 @@ def _readout(P, x, cmid, cout, prefix, act, act_scale, out_index, k=7):
 
 def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: int = 1, refinement: bool = True,
                refinement_margin: float = 3., refinement_buckets: int = 1, order_weights: bool = True,
-               backbone_kwargs: dict = None) -> Plan:
+               backbone_kwargs: dict = None, fuse_readout: bool = True) -> Plan:
     """Plan of ``Cpn<backbone>`` (celldetection/models/cpn.py:287-439,771-2061)."""
     if backbone not in BACKBONES:
         raise ValueError(f'Unsupported backbone {backbone!r}; supported: {sorted(BACKBONES)}')
@@ -311,15 +311,15 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
         f0, f1 = outs[0], outs[1]
         c0 = c1 = fc
         scale = P.tensors[f1]['down']
-    _readout(P, f1, c1, score_channels, 'core.score_head.', 'sigmoid', 0., _lib.OUT_SCORES)
-    _readout(P, f1, c1, 2, 'core.location_head.', 'none', 0., _lib.OUT_LOCATIONS)
-    _readout(P, f1, c1, order * 4, 'core.fourier_head.', 'none', 0., _lib.OUT_FOURIER)
+    _readout(P, f1, c1, score_channels, 'core.score_head.', 'sigmoid', 0., _lib.OUT_SCORES, fuse=fuse_readout)
+    _readout(P, f1, c1, 2, 'core.location_head.', 'none', 0., _lib.OUT_LOCATIONS, fuse=fuse_readout)
+    _readout(P, f1, c1, order * 4, 'core.fourier_head.', 'none', 0., _lib.OUT_FOURIER, fuse=fuse_readout)
     if refinement:
         r = f0
         while P.tensors[r]['down'] > 1:  # cpn.py:277-278: bilinear resize of the features to the input size
             r = P.bilinear_up2(r)
         _readout(P, r, c0, 2 * refinement_buckets, 'core.refinement_head.', 'tanh_scaled', float(refinement_margin),
-                 _lib.OUT_REFINEMENT)
+                 _lib.OUT_REFINEMENT, fuse=fuse_readout)
     P.meta = dict(backbone=backbone, order=order, head_down=scale, refinement=refinement, in_channels=in_channels)
     return P
 
@@ -359,8 +359,12 @@ def _bundle_geometry(cin, cout, groups):
     return cin // bw, bw, bw, bw // cig
 
 
-def pack(plan: Plan, state_dict, device):
-    """-> (tensor_descs, op_descs, weight_blob[bf16, device], bias_blob[f32, device])."""
+def pack(plan: Plan, state_dict, device, precision: str = 'bf16'):
+    """-> (tensor_descs, op_descs, weight_blob[bf16 | f32, device], bias_blob[f32, device]).
+
+    bf16: weights [bundle][cin_b/32][k*k][cout_b][32]; fp32 (verification path): [bundle][k*k][cin_b][cout_b]."""
+    f32 = precision == 'fp32'
+    wdt, wsz = (torch.float32, 4) if f32 else (torch.bfloat16, 2)
     tens = (_lib.TensorDesc * len(plan.tensors))()
     for i, t in enumerate(plan.tensors):
         tens[i].channels, tens[i].down = _pad32(t['c']), t['down']
@@ -402,7 +406,8 @@ def pack(plan: Plan, state_dict, device):
                 for g in range(groups):
                     dense[g * cog:(g + 1) * cog, g * cig:(g + 1) * cig] = w[g * cog:(g + 1) * cog]
             bundles, cin_b, cout_b = 1, cinp, coutp
-            packed = dense.reshape(1, coutp, cinp // 32, 32, k * k).permute(0, 2, 4, 1, 3)
+            packed = dense.reshape(1, coutp, cinp, k * k).permute(0, 3, 2, 1) if f32 else \
+                dense.reshape(1, coutp, cinp // 32, 32, k * k).permute(0, 2, 4, 1, 3)
             bias = torch.zeros(coutp, dtype=torch.float64)
             bias[:cout] = b
         else:
@@ -412,9 +417,10 @@ def pack(plan: Plan, state_dict, device):
             wg = w.reshape(bundles, gpb, cig, cig, k, k)  # [bundle, group-in-bundle, cout_g, cin_g, k, k]
             for g in range(gpb):
                 dense[:, g * cig:(g + 1) * cig, g * cig:(g + 1) * cig] = wg[:, g]
-            packed = dense.reshape(bundles, cout_b, cin_b // 32, 32, k * k).permute(0, 2, 4, 1, 3)
+            packed = dense.reshape(bundles, cout_b, cin_b, k * k).permute(0, 3, 2, 1) if f32 else \
+                dense.reshape(bundles, cout_b, cin_b // 32, 32, k * k).permute(0, 2, 4, 1, 3)
             bias = b.clone()
-        wparts.append(packed.contiguous().reshape(-1).to(torch.bfloat16))
+        wparts.append(packed.contiguous().reshape(-1).to(wdt))
         bparts.append(bias.to(torch.float32))
         d.op = _lib.OP_CONV
         d.src0 = op['src0']
@@ -432,14 +438,15 @@ def pack(plan: Plan, state_dict, device):
         d.cout_real = cout
         d.fuse_weight_offset = d.fuse_bias_offset = -1
         d.fuse_cout = 0
-        woff += wparts[-1].numel() * 2
+        woff += wparts[-1].numel() * wsz
         boff += bparts[-1].numel()
         # keep blob offsets 16-byte aligned
         padw = (-wparts[-1].numel()) % 8
         if padw:
-            wparts.append(torch.zeros(padw, dtype=torch.bfloat16))
-            woff += padw * 2
+            wparts.append(torch.zeros(padw, dtype=wdt))
+            woff += padw * wsz
         if op.get('fuse'):
+            assert not f32, 'fused heads are a bf16-only feature'
             fz = op['fuse']
             w2 = state_dict[fz['w'] + 'weight'].detach().double().cpu().reshape(fz['cout'], cout)
             b2 = state_dict[fz['w'] + 'bias'].detach().double().cpu()

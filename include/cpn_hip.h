@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CPN_ABI_VERSION 2
+#define CPN_ABI_VERSION 3
 
 #define CPN_E_INVALID (-1)
 #define CPN_E_UNSUPPORTED (-2)
@@ -77,10 +77,17 @@ typedef struct {
 
 typedef struct cpn_plan cpn_plan;
 
+/* precision of a plan: bf16 activations/weights on MFMA with fp32 accumulation (the performance path), or an fp32
+ * verification path (fp32 activations/weights/FMA on the vector ALUs; weights packed [bundle][kh*kw][cin_b][cout_b]
+ * fp32, weight_offset in bytes of that blob; no fused heads) used to check the whole path against the reference's
+ * fp32 CPU forward at 1e-4 */
+enum { CPN_PRECISION_BF16 = 0, CPN_PRECISION_F32 = 1 };
+
 /* Creates a plan (host-side object; copies the descriptors).  `weights` / `bias` are DEVICE pointers to the packed
  * blobs and must stay alive as long as the plan. */
 int cpn_plan_create(cpn_plan **plan, const cpn_tensor_desc *tensors, int32_t n_tensors, const cpn_op_desc *ops,
-                    int32_t n_ops, const void *weights, size_t weight_bytes, const float *bias, size_t bias_count);
+                    int32_t n_ops, const void *weights, size_t weight_bytes, const float *bias, size_t bias_count,
+                    int32_t precision);
 void cpn_plan_destroy(cpn_plan *plan);
 /* Workspace (activation arena, liveness-planned) needed for a batch of N inputs of H x W (H, W multiples of 32). */
 int64_t cpn_plan_workspace_bytes(cpn_plan *plan, int32_t N, int32_t H, int32_t W);
