@@ -20,7 +20,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16 peak of MI355X (MI355X_MICROARCH.md; 2:1-sparsity figures excluded)
-GFLOP_PER_TILE = {'CpnResNeXt101UNet': 2392.83, 'CpnResNet18FPN': 2124.85, 'CpnU22': 201.67}  # SURVEY.md 8a @512/256
+GFLOP_PER_TILE = {'CpnResNeXt101UNet': 2392.83, 'CpnResNet18FPN': 2124.85}  # SURVEY.md section 8a, 3x512x512 tiles
+# HBM bytes of ONE conv-graph execution (batch 16 x 3x512x512, CpnResNeXt101UNet) from the PMC passes committed in
+# profiles/r01_rocprofv3_summary.txt (tools/run_graph_only.py 5): 2 x FETCH_SIZE (gfx950 correction for wide
+# streaming reads, MI355X_MICROARCH.md section HBM) + WRITE_SIZE = 2 x 12.93 GB + 11.80 GB
+TRAFFIC_BYTES_PER_GRAPH_B16 = 37.66e9
 
 
 def build_model(name, dev, seed=0, tile=512, calib_tiles=2):
@@ -155,8 +159,11 @@ def main():
                        'tiles_per_gpu_per_step': args.batch, 'detections_last_step': ndet,
                        'parallelism': f'tile-sharded x{world}, no data-path collective'},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_BF16_TFLOPS, 'traffic': None,
-                         'kernel': 'conv_igemm_kernel (all launches of one conv-graph execution)',
+                         'frac': achieved / PEAK_BF16_TFLOPS,
+                         'traffic': TRAFFIC_BYTES_PER_GRAPH_B16 if (args.model == 'CpnResNeXt101UNet' and args.batch == 16
+                                                                    and args.tile == 512) else None,
+                         'kernel': 'conv_igemm_kernel: one conv-graph execution = 126 convs in 122 launches of the kernel '
+                                   'family (+ input/maxpool helpers), timed with HIP events on the launch stream',
                          'launch_ms': conv_ms, 'algorithmic_gflop_per_launch': gf * args.batch},
         }
         if not args.no_cpu_baseline and world == 1:

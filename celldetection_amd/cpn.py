@@ -258,6 +258,11 @@ class CPN(nn.Module):
         return self.postprocess(scores, locations, refinement, fourier, original_size, nms=nms, flag=self._last_flag,
                                 **kwargs)
 
+    def forward_tiled(self, inputs, crop_size=1024, stride=512, **kwargs):
+        """In-model tiling (celldetection/models/lightning_cpn.py:88-177); see ``inference.forward_tiled``."""
+        from . import inference
+        return inference.forward_tiled(self, inputs, crop_size=crop_size, stride=stride, **kwargs)
+
     @torch.no_grad()
     def postprocess(self, scores, locations, refinement, fourier, original_size, nms=True, flag=None, **kwargs):
         """CPN.forward after the core (cpn.py:575-734) on given head maps: ``scores`` are probabilities

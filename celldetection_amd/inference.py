@@ -22,7 +22,8 @@ import torch
 
 from .util import get_tiling_slices
 
-__all__ = ['shard_tiles', 'pack_detections', 'unpack_detections', 'gather_detections', 'tiled_inference', 'KEYS']
+__all__ = ['shard_tiles', 'pack_detections', 'unpack_detections', 'gather_detections', 'tiled_inference',
+           'forward_tiled', 'KEYS']
 
 KEYS = ('contours', 'boxes', 'scores', 'classes', 'locations', 'fourier', 'contour_proposals')
 
@@ -86,7 +87,7 @@ def _default_ops():
 def tiled_inference(model, img: torch.Tensor, crop_size=(1024, 1024), strides=(768, 768), batch_size: int = 8,
                     border_removal: int = 4, stitching_rule: str = 'nms', rank: Optional[int] = None,
                     world_size: Optional[int] = None, group=None, nms_thresh: Optional[float] = None,
-                    forward_fn: Optional[Callable] = None, ops_fns=None):
+                    forward_fn: Optional[Callable] = None, ops_fns=None, mask: Optional[torch.Tensor] = None):
     """Slide-level CPN inference.
 
     Args:
@@ -99,6 +100,8 @@ def tiled_inference(model, img: torch.Tensor, crop_size=(1024, 1024), strides=(7
         stitching_rule: 'nms' (global NMS) and/or 'ex_br' (cpn_inference.py:382-388,405-408).
         rank, world_size, group: tile sharding; default = torch.distributed state (single process if uninitialised).
         forward_fn / ops_fns: injection points used by the CPU (gloo) tests of the sharding/gather logic.
+        mask: optional [H, W] (or [1, H, W]) foreground mask: tiles whose mask crop is empty are skipped and the crop
+            is passed as ``scores_upper_bound`` (TileLoader semantics, cpn_inference.py:94-100).
 
     Returns:
         OrderedDict of flat tensors (contours [K,S,2], boxes [K,4], scores [K], classes [K], locations [K,2],
@@ -119,8 +122,12 @@ def tiled_inference(model, img: torch.Tensor, crop_size=(1024, 1024), strides=(7
     slices, overlaps, shape = get_tiling_slices((H, W), crop_size, strides, return_overlaps=True)
     slices, overlaps = list(slices), list(overlaps)
     h_tiles, w_tiles = shape
-    mine = shard_tiles(len(slices), rank, world_size)
-    fwd = forward_fn if forward_fn is not None else (lambda x, offsets: model(x, offsets=offsets))
+    tile_ids = list(range(len(slices)))
+    if mask is not None:
+        mask = mask.reshape(mask.shape[-2:])
+        tile_ids = [i for i in tile_ids if bool(torch.any(mask[slices[i]]))]
+    mine = [tile_ids[j] for j in shard_tiles(len(tile_ids), rank, world_size)]
+    fwd = forward_fn if forward_fn is not None else (lambda x, offsets, **kw: model(x, offsets=offsets, **kw))
     nms_thresh = model.nms_thresh if nms_thresh is None else nms_thresh
     rules = stitching_rule.split(',')
     coll: Dict[str, List[torch.Tensor]] = {k: [] for k in KEYS}
@@ -129,7 +136,11 @@ def tiled_inference(model, img: torch.Tensor, crop_size=(1024, 1024), strides=(7
         idxs = mine[b0:b0 + batch_size]
         tiles = torch.stack([img[(...,) + slices[i]] for i in idxs])  # cropped on the device
         offs = torch.tensor([[slices[i][1].start, slices[i][0].start] for i in idxs], dtype=torch.int64)
-        y = fwd(tiles, offs)
+        if mask is not None:
+            ub = torch.stack([mask[slices[i]] for i in idxs])[:, None].to(device=tiles.device, dtype=torch.float32)
+            y = fwd(tiles, offs, scores_upper_bound=ub)
+        else:
+            y = fwd(tiles, offs)
         for n, i in enumerate(idxs):
             h_i, w_i = np.unravel_index(i, shape)
             con = y['contours'][n]
@@ -156,3 +167,50 @@ def tiled_inference(model, img: torch.Tensor, crop_size=(1024, 1024), strides=(7
         keep = nms_fn(res['boxes'], res['scores'], nms_thresh)
         res = OrderedDict((k, v[keep]) for k, v in res.items())
     return res
+
+
+@torch.no_grad()
+def forward_tiled(model, inputs: torch.Tensor, crop_size=1024, stride=512, border_removal: int = 6,
+                  min_box_size: float = 1., nms_thresh: Optional[float] = None, inputs_mask=None, batch_size: int = 8):
+    """In-model tiling variant (``LitCpn.forward_tiled``, celldetection/models/lightning_cpn.py:88-177): for a batch of
+    large images, tiles (default 1024 / 512) -> forward -> ``remove_small_boxes(min 1.0)`` -> border removal (6 px) ->
+    offsets -> concat -> ONE NMS per image.  Returns ``OrderedDict(contours, scores, boxes)`` of per-image lists."""
+    from . import ops
+    n_img = inputs.shape[0]
+    H, W = inputs.shape[-2:]
+    crop = (crop_size,) * 2 if np.isscalar(crop_size) else tuple(crop_size)
+    strd = (stride,) * 2 if np.isscalar(stride) else tuple(stride)
+    assert (np.array(crop) <= np.array(strd) * 2).all()
+    slices, shape = get_tiling_slices((H, W), crop, strd)
+    slices = list(slices)
+    h_tiles, w_tiles = shape
+    nms_thresh = model.nms_thresh if nms_thresh is None else nms_thresh
+    coll = [dict(contours=[], scores=[], boxes=[]) for _ in range(n_img)]
+    jobs = [(j, i) for i in range(len(slices)) for j in range(n_img)
+            if inputs_mask is None or bool(torch.any(inputs_mask[j][(...,) + slices[i]]))]
+    for b0 in range(0, len(jobs), batch_size):
+        chunk = jobs[b0:b0 + batch_size]
+        tiles = torch.stack([inputs[j][(...,) + slices[i]] for j, i in chunk])
+        offs = torch.tensor([[slices[i][1].start, slices[i][0].start] for _, i in chunk], dtype=torch.int64)
+        y = model(tiles, offsets=offs)
+        for n, (j, i) in enumerate(chunk):
+            h_i, w_i = np.unravel_index(i, shape)
+            boxes = y['boxes'][n]
+            keep = ((boxes[:, 2] - boxes[:, 0]) >= min_box_size) & ((boxes[:, 3] - boxes[:, 1]) >= min_box_size)
+            keep &= ops.remove_border_contours(y['contours'][n], tuple(tiles.shape[-2:]), border_removal, top=h_i > 0,
+                                               right=w_i < (w_tiles - 1), bottom=h_i < (h_tiles - 1), left=w_i > 0,
+                                               offsets=-offs[n])
+            for k in ('contours', 'scores', 'boxes'):
+                coll[j][k].append(y[k][n][keep])
+    final = OrderedDict(contours=[], scores=[], boxes=[])
+    dev = inputs.device
+    for j in range(n_img):
+        if coll[j]['scores']:
+            con, sco, box = (torch.cat(coll[j][k]) for k in ('contours', 'scores', 'boxes'))
+            keep = ops.nms(box, sco, nms_thresh)
+            con, sco, box = con[keep], sco[keep], box[keep]
+        else:
+            con = torch.zeros((0, model.samples, 2), device=dev)
+            sco, box = torch.zeros((0,), device=dev), torch.zeros((0, 4), device=dev)
+        final['contours'].append(con), final['scores'].append(sco), final['boxes'].append(box)
+    return final

@@ -212,3 +212,39 @@ def test_fp32_path_end_to_end_parity(dev, name):
     check_exact('nms', model(x), g, n, raw_atol=5e-4)
     check_exact('nonms', model(x, nms=False), g, n, raw_atol=5e-4)
     check_exact('offs', model(x, offsets=torch.as_tensor(g['offsets'])), g, n, raw_atol=5e-4)
+
+
+def test_forward_tiled_and_mask(dev):
+    """In-model tiling (LitCpn.forward_tiled semantics) and mask handling of the slide loop."""
+    import cpn_oracle as orc
+    from celldetection_amd import inference
+    model, g = build('CpnU22', dev, fixture='stitch.npz')
+    img = torch.as_tensor(g['img']).to(dev)  # [1, 3, 160, 224]
+    res = model.forward_tiled(img, crop_size=96, stride=64, border_removal=6)
+    assert list(res.keys()) == ['contours', 'scores', 'boxes'] and len(res['contours']) == 1
+    # oracle-side stitching of the same per-tile GPU outputs
+    slices, _, shape = orc.get_tiling_slices((160, 224), (96, 96), (64, 64))
+    cons, scos, boxs = [], [], []
+    for idx, ((h0, h1), (w0, w1)) in enumerate(slices):
+        offs = torch.tensor([[w0, h0]])
+        y = model(img[..., h0:h1, w0:w1], offsets=offs)
+        h_i, w_i = np.unravel_index(idx, shape)
+        con, box, sco = (y[k][0].cpu().numpy() for k in ('contours', 'boxes', 'scores'))
+        keep = ((box[:, 2] - box[:, 0]) >= 1.) & ((box[:, 3] - box[:, 1]) >= 1.)
+        keep &= orc.remove_border_contours(con, (96, 96), 6, top=h_i > 0, right=w_i < shape[1] - 1,
+                                           bottom=h_i < shape[0] - 1, left=w_i > 0,
+                                           offsets=-offs[0].numpy().astype(np.float32))
+        cons.append(con[keep]), scos.append(sco[keep]), boxs.append(box[keep])
+    con, sco, box = np.concatenate(cons), np.concatenate(scos), np.concatenate(boxs)
+    keep = orc.nms(box, sco, model.nms_thresh)
+    np.testing.assert_array_equal(res['contours'][0].cpu().numpy(), con[keep])
+    np.testing.assert_array_equal(res['scores'][0].cpu().numpy(), sco[keep])
+    # mask: an empty mask skips every tile; a half mask only yields detections on that half (+ tile context)
+    mask = torch.zeros(160, 224, device=dev)
+    out = inference.tiled_inference(model, img, (96, 96), (64, 64), mask=mask)
+    assert out['scores'].numel() == 0
+    mask[:, :112] = 1
+    out = inference.tiled_inference(model, img, (96, 96), (64, 64), mask=mask)
+    full = inference.tiled_inference(model, img, (96, 96), (64, 64))
+    assert 0 < out['scores'].numel() <= full['scores'].numel()
+    assert float(out['locations'][:, 0].max()) < 112 + 8
