@@ -1,0 +1,29 @@
+#!/bin/bash
+# Round-end GPU pass (run on the MI355X box through gpurun, from the repo root):
+#   tools/gpu_round_pass.sh <tag> [tests] [bench] [profile]
+# writes everything under gpurun_out/ (the summaries that should be judged are then copied into profiles/).
+TAG=${1:-r01}; shift
+WHAT=${*:-tests bench profile}
+cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
+P=/tmp/prof_$TAG; mkdir -p $P
+G="python tools/run_graph_only.py 5"
+for w in $WHAT; do case $w in
+tests)
+  timeout 900 python -m pytest tests -x -q -m gpu > gpurun_out/${TAG}_pytest_gpu.log 2>&1; tail -3 gpurun_out/${TAG}_pytest_gpu.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/${TAG}_smoke.log 2>&1; tail -1 gpurun_out/${TAG}_smoke.log;;
+bench)
+  timeout 600 python bench.py --steps 10 --warmup 3 --profile-layers > gpurun_out/${TAG}_bench_n1.json 2> gpurun_out/${TAG}_per_layer_timing.txt; cat gpurun_out/${TAG}_bench_n1.json;;
+profile)
+  (timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -o b -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline) > $P/trace.log 2>&1
+  (timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $P/gtrace -o b -- $G) > $P/gtrace.log 2>&1
+  (timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P/fetch -o b -- $G) > $P/fetch.log 2>&1
+  (timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $P/write -o b -- $G) > $P/write.log 2>&1
+  (timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VALU SQ_WAIT_ANY --output-format csv -d $P/mfma -o b -- $G) > $P/mfma.log 2>&1
+  (echo "### bench.py --steps 5 --warmup 2 under rocprofv3 --kernel-trace --stats"
+   python tools/summarize_rocprof.py $P/trace; echo
+   echo "### tools/run_graph_only.py 5 (5 conv-graph executions, batch 16): kernel-trace, FETCH_SIZE, WRITE_SIZE, MFMA/SQ counters"
+   python tools/summarize_rocprof.py $P/gtrace $P/fetch $P/write $P/mfma) > gpurun_out/${TAG}_rocprofv3_summary.txt 2>&1
+  grep -h "^{" $P/trace.log > gpurun_out/${TAG}_bench_lines_under_rocprof.txt
+  grep -A8 "run_graph_only" gpurun_out/${TAG}_rocprofv3_summary.txt | cut -c1-150;;
+esac; done
