@@ -36,9 +36,8 @@ def shard_tiles(num_tiles: int, rank: int, world_size: int) -> List[int]:
 def pack_detections(d: Dict[str, torch.Tensor]) -> torch.Tensor:
     """dict of [K, ...] tensors -> one float32 [K, D] struct-of-rows buffer (classes stored as float, exact)."""
     k = d['scores'].shape[0]
-    cols = [d[key].reshape(k, -1).to(torch.float32) for key in KEYS]
-    return torch.cat(cols, 1) if k else torch.zeros((0, sum(c.shape[1] for c in cols)), dtype=torch.float32,
-                                                    device=d['scores'].device)
+    cols = [d[key].reshape(k, int(np.prod(d[key].shape[1:]))).to(torch.float32) for key in KEYS]
+    return torch.cat(cols, 1)
 
 
 def unpack_detections(buf: torch.Tensor, samples: int, order: int) -> 'OrderedDict[str, torch.Tensor]':

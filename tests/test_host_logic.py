@@ -130,3 +130,14 @@ def test_weight_packing_layout(cfg):
     ref_bf = F.conv2d(xin, wf.float().to(torch.bfloat16).float(), bf.float(), stride, k // 2, 1, groups)
     assert torch.allclose(got, ref_bf, atol=1e-4, rtol=1e-4)
     assert (got - ref).abs().max() < 0.1
+
+
+def test_pack_unpack_empty_detections():
+    from celldetection_amd.inference import pack_detections, unpack_detections
+    d = dict(contours=torch.zeros(0, 32, 2), boxes=torch.zeros(0, 4), scores=torch.zeros(0),
+             classes=torch.zeros(0, dtype=torch.int64), locations=torch.zeros(0, 2), fourier=torch.zeros(0, 5, 4),
+             contour_proposals=torch.zeros(0, 32, 2))
+    buf = pack_detections(d)
+    assert tuple(buf.shape) == (0, 32 * 2 + 4 + 1 + 1 + 2 + 20 + 64)
+    out = unpack_detections(buf, 32, 5)
+    assert all(tuple(out[k].shape) == tuple(d[k].shape) for k in d)
