@@ -10,12 +10,13 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CPN_HIP_LIB') or os.path.join(HERE, 'libcpn_hip.so')  # env: kernel A/B tuning only
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 PRECISION_BF16, PRECISION_F32 = 0, 1
 
 OP_INPUT, OP_CONV, OP_MAXPOOL, OP_BILINEAR = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH_SCALED = 0, 1, 2, 3
-OUT_SCORES, OUT_LOCATIONS, OUT_FOURIER, OUT_REFINEMENT = 0, 1, 2, 3
+OUT_SCORES, OUT_LOCATIONS, OUT_FOURIER, OUT_REFINEMENT, OUT_UNCERTAINTY = 0, 1, 2, 3, 4
+NUM_OUTPUTS = 5
 
 
 class TensorDesc(Structure):
@@ -62,11 +63,17 @@ _SIGNATURES = [
     ('cpn_decode', ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                   c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                  c_void_p]),
+                                  c_int32, c_void_p, c_void_p, c_void_p]),
     ('cpn_fouriers2contours', ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                              c_void_p, c_void_p]),
     ('cpn_local_refinement', ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32,
-                                            c_int32, c_int32, c_void_p]),
+                                            c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    ('cpn_class_scores', ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_void_p]),
+    ('cpn_certainty_mask', ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p,
+                                          c_void_p]),
+    ('cpn_gather_channels', ctypes.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p,
+                                           c_void_p]),
     ('cpn_nms_workspace_bytes', c_int64, [c_int64, c_int64, c_int32]),
     ('cpn_nms', ctypes.c_int, [c_void_p, c_void_p, c_int64, POINTER(c_int64), c_void_p, c_int32, c_float, c_void_p,
                                c_void_p, c_void_p, c_int64, c_void_p]),

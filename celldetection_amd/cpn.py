@@ -125,14 +125,17 @@ class _Engine:
         x = x.contiguous()
         d = self.plan.meta['head_down']
         f32 = dict(dtype=torch.float32, device=self.device)
-        scores = torch.empty((n, 1, h // d, w // d), **f32)
+        meta = self.plan.meta
+        scores = torch.empty((n, meta.get('score_channels', 1), h // d, w // d), **f32)
         locations = torch.empty((n, 2, h // d, w // d), **f32)
         fourier = torch.empty((n, 4 * order_total, h // d, w // d), **f32)
-        ref = torch.empty((n, 2, h, w), **f32) if refinement else None
+        ref = torch.empty((n, 2 * meta.get('refinement_buckets', 1), h, w), **f32) if refinement else None
+        self.last_uncertainty = torch.empty((n, 4, h // d, w // d), **f32) if meta.get('uncertainty_head') else None
         flag = torch.zeros(1, dtype=torch.int32, device=self.device)
         ws, need = self.workspace(n, h, w)
-        outs = (c_void_p * 4)(scores.data_ptr(), locations.data_ptr(), fourier.data_ptr(),
-                              0 if ref is None else ref.data_ptr())
+        outs = (c_void_p * _lib.NUM_OUTPUTS)(scores.data_ptr(), locations.data_ptr(), fourier.data_ptr(),
+                                             0 if ref is None else ref.data_ptr(),
+                                             0 if self.last_uncertainty is None else self.last_uncertainty.data_ptr())
         if _timed is not None:
             _lib.check(lib.cpn_plan_run_timed(self.handle, _lib.ptr(x), dt, n, h, w, _lib.ptr(ws), need, outs,
                                               _lib.ptr(flag), _lib.stream_ptr(), _timed[0], _timed[1]), 'plan_run_timed')
@@ -159,13 +162,15 @@ class CPN(nn.Module):
                  refinement_buckets: int = 1, uncertainty_head=False, uncertainty_nms=False, order_weights=True,
                  backbone_kwargs: dict = None, **kwargs):
         super().__init__()
-        if uncertainty_head:
-            raise NotImplementedError('uncertainty_head is not implemented on the HIP path')
-        unsupported = {k: v for k, v in kwargs.items() if k in ('contour_head_channels', 'refinement_head_channels',
-                                                                'contour_head_stride', 'refinement_head_stride')
-                       and v not in (None, 1)}
+        unsupported = {k: v for k, v in kwargs.items() if (k in ('contour_head_stride', 'refinement_head_stride')
+                                                           and v not in (None, 1))
+                       or (k in ('contour_features', 'location_features', 'score_features', 'uncertainty_features')
+                           and v != '1') or (k == 'refinement_features' and v != '0')
+                       or (k == 'refinement_interpolation' and v != 'bilinear')
+                       or (k.startswith('head_activation') and v != 'relu')}
         if unsupported:
             raise NotImplementedError(f'Unsupported CPN options on the HIP path: {unsupported}')
+        kernel_sizes = {k[len('kernel_size_'):]: int(v) for k, v in kwargs.items() if k.startswith('kernel_size_')}
         self.order = order
         self.nms_thresh = nms_thresh
         self.samples = samples
@@ -183,12 +188,13 @@ class CPN(nn.Module):
         self._plan_kwargs = dict(backbone=backbone, in_channels=in_channels, order=order,
                                  score_channels=self.score_channels, refinement=refinement,
                                  refinement_margin=refinement_margin, refinement_buckets=refinement_buckets,
-                                 order_weights=bool(order_weights), backbone_kwargs=backbone_kwargs)
+                                 order_weights=bool(order_weights), backbone_kwargs=backbone_kwargs,
+                                 uncertainty_head=bool(uncertainty_head),
+                                 contour_head_channels=kwargs.get('contour_head_channels'),
+                                 refinement_head_channels=kwargs.get('refinement_head_channels'),
+                                 kernel_sizes=kernel_sizes)
         self.precision = 'bf16'  # 'bf16' (MFMA performance path) | 'fp32' (verification path, ~100x slower)
-        self._plan = graph.build_plan(backbone, in_channels, order=order, score_channels=self.score_channels,
-                                      refinement=refinement, refinement_margin=refinement_margin,
-                                      refinement_buckets=refinement_buckets, order_weights=bool(order_weights),
-                                      backbone_kwargs=backbone_kwargs)
+        self._plan = graph.build_plan(**self._plan_kwargs)
         for key, shape, kind in self._plan.entries:
             _register(self, key, shape, kind)
         self.core.order = order
@@ -245,6 +251,7 @@ class CPN(nn.Module):
         eng = self.engine(inputs.device)
         scores, locations, refinement, fourier, flag = eng.run(inputs, self.core.order, self.refinement)
         self._last_flag = flag
+        self._last_uncertainty = eng.last_uncertainty  # fifth CPNCore output (cpn.py:283), [N,4,h,w] or None
         return scores, locations, refinement, fourier
 
     @torch.no_grad()
@@ -256,7 +263,7 @@ class CPN(nn.Module):
         original_size = tuple(inputs.shape[-2:])
         scores, locations, refinement, fourier = self.core_forward(inputs)
         return self.postprocess(scores, locations, refinement, fourier, original_size, nms=nms, flag=self._last_flag,
-                                **kwargs)
+                                uncertainty=self._last_uncertainty, **kwargs)
 
     def forward_tiled(self, inputs, crop_size=1024, stride=512, **kwargs):
         """In-model tiling (celldetection/models/lightning_cpn.py:88-177); see ``inference.forward_tiled``."""
@@ -264,31 +271,54 @@ class CPN(nn.Module):
         return inference.forward_tiled(self, inputs, crop_size=crop_size, stride=stride, **kwargs)
 
     @torch.no_grad()
-    def postprocess(self, scores, locations, refinement, fourier, original_size, nms=True, flag=None, **kwargs):
-        """CPN.forward after the core (cpn.py:575-734) on given head maps: ``scores`` are probabilities
-        (sigmoid already applied) [N,1,h,w]; locations [N,2,h,w]; refinement [N,2,H,W] or None; fourier [N,4*O,h,w]."""
+    def postprocess(self, scores, locations, refinement, fourier, original_size, nms=True, flag=None,
+                    uncertainty=None, **kwargs):
+        """CPN.forward after the core (cpn.py:575-734) on given head maps: ``scores`` [N,1,h,w] probabilities (sigmoid
+        already applied; binary CPNs) or [N,classes,h,w] raw logits (multi-class, cpn.py:583-585); locations [N,2,h,w];
+        refinement [N,2*buckets,H,W] or None; fourier [N,4*O,h,w]; uncertainty [N,4,h,w] or None (cpn.py:209-221)."""
         n = scores.shape[0]
         lb, ub = kwargs.get('scores_lower_bound'), kwargs.get('scores_upper_bound')
-        if ub is not None:  # cpn.py:118-123
-            scores = torch.minimum(scores, _equal_size(ub.to(scores), scores))
-        if lb is not None:
-            scores = torch.maximum(scores, _equal_size(lb.to(scores), scores))
+        ub = None if ub is None else _equal_size(ub.to(scores), scores)  # cpn.py:118-123
+        lb = None if lb is None else _equal_size(lb.to(scores), scores)
+        class_map = None
+        if scores.shape[1] == 1:
+            if ub is not None:
+                scores = torch.minimum(scores, ub)
+            if lb is not None:
+                scores = torch.maximum(scores, lb)
+            select_map, thresh = scores, self.score_thresh
+        else:  # softmax + bounds + argmax; proposals are the pixels whose class is > 0 (cpn.py:583-585,614)
+            scores, class_map, select_map, _ = ops.class_scores(scores, lb, ub)
+            thresh = .5
+        if self.certainty_thresh is not None and uncertainty is not None:  # cpn.py:617-618
+            select_map = ops.certainty_mask(select_map, uncertainty, self.certainty_thresh)
+            if class_map is not None:
+                thresh = .5  # foreground map is 1 / 0 / -1
         order = min(self.order, self.core.order)  # cpn.py:597-598
-        indices, counts, flag_v = ops.compact_scores(scores, self.score_thresh, extra_flag=flag)
+        indices, counts, flag_v = ops.compact_scores(select_map, thresh, extra_flag=flag)
         if flag_v:
             raise AssertionError('Inputs should be in interval (0.0, 1.0)')  # models/commons.py:696-697
         iters = self.refinement_iterations if (self.refinement and refinement is not None) else 0
         flat = ops.decode_proposals(indices, scores, locations, fourier, refinement if iters > 0 else None,
                                     size=original_size, order=order, samples=self.samples, iterations=iters,
-                                    offsets=kwargs.get('offsets'))
+                                    offsets=kwargs.get('offsets'), num_buckets=self.core.refinement_buckets)
         offs = [0]
         for c in counts:
             offs.append(offs[-1] + c)
-        flat['classes'] = torch.ones((offs[-1],), dtype=torch.int64, device=scores.device)
-        keys = ('contours', 'boxes', 'scores', 'classes', 'locations', 'fourier', 'contour_proposals')
+        if class_map is None:
+            flat['classes'] = torch.ones((offs[-1],), dtype=torch.int64, device=scores.device)
+        else:
+            flat['classes'] = class_map.reshape(-1)[indices.long()].to(torch.int64)
+        keys = ['contours', 'boxes', 'scores', 'classes', 'locations', 'fourier', 'contour_proposals']
+        nms_weights = flat['scores']
+        if uncertainty is not None:  # cpn.py:634-636,723-726
+            flat['box_uncertainties'] = ops.gather_channels(uncertainty, indices)
+            keys.append('box_uncertainties')
+            if self.uncertainty_nms:
+                nms_weights = flat['scores'] * (1. - flat['box_uncertainties'].mean(1))
         if nms and max(counts + [0]) <= ops.NMS_BATCH_SIZE and offs[-1] > 0:
             # one segmented NMS over all images + ONE gather per output key (instead of N x 7 small index kernels)
-            keep, kc = ops._nms_segments(flat['boxes'], flat['scores'], offs, self.nms_thresh)
+            keep, kc = ops._nms_segments(flat['boxes'], nms_weights, offs, self.nms_thresh)
             sel = torch.cat([keep[offs[i]:offs[i] + kc[i]] for i in range(n)])
             flat = {k: flat[k].index_select(0, sel) for k in keys}  # cpn.py:53-60
             offs = [0]
@@ -296,9 +326,11 @@ class CPN(nn.Module):
                 offs.append(offs[-1] + c)
             nms = False
         outputs = OrderedDict((k, [flat[k][offs[i]:offs[i + 1]] for i in range(n)]) for k in keys)  # cpn.py:42-50
-        outputs['box_uncertainties'] = None
+        if 'box_uncertainties' not in outputs:
+            outputs['box_uncertainties'] = None
         if nms:  # > NMS_BATCH_SIZE proposals in one image: the reference's chunked procedure (ops/cpn.py:212-224)
-            keep = ops.batched_box_nmsi(outputs['boxes'], outputs['scores'], self.nms_thresh)
+            weights = [nms_weights[offs[i]:offs[i + 1]] for i in range(n)]
+            keep = ops.batched_box_nmsi(outputs['boxes'], weights, self.nms_thresh)
             for k in keys:
                 outputs[k] = [v[kp] for v, kp in zip(outputs[k], keep)]
         return outputs

@@ -115,16 +115,41 @@ __device__ __forceinline__ float synth(const float *coef, int order, int samples
     return __fadd_rn(v, c);
 }
 
+// bucketed refinement (models/cpn.py:72-82, ops/cpn.py:238-255): sample s blends the channel pairs of three
+// neighbouring buckets; idx/w are host-built [3][samples] tables (bucket index, weight) in the reference's order a,b,c
+struct Buckets {
+    int n;               // refinement_buckets (1 = plain two-channel map)
+    const int32_t *idx;  // [3][samples]
+    const float *w;      // [3][samples]
+    int samples;
+};
+
 __device__ __forceinline__ void refine_point(float &cx, float &cy, const float *__restrict__ ref_b, int H, int W,
-                                             int iterations) {
+                                             int iterations, const Buckets &B, int s) {
     // models/cpn.py:63-85: round (half to even) -> clamp -> gather -> add
+    const size_t plane = (size_t) H * W;
     for (int it = 0; it < iterations; ++it) {
         cx = fminf(fmaxf(rintf(cx), 0.f), (float) (W - 1));
         cy = fminf(fmaxf(rintf(cy), 0.f), (float) (H - 1));
         const int ix = (int) cx, iy = (int) cy;
         const size_t o = (size_t) iy * W + ix;
-        cx = __fadd_rn(cx, ref_b[o]);
-        cy = __fadd_rn(cy, ref_b[(size_t) H * W + o]);
+        if (B.n <= 1) {
+            cx = __fadd_rn(cx, ref_b[o]);
+            cy = __fadd_rn(cy, ref_b[plane + o]);
+        } else {  // responses = (r_a*w_a + r_b*w_b) + r_c*w_c, every product and sum rounded (cpn.py:76-81)
+            float rx = 0.f, ry = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int bi = B.idx[k * B.samples + s];
+                const float wk = B.w[k * B.samples + s];
+                const float tx = __fmul_rn(ref_b[(size_t) (2 * bi) * plane + o], wk);
+                const float ty = __fmul_rn(ref_b[(size_t) (2 * bi + 1) * plane + o], wk);
+                rx = k == 0 ? tx : __fadd_rn(rx, tx);
+                ry = k == 0 ? ty : __fadd_rn(ry, ty);
+            }
+            cx = __fadd_rn(cx, rx);
+            cy = __fadd_rn(cy, ry);
+        }
     }
 }
 
@@ -137,6 +162,7 @@ struct DecodeArgs {
     const int64_t *offsets;
     float *contours, *proposals, *boxes, *out_scores, *out_locations, *out_fourier;
     int32_t *batch_index;
+    Buckets bk;
 };
 
 __global__ __launch_bounds__(DWAVES *WAVE) void decode_kernel(const DecodeArgs a) {
@@ -169,7 +195,7 @@ __global__ __launch_bounds__(DWAVES *WAVE) void decode_kernel(const DecodeArgs a
         offy = (float) a.offsets[b * 2 + 1];
     }
     const bool do_refine = a.refinement != nullptr && a.iterations > 0;
-    const float *ref_b = do_refine ? a.refinement + (size_t) b * 2 * a.H * a.W : nullptr;
+    const float *ref_b = do_refine ? a.refinement + (size_t) b * 2 * (a.bk.n < 1 ? 1 : a.bk.n) * a.H * a.W : nullptr;
     float mnx = __builtin_inff(), mny = __builtin_inff(), mxx = -__builtin_inff(), mxy = -__builtin_inff();
     for (int s = lane; s < a.samples; s += 64) {
         float px = synth(coef, a.order, a.samples, s, 1, 0, a.cos_t, a.sin_t, lx);
@@ -177,7 +203,7 @@ __global__ __launch_bounds__(DWAVES *WAVE) void decode_kernel(const DecodeArgs a
         px = __fmul_rn(px, sx);  // scale_contours, ops/cpn.py:106-130
         py = __fmul_rn(py, sy);
         float cx = px, cy = py;
-        if (do_refine) refine_point(cx, cy, ref_b, a.H, a.W, a.iterations);
+        if (do_refine) refine_point(cx, cy, ref_b, a.H, a.W, a.iterations, a.bk, s);
         cx = fminf(fmaxf(cx, 0.f), (float) (a.W - 1));  // models/cpn.py:661-663
         cy = fminf(fmaxf(cy, 0.f), (float) (a.H - 1));
         if (!do_refine) { px = cx; py = cy; }  // proposals alias the contours tensor in the reference
@@ -225,12 +251,13 @@ __global__ __launch_bounds__(DWAVES *WAVE) void f2c_kernel(const float *__restri
 
 __global__ __launch_bounds__(256) void refine_kernel(float *__restrict__ contours, const int32_t *__restrict__ bidx,
                                                     long total, int samples, const float *__restrict__ refinement,
-                                                    int H, int W, int iterations) {
+                                                    int H, int W, int iterations, const Buckets bk) {
     const long i = blockIdx.x * 256l + threadIdx.x;
     if (i >= total) return;
     const int b = bidx[i / samples];
     float cx = contours[i * 2], cy = contours[i * 2 + 1];
-    refine_point(cx, cy, refinement + (size_t) b * 2 * H * W, H, W, iterations);
+    refine_point(cx, cy, refinement + (size_t) b * 2 * (bk.n < 1 ? 1 : bk.n) * H * W, H, W, iterations, bk,
+                 (int) (i % samples));
     contours[i * 2] = cx;
     contours[i * 2 + 1] = cy;
 }
@@ -253,6 +280,67 @@ __global__ __launch_bounds__(256) void border_kernel(const float *__restrict__ c
     }
     const bool all_ok = __all(ok);
     if (lane == 0) keep[p] = all_ok ? 1 : 0;
+}
+
+// =========================================================================================================
+// 2b. score variants: multi-class softmax/argmax (models/cpn.py:583-585,631-632), certainty filter (cpn.py:617-618),
+//     per-proposal channel gather (cpn.py:634-636)
+// =========================================================================================================
+// one thread per pixel: probs = softmax(logits) over C channels, bounds (min with upper, max with lower) applied to
+// every channel, cls = first argmax; sel = probs[cls]; fg = cls > 0
+__global__ __launch_bounds__(256) void class_scores_kernel(const float *__restrict__ logits, int N, int C, int hw,
+                                                          const float *__restrict__ lower,
+                                                          const float *__restrict__ upper, float *__restrict__ probs,
+                                                          float *__restrict__ sel, int32_t *__restrict__ cls,
+                                                          float *__restrict__ fg) {
+    const long i = blockIdx.x * 256l + threadIdx.x;
+    if (i >= (long) N * hw) return;
+    const int b = (int) (i / hw);
+    const long pos = i - (long) b * hw;
+    const float *lg = logits + (size_t) b * C * hw + pos;
+    float mx = lg[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, lg[(size_t) c * hw]);
+    float sum = 0.f;
+    for (int c = 0; c < C; ++c) sum = __fadd_rn(sum, expf(__fsub_rn(lg[(size_t) c * hw], mx)));
+    const float ub = upper ? upper[i] : __builtin_inff(), lb = lower ? lower[i] : -__builtin_inff();
+    float best = -__builtin_inff();
+    int arg = 0;
+    for (int c = 0; c < C; ++c) {
+        float p = __fdiv_rn(expf(__fsub_rn(lg[(size_t) c * hw], mx)), sum);
+        p = fmaxf(fminf(p, ub), lb);
+        if (probs) probs[(size_t) b * C * hw + (size_t) c * hw + pos] = p;
+        if (p > best) { best = p; arg = c; }
+    }
+    sel[i] = best;
+    cls[i] = arg;
+    fg[i] = arg > 0 ? 1.f : 0.f;
+}
+
+// out = mean_c(uncertainty) < limit ? scores : -1   (fg_mask &= uncertainty.mean(1) < 1 - certainty_thresh)
+__global__ __launch_bounds__(256) void certainty_kernel(const float *__restrict__ scores,
+                                                       const float *__restrict__ unc, int N, int C, int hw, float limit,
+                                                       float *__restrict__ out) {
+    const long i = blockIdx.x * 256l + threadIdx.x;
+    if (i >= (long) N * hw) return;
+    const int b = (int) (i / hw);
+    const long pos = i - (long) b * hw;
+    float s = unc[(size_t) b * C * hw + pos];
+    for (int c = 1; c < C; ++c) s = __fadd_rn(s, unc[(size_t) b * C * hw + (size_t) c * hw + pos]);
+    const float m = __fdiv_rn(s, (float) C);
+    out[i] = m < limit ? scores[i] : -1.f;
+}
+
+// out[p][c] = map[b][c][pos] for the linear pixel index lin = b*hw + pos of proposal p
+__global__ __launch_bounds__(256) void gather_channels_kernel(const float *__restrict__ map,
+                                                             const int32_t *__restrict__ indices, long P, int C, int hw,
+                                                             float *__restrict__ out) {
+    const long i = blockIdx.x * 256l + threadIdx.x;
+    if (i >= P * C) return;
+    const long p = i / C;
+    const int c = (int) (i - p * C);
+    const int lin = indices[p];
+    const int b = lin / hw;
+    out[i] = map[(size_t) b * C * hw + (size_t) c * hw + (lin - b * hw)];
 }
 
 // =========================================================================================================
@@ -435,13 +523,16 @@ int cpn_decode(const int32_t *indices, int32_t P, const float *scores, const flo
                const float *refinement, int32_t N, int32_t h, int32_t w, int32_t H, int32_t W, int32_t order_total,
                int32_t order, int32_t samples, int32_t iterations, const float *cos_table, const float *sin_table,
                const int64_t *offsets, float *contours, float *proposals, float *boxes, float *out_scores,
-               float *out_locations, float *out_fourier, int32_t *batch_index, void *stream) {
+               float *out_locations, float *out_fourier, int32_t *batch_index, int32_t buckets,
+               const int32_t *bucket_index, const float *bucket_weight, void *stream) {
     if (P < 0 || order < 1 || order > order_total || order * 4 > MAX_COEF || samples < 1)
         return cpn::fail(CPN_E_INVALID, "cpn_decode: bad arguments (need 1 <= order <= min(order_total, 64))");
+    if (buckets > 1 && refinement && iterations > 0 && (!bucket_index || !bucket_weight))
+        return cpn::fail(CPN_E_INVALID, "cpn_decode: refinement_buckets > 1 needs the bucket tables");
     if (P == 0) return 0;
     DecodeArgs a{indices, P, scores, locations, fourier, refinement, N, h, w, H, W, order_total, order, samples,
                  iterations, cos_table, sin_table, offsets, contours, proposals, boxes, out_scores, out_locations,
-                 out_fourier, batch_index};
+                 out_fourier, batch_index, Buckets{buckets, bucket_index, bucket_weight, samples}};
     hipLaunchKernelGGL(decode_kernel, dim3((P + DWAVES - 1) / DWAVES), dim3(DWAVES * WAVE), 0, (hipStream_t) stream, a);
     return cpn::check_hip(hipGetLastError(), "cpn_decode");
 }
@@ -457,13 +548,50 @@ int cpn_fouriers2contours(const float *fourier, const float *locations, int32_t 
 }
 
 int cpn_local_refinement(float *contours, const int32_t *batch_index, int32_t P, int32_t samples,
-                         const float *refinement, int32_t N, int32_t H, int32_t W, int32_t iterations, void *stream) {
+                         const float *refinement, int32_t N, int32_t H, int32_t W, int32_t iterations,
+                         int32_t buckets, const int32_t *bucket_index, const float *bucket_weight, void *stream) {
     (void) N;
     if (P <= 0 || iterations <= 0) return 0;
+    if (buckets > 1 && (!bucket_index || !bucket_weight))
+        return cpn::fail(CPN_E_INVALID, "cpn_local_refinement: refinement_buckets > 1 needs the bucket tables");
     const long total = (long) P * samples;
     hipLaunchKernelGGL(refine_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, (hipStream_t) stream,
-                       contours, batch_index, total, samples, refinement, H, W, iterations);
+                       contours, batch_index, total, samples, refinement, H, W, iterations,
+                       Buckets{buckets, bucket_index, bucket_weight, samples});
     return cpn::check_hip(hipGetLastError(), "cpn_local_refinement");
+}
+
+int cpn_class_scores(const float *logits, int32_t N, int32_t C, int32_t h, int32_t w, const float *lower,
+                     const float *upper, float *probs, float *selected, int32_t *classes, float *foreground,
+                     void *stream) {
+    if (N < 0 || C < 1 || !logits || !selected || !classes || !foreground)
+        return cpn::fail(CPN_E_INVALID, "cpn_class_scores: bad arguments");
+    const long total = (long) N * h * w;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(class_scores_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, (hipStream_t) stream,
+                       logits, N, C, h * w, lower, upper, probs, selected, classes, foreground);
+    return cpn::check_hip(hipGetLastError(), "cpn_class_scores");
+}
+
+int cpn_certainty_mask(const float *scores, const float *uncertainty, int32_t N, int32_t C, int32_t h, int32_t w,
+                       float limit, float *out, void *stream) {
+    if (N < 0 || C < 1 || !scores || !uncertainty || !out)
+        return cpn::fail(CPN_E_INVALID, "cpn_certainty_mask: bad arguments");
+    const long total = (long) N * h * w;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(certainty_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, (hipStream_t) stream,
+                       scores, uncertainty, N, C, h * w, limit, out);
+    return cpn::check_hip(hipGetLastError(), "cpn_certainty_mask");
+}
+
+int cpn_gather_channels(const float *map, const int32_t *indices, int64_t P, int32_t C, int32_t h, int32_t w,
+                        float *out, void *stream) {
+    if (P < 0 || C < 1) return cpn::fail(CPN_E_INVALID, "cpn_gather_channels: bad arguments");
+    if (P == 0) return 0;
+    const long total = (long) P * C;
+    hipLaunchKernelGGL(gather_channels_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t) stream, map, indices, (long) P, C, h * w, out);
+    return cpn::check_hip(hipGetLastError(), "cpn_gather_channels");
 }
 
 int cpn_border_keep(const float *contours, int64_t P, int32_t samples, float off_x, float off_y, float h, float w,

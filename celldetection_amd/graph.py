@@ -279,14 +279,17 @@ def _readout(P, x, cmid, cout, prefix, act, act_scale, out_index, k=7, fuse=True
 
 def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: int = 1, refinement: bool = True,
                refinement_margin: float = 3., refinement_buckets: int = 1, order_weights: bool = True,
-               backbone_kwargs: dict = None, fuse_readout: bool = True) -> Plan:
-    """Plan of ``Cpn<backbone>`` (celldetection/models/cpn.py:287-439,771-2061)."""
+               backbone_kwargs: dict = None, fuse_readout: bool = True, uncertainty_head: bool = False,
+               contour_head_channels: int = None, refinement_head_channels: int = None,
+               kernel_sizes: dict = None) -> Plan:
+    """Plan of ``Cpn<backbone>`` (celldetection/models/cpn.py:287-439,771-2061; heads: CPNCore.__init__
+    cpn.py:125-236).  ``kernel_sizes``: optional {'score'|'location'|'fourier'|'uncertainty'|'refinement': k}
+    (the reference's ``kernel_size_<head>`` kwargs, default 7)."""
     if backbone not in BACKBONES:
         raise ValueError(f'Unsupported backbone {backbone!r}; supported: {sorted(BACKBONES)}')
-    if score_channels != 1:
-        raise NotImplementedError('Only binary CPNs (classes in (1, 2)) are implemented on the HIP path.')
-    if refinement_buckets != 1:
-        raise NotImplementedError('refinement_buckets > 1 is not implemented on the HIP path.')
+    if score_channels < 1 or refinement_buckets < 1:
+        raise ValueError('score_channels and refinement_buckets must be >= 1')
+    ks = dict(kernel_sizes or {})
     family, enc = BACKBONES[backbone]
     bkw = dict(backbone_kwargs or {})
     P = Plan()
@@ -311,16 +314,27 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
         f0, f1 = outs[0], outs[1]
         c0 = c1 = fc
         scale = P.tensors[f1]['down']
-    _readout(P, f1, c1, score_channels, 'core.score_head.', 'sigmoid', 0., _lib.OUT_SCORES, fuse=fuse_readout)
-    _readout(P, f1, c1, 2, 'core.location_head.', 'none', 0., _lib.OUT_LOCATIONS, fuse=fuse_readout)
-    _readout(P, f1, c1, order * 4, 'core.fourier_head.', 'none', 0., _lib.OUT_FOURIER, fuse=fuse_readout)
+    cm1 = c1 if contour_head_channels is None else int(contour_head_channels)
+    cm0 = c0 if refinement_head_channels is None else int(refinement_head_channels)
+    # binary: sigmoid fused into the head; multi-class: raw logits, softmax/argmax in cpn_class_scores (cpn.py:583-585)
+    _readout(P, f1, cm1, score_channels, 'core.score_head.', 'sigmoid' if score_channels == 1 else 'none', 0.,
+             _lib.OUT_SCORES, k=ks.get('score', 7), fuse=fuse_readout)
+    _readout(P, f1, cm1, 2, 'core.location_head.', 'none', 0., _lib.OUT_LOCATIONS, k=ks.get('location', 7),
+             fuse=fuse_readout)
+    _readout(P, f1, cm1, order * 4, 'core.fourier_head.', 'none', 0., _lib.OUT_FOURIER, k=ks.get('fourier', 7),
+             fuse=fuse_readout)
+    if uncertainty_head:  # cpn.py:209-221: 4 channels, sigmoid
+        _readout(P, f1, cm1, 4, 'core.uncertainty_head.', 'sigmoid', 0., _lib.OUT_UNCERTAINTY,
+                 k=ks.get('uncertainty', 7), fuse=fuse_readout)
     if refinement:
         r = f0
         while P.tensors[r]['down'] > 1:  # cpn.py:277-278: bilinear resize of the features to the input size
             r = P.bilinear_up2(r)
-        _readout(P, r, c0, 2 * refinement_buckets, 'core.refinement_head.', 'tanh_scaled', float(refinement_margin),
-                 _lib.OUT_REFINEMENT, fuse=fuse_readout)
-    P.meta = dict(backbone=backbone, order=order, head_down=scale, refinement=refinement, in_channels=in_channels)
+        _readout(P, r, cm0, 2 * refinement_buckets, 'core.refinement_head.', 'tanh_scaled', float(refinement_margin),
+                 _lib.OUT_REFINEMENT, k=ks.get('refinement', 7), fuse=fuse_readout)
+    P.meta = dict(backbone=backbone, order=order, head_down=scale, refinement=refinement, in_channels=in_channels,
+                  score_channels=score_channels, refinement_buckets=refinement_buckets,
+                  uncertainty_head=bool(uncertainty_head))
     return P
 
 

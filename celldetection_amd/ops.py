@@ -16,7 +16,7 @@ from ._lib import check, ptr, stream_ptr
 
 __all__ = ['fouriers2contours', 'local_refinement', 'nms', 'batched_box_nmsi', 'remove_border_contours',
            'filter_contours_by_stitching_rule', 'compact_scores', 'decode_proposals', 'sampling_tables',
-           'NMS_BATCH_SIZE']
+           'bucket_tables', 'class_scores', 'certainty_mask', 'gather_channels', 'NMS_BATCH_SIZE']
 
 NMS_BATCH_SIZE = 50000  # celldetection/ops/cpn.py:12
 
@@ -43,6 +43,26 @@ def sampling_tables(order: int, samples: int, device):
     return _table_cache[key]
 
 
+def bucket_tables(samples: int, num_buckets: int, device):
+    """Per-sample bucket numbers and blend weights of bucketed refinement for the default sampling
+    t = linspace(0, 1, S), built on the CPU with the reference's arithmetic (resolve_refinement_buckets /
+    refinement_bucket_weight, celldetection/ops/cpn.py:238-255): base = t * buckets; for j in (int(base) - 1,
+    int(base), int(base) + 1): bucket j mod buckets with weight max(0, 1 - |j + 0.5 - base|) (0 beyond distance 1).
+    Returns (int32 [3, S], float32 [3, S]) on ``device``."""
+    key = ('buckets', samples, num_buckets, str(device))
+    if key not in _table_cache:
+        base = torch.linspace(0, 1.0, samples) * num_buckets
+        whole = base.long()
+        idx, wgt = [], []
+        for j in (whole - 1, whole, whole + 1):
+            dist = torch.abs(j + 0.5 - base)
+            wgt.append(torch.where(dist > 1, torch.zeros_like(dist), 1. - dist))
+            idx.append(j % num_buckets)
+        _table_cache[key] = (torch.stack(idx).to(torch.int32).contiguous().to(device),
+                             torch.stack(wgt).to(torch.float32).contiguous().to(device))
+    return _table_cache[key]
+
+
 def fouriers2contours(fourier: Tensor, locations: Tensor, samples: int = 64, sampling=None, cache=None):
     """celldetection/ops/cpn.py:44-95 (default sampling only). fourier [..., order, 4], locations [..., 2]
     -> (contours [..., samples, 2], sampling)."""
@@ -61,17 +81,21 @@ def fouriers2contours(fourier: Tensor, locations: Tensor, samples: int = 64, sam
     return out.reshape(*lead, samples, 2), torch.linspace(0, 1.0, samples, device=f.device)
 
 
-def local_refinement(contours: Tensor, refinement: Tensor, num_loops: int, b: Tensor, original_size=None):
-    """celldetection/models/cpn.py:63-85 with num_buckets == 1. contours [P,S,2], refinement [N,2,H,W], b [P]."""
+def local_refinement(contours: Tensor, refinement: Tensor, num_loops: int, b: Tensor, original_size=None,
+                     num_buckets: int = 1):
+    """celldetection/models/cpn.py:63-85 (default sampling). contours [P,S,2], refinement [N,2*buckets,H,W], b [P]."""
     _need_cuda(contours, refinement, b)
     c = contours.contiguous().float().clone()
     r = refinement.contiguous().float()
-    N, _, H, W = r.shape
+    N, ch, H, W = r.shape
+    if ch != 2 * num_buckets:
+        raise ValueError(f'refinement tensor must have 2 * num_buckets = {2 * num_buckets} channels, got {ch}')
     if original_size is not None and tuple(original_size) != (H, W):
         raise ValueError('refinement tensor must have the original size')
     bi = b.to(torch.int32).contiguous()
+    bidx, bw = bucket_tables(c.shape[1], num_buckets, c.device) if num_buckets > 1 else (None, None)
     check(_lib.load().cpn_local_refinement(ptr(c), ptr(bi), c.shape[0], c.shape[1], ptr(r), N, H, W, int(num_loops),
-                                           stream_ptr()), 'local_refinement')
+                                           int(num_buckets), ptr(bidx), ptr(bw), stream_ptr()), 'local_refinement')
     return c
 
 
@@ -203,8 +227,49 @@ def compact_scores(scores: Tensor, thresh: float, extra_flag: Tensor = None):
     return indices[:total], host[:N], flag
 
 
+def class_scores(logits: Tensor, lower=None, upper=None, return_probs: bool = False):
+    """Multi-class score path (celldetection/models/cpn.py:583-585): softmax over the class planes, score bounds,
+    argmax.  logits [N,C,h,w]; lower/upper [N,1,h,w] or None -> (selected [N,1,h,w] = probability of the argmax
+    class, classes int32 [N,h,w], foreground float [N,1,h,w] (1 where class > 0), probs [N,C,h,w] or None)."""
+    _need_cuda(logits, lower, upper)
+    x = logits.contiguous().float()
+    N, C, h, w = x.shape
+    f32 = dict(dtype=torch.float32, device=x.device)
+    sel, fg = torch.empty((N, 1, h, w), **f32), torch.empty((N, 1, h, w), **f32)
+    cls = torch.empty((N, h, w), dtype=torch.int32, device=x.device)
+    probs = torch.empty((N, C, h, w), **f32) if return_probs else None
+    lo = None if lower is None else lower.contiguous().float()
+    up = None if upper is None else upper.contiguous().float()
+    check(_lib.load().cpn_class_scores(ptr(x), N, C, h, w, ptr(lo), ptr(up), ptr(probs), ptr(sel), ptr(cls), ptr(fg),
+                                       stream_ptr()), 'class_scores')
+    return sel, cls, fg, probs
+
+
+def certainty_mask(scores: Tensor, uncertainty: Tensor, certainty_thresh: float):
+    """scores where ``uncertainty.mean(1) < 1 - certainty_thresh`` else -1 (celldetection/models/cpn.py:617-618)."""
+    _need_cuda(scores, uncertainty)
+    s, u = scores.contiguous().float(), uncertainty.contiguous().float()
+    N, C, h, w = u.shape
+    out = torch.empty_like(s)
+    check(_lib.load().cpn_certainty_mask(ptr(s), ptr(u), N, C, h, w, float(1 - certainty_thresh), ptr(out),
+                                         stream_ptr()), 'certainty_mask')
+    return out
+
+
+def gather_channels(maps: Tensor, indices: Tensor):
+    """maps [N,C,h,w] fp32, indices int32 [P] (linear (b,y,x) pixel indices of ``compact_scores``) -> [P,C]."""
+    _need_cuda(maps, indices)
+    m = maps.contiguous().float()
+    N, C, h, w = m.shape
+    P = int(indices.shape[0])
+    out = torch.empty((P, C), dtype=torch.float32, device=m.device)
+    check(_lib.load().cpn_gather_channels(ptr(m), ptr(indices.contiguous()), P, C, h, w, ptr(out), stream_ptr()),
+          'gather_channels')
+    return out
+
+
 def decode_proposals(indices: Tensor, scores: Tensor, locations: Tensor, fourier: Tensor, refinement, *, size,
-                     order: int, samples: int, iterations: int, offsets=None):
+                     order: int, samples: int, iterations: int, offsets=None, num_buckets: int = 1):
     """Fused proposal decode (celldetection/models/cpn.py:613-702): gather + rel->abs locations + Fourier synthesis +
     rescale + local refinement + clamp + boxes (+ offsets).  Returns a dict of flat [P, ...] tensors + 'b' [P]."""
     _need_cuda(indices, scores, locations, fourier)
@@ -226,9 +291,13 @@ def decode_proposals(indices: Tensor, scores: Tensor, locations: Tensor, fourier
         offs = torch.as_tensor(offsets).to(device=dev, dtype=torch.int64).contiguous()
         assert offs.shape == (N, 2), 'offsets must be Tensor[N, 2] (xy)'
     ref = None if refinement is None else refinement.contiguous().float()
+    bidx, bw = bucket_tables(samples, num_buckets, dev) if (num_buckets > 1 and ref is not None) else (None, None)
+    if ref is not None and ref.shape[1] != 2 * num_buckets:
+        raise ValueError(f'refinement tensor must have {2 * num_buckets} channels, got {ref.shape[1]}')
     check(lib.cpn_decode(ptr(indices), P, ptr(scores.contiguous()), ptr(locations.contiguous()),
                          ptr(fourier.contiguous()), ptr(ref), N, h, w, H, W, order_total, order, samples,
                          int(iterations), ptr(cos_t), ptr(sin_t), ptr(offs), ptr(out['contours']),
                          ptr(out['contour_proposals']), ptr(out['boxes']), ptr(out['scores']), ptr(out['locations']),
-                         ptr(out['fourier']), ptr(out['b']), stream_ptr()), 'decode')
+                         ptr(out['fourier']), ptr(out['b']), int(num_buckets), ptr(bidx), ptr(bw), stream_ptr()),
+          'decode')
     return out

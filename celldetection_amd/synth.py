@@ -101,7 +101,17 @@ def calibrate_heads(state_dict, core_fn, score_shift: float = -2., score_gain: f
 
     m, s = float(scores.mean()), float(scores.std()) + 1e-12
     g = score_gain / s
-    _apply('core.score_head.block.4.', g, lambda b: g * (b - m) + score_shift)
+    if scores.shape[1] == 1:
+        _apply('core.score_head.block.4.', g, lambda b: g * (b - m) + score_shift)
+    else:  # multi-class logits: standardise every class plane, then favour class 0 (background) by |score_shift|
+        mc = scores.mean((0, 2, 3))
+        gc = score_gain / (scores.std((0, 2, 3)) + 1e-12)
+
+        def _bias(b):
+            nb = gc * (b - mc)
+            nb[0] = nb[0] - score_shift
+            return nb
+        _apply('core.score_head.block.4.', gc[:, None, None, None], _bias)
     g = fourier_std / (float(fourier.std()) + 1e-12)
     _apply('core.fourier_head.block.4.', g, lambda b: b * g)
     g = location_std / (float(locations.std()) + 1e-12)

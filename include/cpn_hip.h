@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CPN_ABI_VERSION 3
+#define CPN_ABI_VERSION 4
 
 #define CPN_E_INVALID (-1)
 #define CPN_E_UNSUPPORTED (-2)
@@ -48,7 +48,8 @@ typedef struct {
 
 enum { CPN_OP_INPUT = 0, CPN_OP_CONV = 1, CPN_OP_MAXPOOL = 2, CPN_OP_BILINEAR = 3 };
 enum { CPN_ACT_NONE = 0, CPN_ACT_RELU = 1, CPN_ACT_SIGMOID = 2, CPN_ACT_TANH_SCALED = 3 };
-enum { CPN_OUT_SCORES = 0, CPN_OUT_LOCATIONS = 1, CPN_OUT_FOURIER = 2, CPN_OUT_REFINEMENT = 3 };
+enum { CPN_OUT_SCORES = 0, CPN_OUT_LOCATIONS = 1, CPN_OUT_FOURIER = 2, CPN_OUT_REFINEMENT = 3, CPN_OUT_UNCERTAINTY = 4,
+       CPN_NUM_OUTPUTS = 5 };
 
 typedef struct {
     int32_t op;               /* CPN_OP_*                                                                   */
@@ -95,8 +96,10 @@ int64_t cpn_plan_workspace_bytes(cpn_plan *plan, int32_t N, int32_t H, int32_t W
 double cpn_plan_executed_flops(cpn_plan *plan, int32_t N, int32_t H, int32_t W);
 
 /* Runs the conv graph.  input: fp32 (dtype 0) or uint8 (dtype 1, scaled by 1/255) NCHW [N,C,H,W].
- * outputs[CPN_OUT_*]: fp32 NCHW device buffers: scores [N,1,h,w] (sigmoid applied), locations [N,2,h,w],
- * fourier [N,4*order,h,w], refinement [N,2,H,W] (tanh*margin applied).
+ * outputs[CPN_OUT_*] (CPN_NUM_OUTPUTS pointers; unused ones may be NULL): fp32 NCHW device buffers: scores
+ * [N,1,h,w] with the sigmoid applied (binary) or raw logits [N,classes,h,w] (multi-class, cpn.py:583-585), locations
+ * [N,2,h,w], fourier [N,4*order,h,w], refinement [N,2*buckets,H,W] (tanh*margin applied), uncertainty [N,4,h,w]
+ * (sigmoid applied; only for plans with an uncertainty head, cpn.py:209-221).
  * range_flag: device int32, zeroed by the caller; set to 1 if an input value lies outside [0,1]
  * (the caller raises the reference's AssertionError, models/commons.py:696-697). */
 int cpn_plan_run(cpn_plan *plan, const void *input, int32_t in_dtype, int32_t N, int32_t H, int32_t W,
@@ -142,19 +145,40 @@ int cpn_compact(const float *scores, int32_t N, int32_t h, int32_t w, float thre
  *   order <= order_total (cpn.py:597-598 "changed order"), samples = S, iterations = refinement iterations
  *   cos_table/sin_table [order][samples] fp32 device (built by the host exactly like ops/cpn.py:69-78)
  *   offsets: int64 [N,2] (xy) device or NULL
+ *   buckets = refinement_buckets (cpn.py:72-82): 1 = plain map; > 1: refinement is [N,2*buckets,H,W] and
+ *   bucket_index / bucket_weight are [3][samples] device tables (bucket number and blend weight of the three
+ *   neighbouring buckets of every sample, built by the host like resolve_refinement_buckets, ops/cpn.py:238-255)
  * outputs (device, row-major): contours [P,S,2], proposals [P,S,2], boxes [P,4], out_scores [P], out_locations [P,2],
  *   out_fourier [P,order,4], batch_index [P] int32. */
 int cpn_decode(const int32_t *indices, int32_t P, const float *scores, const float *locations, const float *fourier,
                const float *refinement, int32_t N, int32_t h, int32_t w, int32_t H, int32_t W, int32_t order_total,
                int32_t order, int32_t samples, int32_t iterations, const float *cos_table, const float *sin_table,
                const int64_t *offsets, float *contours, float *proposals, float *boxes, float *out_scores,
-               float *out_locations, float *out_fourier, int32_t *batch_index, void *stream);
+               float *out_locations, float *out_fourier, int32_t *batch_index, int32_t buckets,
+               const int32_t *bucket_index, const float *bucket_weight, void *stream);
 
 /* Standalone pieces of the decode (parity tests, reference ops API celldetection/ops/cpn.py). */
 int cpn_fouriers2contours(const float *fourier, const float *locations, int32_t P, int32_t order, int32_t samples,
                           const float *cos_table, const float *sin_table, float *contours, void *stream);
 int cpn_local_refinement(float *contours /* in/out [P,S,2] */, const int32_t *batch_index, int32_t P, int32_t samples,
-                         const float *refinement, int32_t N, int32_t H, int32_t W, int32_t iterations, void *stream);
+                         const float *refinement, int32_t N, int32_t H, int32_t W, int32_t iterations,
+                         int32_t buckets, const int32_t *bucket_index, const float *bucket_weight, void *stream);
+
+/* Score variants of CPN.forward.
+ * cpn_class_scores (multi-class CPNs, celldetection/models/cpn.py:583-585,631-632): softmax over the C logit planes
+ * [N,C,h,w], optional score bounds lower/upper [N,1,h,w] applied to every class plane (_apply_score_bounds,
+ * cpn.py:118-123), classes = argmax (first maximum), selected = probability of that class, foreground = 1.0 where
+ * classes > 0 else 0.0 (feeds cpn_compact with thresh 0.5).  probs [N,C,h,w] may be NULL.
+ * cpn_certainty_mask (cpn.py:617-618): out = scores where mean_c(uncertainty[N,C,h,w]) < limit, else -1
+ * (limit = 1 - certainty_thresh), so that the thresholding in cpn_compact applies `fg_mask &= ...`.
+ * cpn_gather_channels (cpn.py:634-636): out[p][c] = map[b][c][y][x] for the pixel index indices[p] of cpn_compact. */
+int cpn_class_scores(const float *logits, int32_t N, int32_t C, int32_t h, int32_t w, const float *lower,
+                     const float *upper, float *probs, float *selected, int32_t *classes, float *foreground,
+                     void *stream);
+int cpn_certainty_mask(const float *scores, const float *uncertainty, int32_t N, int32_t C, int32_t h, int32_t w,
+                       float limit, float *out, void *stream);
+int cpn_gather_channels(const float *map, const int32_t *indices, int64_t P, int32_t C, int32_t h, int32_t w,
+                        float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Box NMS.  Replaces torch.ops.torchvision.nms as called from batched_box_nmsi (celldetection/ops/cpn.py:189-227)

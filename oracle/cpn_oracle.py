@@ -154,8 +154,9 @@ def _readout(x, sd, p):
     return _conv(x, sd, p + 'block.4.')
 
 
-def core_forward(state_dict, x, refinement_margin=3.):
-    """CPNCore.forward, models/cpn.py:238-283 -> (raw scores, locations, refinement, fourier), all fp32 NCHW.
+def core_forward(state_dict, x, refinement_margin=3., with_uncertainty=False):
+    """CPNCore.forward, models/cpn.py:238-283 -> (raw scores, locations, refinement, fourier), all fp32 NCHW
+    (+ the sigmoid uncertainty map [N,4,h,w] or None as fifth element when ``with_uncertainty``).
 
     The backbone family is recognised from the state-dict keys (``unet.`` vs ``fpn.``; ``body.0.0.weight`` 7x7 =>
     ResNet stem, otherwise UNetEncoder)."""
@@ -179,11 +180,16 @@ def core_forward(state_dict, x, refinement_margin=3.):
         scores = _readout(f1, sd, 'core.score_head.')
         locations = _readout(f1, sd, 'core.location_head.')
         fourier = _readout(f1, sd, 'core.fourier_head.')
+        uncertainty = None
+        if _has(sd, 'core.uncertainty_head.'):  # cpn.py:209-221,266-271: ReadOut with final sigmoid
+            uncertainty = torch.sigmoid(_readout(f1, sd, 'core.uncertainty_head.'))
         if f0.shape[2:] != x.shape[2:]:  # cpn.py:277-278
             f0 = F.interpolate(f0, x.shape[2:], mode='bilinear', align_corners=False)
         refinement = torch.tanh(_readout(f0, sd, 'core.refinement_head.')) * refinement_margin
         if refinement.shape[2:] != x.shape[2:]:
             refinement = F.interpolate(refinement, x.shape[2:], mode='bilinear', align_corners=False)
+    if with_uncertainty:
+        return scores, locations, refinement, fourier, uncertainty
     return scores, locations, refinement, fourier
 
 
@@ -216,17 +222,42 @@ def fouriers2contours(fourier, locations, samples):
     return con.astype(np.float32)
 
 
-def local_refinement(contours, refinement, b, iterations, size):
-    """models/cpn.py:63-85 (buckets == 1): round-half-even, clamp, gather refinement[b,:,y,x], add."""
+def refinement_buckets_table(samples, num_buckets):
+    """ops/cpn.py:238-255 for the default sampling t = linspace(0, 1, S): three (bucket index [S], weight [S]) pairs
+    for the buckets int(t*nb) - 1, int(t*nb), int(t*nb) + 1 (mod nb); weight = 1 - |j + .5 - t*nb|, 0 beyond 1."""
+    base = torch.linspace(0, 1.0, samples) * num_buckets
+    whole = base.long()
+    out = []
+    for j in (whole - 1, whole, whole + 1):
+        dist = torch.abs(j + 0.5 - base)
+        wgt = 1. - dist
+        wgt[dist > 1] = 0
+        out.append(((j % num_buckets).numpy(), wgt.numpy().astype(np.float32)))
+    return out
+
+
+def local_refinement(contours, refinement, b, iterations, size, num_buckets=1):
+    """models/cpn.py:63-85: round-half-even, clamp, gather refinement[b,:,y,x], add.  Bucketed variant
+    (cpn.py:72-82): the response of sample s is the weighted sum, in the order a, b, c, of the channel pairs of its
+    three neighbouring buckets."""
     h, w = size
     c = np.asarray(contours, np.float32).copy()
     all_c = []
+    table = refinement_buckets_table(c.shape[1], num_buckets) if num_buckets > 1 else None
     for _ in range(iterations):
         c = np.rint(c)
         c[..., 0] = np.clip(c[..., 0], 0, w - 1)
         c[..., 1] = np.clip(c[..., 1], 0, h - 1)
         idx = c.astype(np.int64)
-        resp = refinement[b[:, None], :, idx[:, :, 1], idx[:, :, 0]]  # [P, S, 2]
+        if table is None:
+            resp = refinement[b[:, None], :, idx[:, :, 1], idx[:, :, 0]]  # [P, S, 2]
+        else:
+            resp = None
+            for bi, bw in table:
+                ch = np.stack((bi * 2, bi * 2 + 1), -1)  # [S, 2]
+                cur = refinement[b[:, None, None], ch[None], idx[:, :, 1, None], idx[:, :, 0, None]]  # [P, S, 2]
+                cur = (cur * bw[None, :, None]).astype(np.float32)
+                resp = cur if resp is None else (resp + cur).astype(np.float32)
         c = (c + resp).astype(np.float32)
         all_c.append(c)
     return c, all_c
@@ -320,8 +351,12 @@ def _resize_bilinear(x, size):
 
 def cpn_postprocess(scores_raw, locations, refinement, fourier, *, input_size, order=None, samples=32,
                     score_thresh=.9, nms_thresh=.2, refinement_iterations=4, nms=True, offsets=None,
-                    scores_lower_bound=None, scores_upper_bound=None, scores_are_probabilities=False):
-    """CPN.forward after the core, models/cpn.py:575-734 (binary classes path, eval mode).
+                    scores_lower_bound=None, scores_upper_bound=None, scores_are_probabilities=False,
+                    refinement_buckets=1, uncertainty=None, certainty_thresh=None, uncertainty_nms=False):
+    """CPN.forward after the core, models/cpn.py:575-734 (eval mode): binary (one score plane, sigmoid) and
+    multi-class (``classes`` planes, softmax/argmax, cpn.py:583-585) scores, bucketed refinement (cpn.py:72-82),
+    uncertainty head (certainty filter cpn.py:617-618, ``box_uncertainties`` cpn.py:634-636, ``uncertainty_nms``
+    cpn.py:723-726).
 
     Args are fp32 NCHW numpy arrays (or tensors).  Returns an OrderedDict of per-image lists like the reference.
     """
@@ -330,8 +365,11 @@ def cpn_postprocess(scores_raw, locations, refinement, fourier, *, input_size, o
     refinement = None if refinement is None else to_np(refinement)
     H, W = input_size
     n, c, h, w = fourier.shape
+    multi = scores_raw.shape[1] > 2
     if scores_are_probabilities:
         scores = scores_raw.astype(np.float32)
+    elif multi:
+        scores = F.softmax(torch.as_tensor(scores_raw), dim=1).numpy()  # cpn.py:584
     else:
         scores = torch.sigmoid(torch.as_tensor(scores_raw)).numpy()  # cpn.py:578
     if scores_upper_bound is not None:  # cpn.py:118-123
@@ -344,7 +382,10 @@ def cpn_postprocess(scores_raw, locations, refinement, fourier, *, input_size, o
         if lb.shape[2:] != scores.shape[2:]:
             lb = _resize_bilinear(lb, scores.shape[2:])
         scores = np.maximum(scores, lb)
-    classes = (scores > np.float32(score_thresh)).astype(np.int64)[:, 0]  # cpn.py:579
+    if multi:
+        classes = torch.argmax(torch.as_tensor(scores), dim=1).numpy().astype(np.int64)  # cpn.py:585
+    else:
+        classes = (scores > np.float32(score_thresh)).astype(np.int64)[:, 0]  # cpn.py:579
     fourier = fourier.reshape(n, c // 4, 4, h, w)  # cpn.py:594
     if order is not None and order < c // 4:
         fourier = fourier[:, :order]  # cpn.py:597-598
@@ -352,11 +393,16 @@ def cpn_postprocess(scores_raw, locations, refinement, fourier, *, input_size, o
     gx = np.arange(w, dtype=np.float32)[None] + np.zeros((h, 1), np.float32)
     gy = np.zeros((1, w), np.float32) + np.arange(h, dtype=np.float32)[:, None]
     locations = locations + np.stack((gx, gy), 0)
-    b, y, x = np.where(classes > 0)  # row-major (b, y, x) order, cpn.py:620
+    fg = classes > 0
+    unc = None if uncertainty is None else to_np(uncertainty).astype(np.float32)
+    if certainty_thresh is not None and unc is not None:  # cpn.py:617-618
+        fg = fg & (torch.as_tensor(unc).mean(1).numpy() < (1 - certainty_thresh))
+    b, y, x = np.where(fg)  # row-major (b, y, x) order, cpn.py:620
     sel_fourier = fourier[b, :, :, y, x].astype(np.float32)  # [P, O, 4]
     sel_loc = locations[b, :, y, x].astype(np.float32)  # [P, 2]
     sel_classes = classes[b, y, x]
-    sel_scores = scores[b, 0, y, x]
+    sel_scores = scores[b, sel_classes, y, x] if multi else scores[b, 0, y, x]  # cpn.py:629-632
+    sel_unc = None if unc is None else unc[b, :, y, x]  # cpn.py:634-636
     proposals = fouriers2contours(sel_fourier, sel_loc, samples)
     scale = np.array([W / w, H / h], np.float32)  # get_scale flip -> (x, y), ops/cpn.py:98-103
     proposals = proposals * scale
@@ -365,7 +411,8 @@ def cpn_postprocess(scores_raw, locations, refinement, fourier, *, input_size, o
     sel_fourier[..., [2, 3]] = sel_fourier[..., [2, 3]] * scale[1]
     sel_loc = sel_loc * scale
     if refinement is not None and refinement_iterations > 0:
-        contours, _ = local_refinement(proposals, refinement, b, refinement_iterations, (H, W))
+        contours, _ = local_refinement(proposals, refinement, b, refinement_iterations, (H, W),
+                                       num_buckets=refinement_buckets)
     else:
         contours = proposals.copy()
     contours[..., 0] = np.clip(contours[..., 0], 0, W - 1)  # cpn.py:661-663 (also clamps the proposals when
@@ -388,18 +435,26 @@ def cpn_postprocess(scores_raw, locations, refinement, fourier, *, input_size, o
     flat = OrderedDict(contours=contours.astype(np.float32), boxes=boxes.astype(np.float32), scores=sel_scores,
                        classes=sel_classes, locations=sel_loc.astype(np.float32), fourier=sel_fourier,
                        contour_proposals=proposals.astype(np.float32))
+    if sel_unc is not None:
+        flat['box_uncertainties'] = sel_unc
     out = OrderedDict((k, [v[b == i] for i in range(n)]) for k, v in flat.items())  # cpn.py:42-50
     if nms:
-        keeps = batched_box_nmsi(out['boxes'], out['scores'], nms_thresh)
+        weights = out['scores']
+        if uncertainty_nms and sel_unc is not None:  # cpn.py:723-726
+            weights = [(torch.as_tensor(s_) * (1. - torch.as_tensor(u_).mean(1))).numpy()
+                       for s_, u_ in zip(out['scores'], out['box_uncertainties'])]
+        keeps = batched_box_nmsi(out['boxes'], weights, nms_thresh)
         out = OrderedDict((k, [v[i][keeps[i]] for i in range(n)]) for k, v in out.items())  # cpn.py:53-60
-    out['box_uncertainties'] = None
+    if sel_unc is None:
+        out['box_uncertainties'] = None
     return out
 
 
 def cpn_forward(state_dict, x, **kw):
     """Full eval-mode CPN.forward (core + post-processing) on CPU."""
-    s, l, r, f = core_forward(state_dict, x, refinement_margin=kw.pop('refinement_margin', 3.))
-    return cpn_postprocess(s, l, r, f, input_size=tuple(x.shape[-2:]), **kw)
+    s, l, r, f, u = core_forward(state_dict, x, refinement_margin=kw.pop('refinement_margin', 3.),
+                                 with_uncertainty=True)
+    return cpn_postprocess(s, l, r, f, input_size=tuple(x.shape[-2:]), uncertainty=u, **kw)
 
 
 # =====================================================================================================

@@ -53,6 +53,20 @@ MODEL_SPECS = {
     'CpnU22_wide': ('CpnU22', dict(in_channels=3, order=7, samples=48, score_thresh=.8, nms_thresh=.3,
                                    backbone_kwargs={'backbone_kwargs': {'base_channels': 32}}),
                     (1, 3, 96, 128)),
+    # CPN.forward variants: bucketed refinement, uncertainty head (+ certainty filter and
+    # uncertainty-weighted NMS), multi-class scores, narrower head channels / other head kernel sizes
+    'CpnU22_buckets': ('CpnU22', dict(in_channels=3, refinement_buckets=6,
+                                      backbone_kwargs={'backbone_kwargs': {'base_channels': 8}}), (2, 3, 64, 96)),
+    'CpnU22_uncertainty': ('CpnU22', dict(in_channels=3, uncertainty_head=True, uncertainty_nms=True,
+                                          certainty_thresh=.65,
+                                          backbone_kwargs={'backbone_kwargs': {'base_channels': 8}}), (2, 3, 64, 96)),
+    'CpnU22_classes4': ('CpnU22', dict(in_channels=3, classes=4,
+                                       backbone_kwargs={'backbone_kwargs': {'base_channels': 8}}), (2, 3, 64, 96)),
+    'CpnResNet18FPN_heads': ('CpnResNet18FPN', dict(in_channels=3, contour_head_channels=24,
+                                                    refinement_head_channels=8, kernel_size_score=3,
+                                                    kernel_size_refinement=5, refinement_buckets=3, backbone_kwargs={
+                                                        'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}),
+                             (1, 3, 64, 64)),
 }
 
 
@@ -175,8 +189,11 @@ def flat_outputs(prefix, y, out):
             out[f'{prefix}.{k}.{i}'] = npy(t)
 
 
+MODEL_CALIBRATION = {'CpnU22_classes4': dict(score_shift=-3.5)}  # per-spec calibrate_heads arguments
+
+
 def gen_model(name, seed=0):
-    model, overrides, shape = build_ref_model(name, seed)
+    model, overrides, shape = build_ref_model(name, seed, **MODEL_CALIBRATION.get(name, {}))
     out = {f'override.{k}': npy(v) for k, v in overrides.items()}
     out['seed'] = np.array(seed)
     tmpl = model.state_dict()
@@ -185,9 +202,11 @@ def gen_model(name, seed=0):
     x = torch.rand(*shape, generator=torch.Generator().manual_seed(7))
     out['x'] = npy(x)
     with torch.no_grad():
-        s, l, r, f, _ = model.core(x)
+        s, l, r, f, u = model.core(x)
         out['core.scores'], out['core.locations'], out['core.refinement'], out['core.fourier'] = \
             npy(s), npy(l), npy(r), npy(f)
+        if u is not None:
+            out['core.uncertainty'] = npy(u)
         flat_outputs('nms', model(x), out)
         flat_outputs('nonms', model(x, nms=False), out)
         offsets = torch.tensor([[100, 200], [-5, 7]][:shape[0]])
@@ -204,8 +223,8 @@ def gen_model(name, seed=0):
             model.order = 3
             flat_outputs('attr_order3', model(x), out)
     n_det = [len(t) for t in model(x)['scores']] if name != 'CpnU22' else None
-    print(name, 'detections/img (last config):', n_det, 'proposals:',
-          [int((torch.sigmoid(s[i]) > model.score_thresh).sum()) for i in range(shape[0])])
+    print(name, 'detections/img (last config):', n_det, 'proposals/img (nonms):',
+          [len(out[f'nonms.scores.{i}']) for i in range(shape[0])])
     save(f'model_{name}.npz', **out)
 
 
@@ -251,6 +270,9 @@ if __name__ == '__main__':
         gen_tiling()
     if 'models' in which:
         for name_ in MODEL_SPECS:
+            gen_model(name_)
+    for name_ in which:  # single models by name
+        if name_ in MODEL_SPECS:
             gen_model(name_)
     if 'stitch' in which:
         gen_stitch()

@@ -27,6 +27,25 @@ MODEL_SPECS = {
                         cpn_kwargs=dict(samples=48, score_thresh=.8, nms_thresh=.3, refinement_iterations=4)),
 }
 
+_U8 = {'backbone_kwargs': {'base_channels': 8}}
+# CPN.forward variants (fixtures model_<name>.npz): ``kwargs`` = constructor arguments (as in make_golden.py),
+# ``cpn_kwargs`` = the matching arguments of the oracle's post-processing
+VARIANT_SPECS = {
+    'CpnU22_buckets': dict(cls='CpnU22', kwargs=dict(in_channels=3, refinement_buckets=6, backbone_kwargs=_U8),
+                           cpn_kwargs=dict(_DEF, refinement_buckets=6)),
+    'CpnU22_uncertainty': dict(cls='CpnU22', kwargs=dict(in_channels=3, uncertainty_head=True, uncertainty_nms=True,
+                                                         certainty_thresh=.65, backbone_kwargs=_U8),
+                               cpn_kwargs=dict(_DEF, certainty_thresh=.65, uncertainty_nms=True)),
+    'CpnU22_classes4': dict(cls='CpnU22', kwargs=dict(in_channels=3, classes=4, backbone_kwargs=_U8),
+                            cpn_kwargs=dict(_DEF)),
+    'CpnResNet18FPN_heads': dict(cls='CpnResNet18FPN', kwargs=dict(
+        in_channels=3, contour_head_channels=24, refinement_head_channels=8, kernel_size_score=3,
+        kernel_size_refinement=5, refinement_buckets=3,
+        backbone_kwargs={'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}),
+        cpn_kwargs=dict(_DEF, refinement_buckets=3)),
+}
+ALL_SPECS = dict(MODEL_SPECS, **VARIANT_SPECS)
+
 
 def ref_template_state_dict(name, fixture=None):
     """Reference state-dict key names + shapes, as recorded in the golden fixture (no reference import needed)."""

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from model_specs import MODEL_SPECS
+from model_specs import ALL_SPECS, MODEL_SPECS, VARIANT_SPECS
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
@@ -28,7 +28,7 @@ def dev():
 def build(name, dev, fixture=None):
     import celldetection_amd as cda
     from celldetection_amd.synth import synth_state_dict
-    spec = MODEL_SPECS[name]
+    spec = ALL_SPECS[name]
     g = np.load(os.path.join(G, fixture or f'model_{name}.npz'))
     model = getattr(cda.models, spec['cls'])(**spec['kwargs'])
     assert list(model.state_dict().keys()) == [str(k) for k in g['sd_keys']]
@@ -41,14 +41,17 @@ def build(name, dev, fixture=None):
 def check_exact(prefix, y, g, n, raw_atol=1e-4):
     """Index sets equal (shapes/classes), final contours / boxes / scores within 1e-4 (north-star tolerance);
     ``raw_atol`` applies to the un-snapped regression outputs (locations, fourier, contour_proposals)."""
-    for k in KEYS:
+    keys = KEYS + (('box_uncertainties',) if f'{prefix}.box_uncertainties.0' in g.files else ())
+    if len(keys) == len(KEYS):
+        assert y['box_uncertainties'] is None
+    for k in keys:
         for i in range(n):
             exp, got = g[f'{prefix}.{k}.{i}'], y[k][i].cpu().numpy()
             assert got.shape == exp.shape, (prefix, k, i, got.shape, exp.shape)
             if k == 'classes':
                 np.testing.assert_array_equal(got, exp)
             else:
-                atol = 1e-4 if k in ('contours', 'boxes', 'scores') else raw_atol
+                atol = 1e-4 if k in ('contours', 'boxes', 'scores', 'box_uncertainties') else raw_atol
                 np.testing.assert_allclose(got, exp, rtol=0, atol=atol, err_msg=f'{prefix}.{k}.{i}')
 
 
@@ -248,3 +251,57 @@ def test_forward_tiled_and_mask(dev):
     full = inference.tiled_inference(model, img, (96, 96), (64, 64))
     assert 0 < out['scores'].numel() <= full['scores'].numel()
     assert float(out['locations'][:, 0].max()) < 112 + 8
+
+
+# ---- CPN.forward variants: bucketed refinement, uncertainty head, multi-class scores, head options --------------------
+def _variant_maps(g, dev, multi):
+    sc = torch.as_tensor(g['core.scores'])
+    maps = [(sc if multi else torch.sigmoid(sc)).to(dev), torch.as_tensor(g['core.locations']).to(dev),
+            torch.as_tensor(g['core.refinement']).to(dev), torch.as_tensor(g['core.fourier']).to(dev)]
+    unc = torch.as_tensor(g['core.uncertainty']).to(dev) if 'core.uncertainty' in g.files else None
+    return maps, unc
+
+
+@pytest.mark.parametrize('name', list(VARIANT_SPECS))
+def test_variant_postprocess_on_reference_head_maps(dev, name):
+    """Variant post-processing (class softmax/argmax, certainty filter, uncertainty-weighted NMS, bucketed
+    refinement) on the reference's head maps: index sets equal, values within 1e-4."""
+    model, g = build(name, dev)
+    x = g['x']
+    n, size = x.shape[0], tuple(x.shape[-2:])
+    maps, unc = _variant_maps(g, dev, multi=model.score_channels > 1)
+    check_exact('nms', model.postprocess(*maps, size, uncertainty=unc), g, n)
+    check_exact('nonms', model.postprocess(*maps, size, nms=False, uncertainty=unc), g, n)
+    check_exact('offs', model.postprocess(*maps, size, offsets=torch.as_tensor(g['offsets']), uncertainty=unc), g, n)
+    y = model.postprocess(*maps, size, uncertainty=unc,
+                          scores_upper_bound=torch.as_tensor(g['scores_upper_bound']).to(dev),
+                          scores_lower_bound=torch.as_tensor(g['scores_lower_bound']).to(dev))
+    for i in range(n):
+        assert abs(len(y['scores'][i]) - len(g[f'bounds.scores.{i}'])) <= max(1, 0.02 * len(g[f'bounds.scores.{i}']))
+
+
+@pytest.mark.parametrize('name', list(VARIANT_SPECS))
+def test_variant_fp32_end_to_end_and_bf16_stack(dev, name):
+    model, g = build(name, dev)
+    x = torch.as_tensor(g['x']).to(dev)
+    multi = model.score_channels > 1
+    exp = dict(scores=torch.as_tensor(g['core.scores']) if multi else torch.sigmoid(torch.as_tensor(g['core.scores'])),
+               locations=torch.as_tensor(g['core.locations']), refinement=torch.as_tensor(g['core.refinement']),
+               fourier=torch.as_tensor(g['core.fourier']))
+    if 'core.uncertainty' in g.files:
+        exp['uncertainty'] = torch.as_tensor(g['core.uncertainty'])
+    for precision, tol in (('bf16', 6e-2), ('fp32', 2e-4)):
+        model.precision = precision
+        s, l, r, f = [t.cpu() for t in model.core_forward(x)]
+        got = dict(scores=s, locations=l, refinement=r, fourier=f)
+        if 'uncertainty' in exp:
+            got['uncertainty'] = model._last_uncertainty.cpu()
+        for key, e in exp.items():
+            assert got[key].shape == e.shape, (key, got[key].shape, e.shape)
+            rel = ((got[key] - e).norm() / (e.norm() + 1e-12)).item()
+            print(name, precision, key, f'relL2 {rel:.3e}')
+            assert rel < tol, (name, precision, key, rel)
+    n = x.shape[0]  # fp32 path end to end
+    check_exact('nms', model(x), g, n, raw_atol=5e-4)
+    check_exact('nonms', model(x, nms=False), g, n, raw_atol=5e-4)
+    check_exact('offs', model(x, offsets=torch.as_tensor(g['offsets'])), g, n, raw_atol=5e-4)

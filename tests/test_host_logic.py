@@ -10,15 +10,15 @@ import torch.nn.functional as F
 
 import celldetection_amd as cda
 from celldetection_amd import _lib, graph
-from model_specs import MODEL_SPECS, ref_template_state_dict
+from model_specs import ALL_SPECS, MODEL_SPECS, ref_template_state_dict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, 'tests', 'golden')
 
 
-@pytest.mark.parametrize('name', list(MODEL_SPECS))
+@pytest.mark.parametrize('name', list(ALL_SPECS))
 def test_state_dict_keys_match_reference(name):
-    spec = MODEL_SPECS[name]
+    spec = ALL_SPECS[name]
     model = getattr(cda.models, spec['cls'])(**spec['kwargs'])
     ref = ref_template_state_dict(name)
     mine = model.state_dict()

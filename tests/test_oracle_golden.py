@@ -8,7 +8,7 @@ import torch
 
 import cpn_oracle as orc
 from celldetection_amd.synth import synth_state_dict
-from model_specs import MODEL_SPECS, ref_template_state_dict
+from model_specs import MODEL_SPECS, VARIANT_SPECS, ref_template_state_dict
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
@@ -74,7 +74,12 @@ def _load_model_fixture(name):
 
 
 def _check_outputs(prefix, y, g, n):
-    for k in ('contours', 'boxes', 'scores', 'classes', 'locations', 'fourier', 'contour_proposals'):
+    keys = ('contours', 'boxes', 'scores', 'classes', 'locations', 'fourier', 'contour_proposals')
+    if f'{prefix}.box_uncertainties.0' in g.files:
+        keys += ('box_uncertainties',)
+    else:
+        assert y['box_uncertainties'] is None
+    for k in keys:
         for i in range(n):
             exp = g[f'{prefix}.{k}.{i}']
             got = y[k][i]
@@ -111,6 +116,32 @@ def test_model_core_and_forward(name):
         kw2 = dict(kw, samples=17, refinement_iterations=2, score_thresh=.7, nms_thresh=.5)
         _check_outputs('attr', orc.cpn_postprocess(*maps, input_size=size, **kw2), g, n)
         _check_outputs('attr_order3', orc.cpn_postprocess(*maps, input_size=size, order=3, **kw2), g, n)
+
+
+@pytest.mark.parametrize('name', list(VARIANT_SPECS))
+def test_variant_core_and_forward(name):
+    """CPN.forward variants: bucketed refinement, uncertainty head (+ certainty filter, uncertainty-weighted NMS),
+    multi-class softmax scores, narrower head channels / other head kernel sizes."""
+    g, sd = _load_model_fixture(name)
+    kw = VARIANT_SPECS[name]['cpn_kwargs']
+    x = torch.as_tensor(g['x'])
+    torch.set_num_threads(4)
+    s, l, r, f, u = orc.core_forward(sd, x, with_uncertainty=True)
+    for got, key in ((s, 'scores'), (l, 'locations'), (r, 'refinement'), (f, 'fourier'), (u, 'uncertainty')):
+        if got is None:
+            assert f'core.{key}' not in g.files
+            continue
+        np.testing.assert_allclose(got.numpy(), g[f'core.{key}'], rtol=1e-4, atol=1e-3)
+    n, size = x.shape[0], tuple(x.shape[-2:])
+    maps = (g['core.scores'], g['core.locations'], g['core.refinement'], g['core.fourier'])
+    unc = g['core.uncertainty'] if 'core.uncertainty' in g.files else None
+    _check_outputs('nms', orc.cpn_postprocess(*maps, input_size=size, uncertainty=unc, **kw), g, n)
+    _check_outputs('nonms', orc.cpn_postprocess(*maps, input_size=size, nms=False, uncertainty=unc, **kw), g, n)
+    _check_outputs('offs', orc.cpn_postprocess(*maps, input_size=size, offsets=g['offsets'], uncertainty=unc, **kw),
+                   g, n)
+    _check_outputs('bounds', orc.cpn_postprocess(*maps, input_size=size, uncertainty=unc,
+                                                 scores_upper_bound=g['scores_upper_bound'],
+                                                 scores_lower_bound=g['scores_lower_bound'], **kw), g, n)
 
 
 def test_stitch():

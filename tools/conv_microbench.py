@@ -25,6 +25,9 @@ CASES = {
 }
 
 
+ZERO = bool(int(os.environ.get('CPN_MB_ZERO', '0')))  # all-zero operands: DVFS ceiling probe (power vs issue bound)
+
+
 def run(name, reps=20):
     cfg = dict(CASES[name])
     dev = torch.device('cuda:0')
@@ -35,10 +38,16 @@ def run(name, reps=20):
     s1 = P.tensor(cin1, 2) if cin1 else None
     P.conv(s0, cout, k, w='c.', bn=None, bias=True, act='relu', groups=groups, src1=s1, up1=bool(cin1))
     sd = {'c.weight': torch.randn(cout, (cin + cin1) // groups, k, k) * .05, 'c.bias': torch.randn(cout) * .1}
+    if ZERO:
+        sd = {k_: torch.zeros_like(v_) for k_, v_ in sd.items()}
     tens, ops, wblob, bblob = graph.pack(P, sd, dev)
     p32 = lambda c: (c + 31) // 32 * 32
     x0 = torch.randn(n, h, w, p32(cin), device=dev).to(torch.bfloat16)
     x1 = torch.randn(n, h // 2, w // 2, p32(cin1), device=dev).to(torch.bfloat16) if cin1 else None
+    if ZERO:
+        x0.zero_()
+        if x1 is not None:
+            x1.zero_()
     dst = torch.empty(n, h, w, p32(cout), dtype=torch.bfloat16, device=dev)
     lib = _lib.load()
 
