@@ -77,6 +77,7 @@ _SIGNATURES = [
     ('cpn_nms_workspace_bytes', c_int64, [c_int64, c_int64, c_int32]),
     ('cpn_nms', ctypes.c_int, [c_void_p, c_void_p, c_int64, POINTER(c_int64), c_void_p, c_int32, c_float, c_void_p,
                                c_void_p, c_void_p, c_int64, c_void_p]),
+    ('cpn_box_votes', ctypes.c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p]),
     ('cpn_border_keep', ctypes.c_int, [c_void_p, c_int64, c_int32, c_float, c_float, c_float, c_float, c_float,
                                        c_int32, c_void_p, c_void_p]),
 ]

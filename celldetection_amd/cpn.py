@@ -336,6 +336,32 @@ class CPN(nn.Module):
         return outputs
 
 
+class Inference:
+    """``cd.models.Inference`` (celldetection/models/inference.py:8-26): array in -> numpy dict out.  ``amp`` is accepted
+    for signature compatibility; the HIP engine's precision is a model attribute (``model.precision``)."""
+
+    def __init__(self, model, device=None, amp=False, transforms=None):
+        self.transforms = transforms
+        self.device = device or 'cuda'
+        self.model = model.to(self.device)
+        self.model.eval()
+        self.model.requires_grad_(False)
+        self.use_amp = amp
+
+    def __call__(self, inputs):
+        if self.transforms is not None:
+            inputs = self.transforms(inputs)
+        inputs = torch.as_tensor(inputs, device=self.device, dtype=torch.float32)
+        while inputs.ndim < 4:
+            inputs = inputs[None]
+        out = self.model(inputs)
+        to_np = lambda v: v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v
+        return OrderedDict((k, None if v is None else [to_np(t) for t in v]) for k, v in out.items())
+
+
+__all__.append('Inference')
+
+
 def _make(backbone):
     def __init__(self, in_channels: int, order: int = 5, nms_thresh: float = .2, score_thresh: float = .9,
                  samples: int = 32, classes: int = 2, refinement: bool = True, refinement_iterations: int = 4,

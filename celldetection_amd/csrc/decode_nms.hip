@@ -343,6 +343,30 @@ __global__ __launch_bounds__(256) void gather_channels_kernel(const float *__res
     out[i] = map[(size_t) b * C * hw + (size_t) c * hw + (lin - b * hw)];
 }
 
+// votes[i] = sum_j iou(i, j) * (iou(i, j) > thresh)  (get_iou_voting, celldetection/ops/boxes.py:52-58; IoU as
+// torchvision.ops.box_iou: inter / (area_i + area_j - inter), NaN propagates like `iou *= iou > thresh`)
+__global__ __launch_bounds__(256) void box_votes_kernel(const float *__restrict__ boxes, long P, float thresh,
+                                                       float *__restrict__ votes) {
+    const int lane = threadIdx.x & 63;
+    const long i = blockIdx.x * 4l + (threadIdx.x >> 6);
+    if (i >= P) return;
+    const float4 a = *(const float4 *) (boxes + i * 4);
+    const float area_a = __fmul_rn(__fsub_rn(a.z, a.x), __fsub_rn(a.w, a.y));
+    float acc = 0.f;
+    for (long j = lane; j < P; j += 64) {
+        const float4 b = *(const float4 *) (boxes + j * 4);
+        const float area_b = __fmul_rn(__fsub_rn(b.z, b.x), __fsub_rn(b.w, b.y));
+        const float w = fmaxf(__fsub_rn(fminf(a.z, b.z), fmaxf(a.x, b.x)), 0.f);
+        const float h = fmaxf(__fsub_rn(fminf(a.w, b.w), fmaxf(a.y, b.y)), 0.f);
+        const float inter = __fmul_rn(w, h);
+        const float iou = __fdiv_rn(inter, __fsub_rn(__fadd_rn(area_a, area_b), inter));
+        acc = __fadd_rn(acc, __fmul_rn(iou, iou > thresh ? 1.f : 0.f));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc = __fadd_rn(acc, __shfl_xor(acc, d, 64));
+    if (lane == 0) votes[i] = acc;
+}
+
 // =========================================================================================================
 // 3. NMS
 // =========================================================================================================
@@ -582,6 +606,14 @@ int cpn_certainty_mask(const float *scores, const float *uncertainty, int32_t N,
     hipLaunchKernelGGL(certainty_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, (hipStream_t) stream,
                        scores, uncertainty, N, C, h * w, limit, out);
     return cpn::check_hip(hipGetLastError(), "cpn_certainty_mask");
+}
+
+int cpn_box_votes(const float *boxes, int64_t P, float thresh, float *votes, void *stream) {
+    if (P < 0) return cpn::fail(CPN_E_INVALID, "cpn_box_votes: bad arguments");
+    if (P == 0) return 0;
+    hipLaunchKernelGGL(box_votes_kernel, dim3((unsigned) ((P + 3) / 4)), dim3(256), 0, (hipStream_t) stream, boxes,
+                       (long) P, thresh, votes);
+    return cpn::check_hip(hipGetLastError(), "cpn_box_votes");
 }
 
 int cpn_gather_channels(const float *map, const int32_t *indices, int64_t P, int32_t C, int32_t h, int32_t w,

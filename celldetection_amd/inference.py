@@ -23,7 +23,7 @@ import torch
 from .util import get_tiling_slices
 
 __all__ = ['shard_tiles', 'pack_detections', 'unpack_detections', 'gather_detections', 'tiled_inference',
-           'forward_tiled', 'KEYS']
+           'ensemble_inference', 'forward_tiled', 'KEYS']
 
 KEYS = ('contours', 'boxes', 'scores', 'classes', 'locations', 'fourier', 'contour_proposals')
 
@@ -164,6 +164,29 @@ def tiled_inference(model, img: torch.Tensor, crop_size=(1024, 1024), strides=(7
     res = unpack_detections(buf, samples, order)
     if 'nms' in rules and res['scores'].shape[0]:
         keep = nms_fn(res['boxes'], res['scores'], nms_thresh)
+        res = OrderedDict((k, v[keep]) for k, v in res.items())
+    return res
+
+
+@torch.no_grad()
+def ensemble_inference(models, img: torch.Tensor, min_vote: float = 1, nms_thresh: Optional[float] = None, **kwargs):
+    """Multi-model slide inference (celldetection_scripts/cpn_inference.py:311-427 with several ``models``): every
+    model runs the tiled loop (incl. its own stitching NMS), the results are concatenated in model order, filtered by
+    box voting when ``min_vote > 1`` (``filter_by_box_voting``, adds the ``votes`` key) and de-duplicated by one final
+    NMS with ``nms_thresh`` (default: the last model's, like the reference)."""
+    from . import ops
+    models = list(models) if isinstance(models, (list, tuple)) else [models]
+    parts = [tiled_inference(m, img, nms_thresh=nms_thresh, **kwargs) for m in models]
+    if len(parts) == 1:
+        return parts[0]
+    res = OrderedDict((k, torch.cat([p[k] for p in parts])) for k in KEYS)
+    thr = models[-1].nms_thresh if nms_thresh is None else nms_thresh
+    if res['scores'].shape[0]:
+        if min_vote > 1:
+            keep, votes = ops.filter_by_box_voting(res['boxes'], thr, min_vote, return_votes=True)
+            res = OrderedDict((k, v[keep.long()]) for k, v in res.items())
+            res['votes'] = votes
+        keep = ops.nms(res['boxes'], res['scores'], thr)
         res = OrderedDict((k, v[keep]) for k, v in res.items())
     return res
 

@@ -16,7 +16,8 @@ from ._lib import check, ptr, stream_ptr
 
 __all__ = ['fouriers2contours', 'local_refinement', 'nms', 'batched_box_nmsi', 'remove_border_contours',
            'filter_contours_by_stitching_rule', 'compact_scores', 'decode_proposals', 'sampling_tables',
-           'bucket_tables', 'class_scores', 'certainty_mask', 'gather_channels', 'NMS_BATCH_SIZE']
+           'bucket_tables', 'class_scores', 'certainty_mask', 'gather_channels', 'filter_by_box_voting',
+           'NMS_BATCH_SIZE']
 
 NMS_BATCH_SIZE = 50000  # celldetection/ops/cpn.py:12
 
@@ -202,6 +203,21 @@ def filter_contours_by_stitching_rule(contours: Tensor, tile_size, overlaps, rul
         raise ValueError(f'Unknown stitching rule: {rule}')
     if indices:
         keep, = torch.where(keep)
+    return keep
+
+
+def filter_by_box_voting(boxes: Tensor, thresh: float, min_vote: float, return_votes: bool = False):
+    """celldetection/ops/boxes.py:61-83: a box receives as vote the IoU of every box (itself included) it overlaps with
+    IoU > ``thresh``; boxes with ``votes >= min_vote`` are kept.  Returns keep indices (int32) [, their votes]."""
+    _need_cuda(boxes)
+    bx = boxes.contiguous().float()
+    P = int(bx.shape[0])
+    votes = torch.empty((P,), dtype=torch.float32, device=bx.device)
+    check(_lib.load().cpn_box_votes(ptr(bx), P, float(thresh), ptr(votes), stream_ptr()), 'box_votes')
+    mask = votes >= min_vote
+    keep = torch.arange(P, device=bx.device, dtype=torch.int)[mask]
+    if return_votes:
+        return keep, votes[mask]
     return keep
 
 

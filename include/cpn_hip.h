@@ -195,6 +195,11 @@ int cpn_nms(const float *boxes, const float *scores, int64_t P, const int64_t *s
             const int64_t *seg_offsets_dev, int32_t nseg, float thresh, int64_t *keep, int32_t *keep_counts,
             void *workspace, int64_t workspace_bytes, void *stream);
 
+/* Box voting of the multi-model ensemble path (get_iou_voting / filter_by_box_voting, celldetection/ops/boxes.py:52-83,
+ * called from celldetection_scripts/cpn_inference.py:419-423): votes[i] = sum_j iou(i,j) * (iou(i,j) > thresh), IoU
+ * as torchvision.ops.box_iou; every box votes for itself (smallest vote 1).  boxes [P,4] fp32 (16-byte aligned). */
+int cpn_box_votes(const float *boxes, int64_t P, float thresh, float *votes, void *stream);
+
 /* remove_border_contours (celldetection/ops/cpn.py:258-290): keep[i] = 1 iff all points of contour i (+offset)
  * satisfy y>pad (top), x<w-pad (right), y<h-pad (bottom), x>pad (left) on the enabled sides.
  * sides: bit0 top, bit1 right, bit2 bottom, bit3 left. */

@@ -345,6 +345,22 @@ def batched_box_nmsi(boxes, scores, thr, batch_size=50000):
     return keeps
 
 
+def filter_by_box_voting(boxes, thresh, min_vote):
+    """ops/boxes.py:52-83 (IoU = torchvision.ops.box_iou restated: inter / (area_i + area_j - inter)):
+    votes = (iou * (iou > thresh)).sum(-1); keep = where(votes >= min_vote).  Returns (keep, votes[keep])."""
+    b = np.asarray(boxes, np.float32)
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    lt = np.maximum(b[:, None, :2], b[None, :, :2])
+    rb = np.minimum(b[:, None, 2:], b[None, :, 2:])
+    wh = np.clip(rb - lt, 0, None)
+    inter = wh[..., 0] * wh[..., 1]
+    with np.errstate(invalid='ignore', divide='ignore'):
+        iou = inter / (area[:, None] + area[None] - inter)
+        votes = (iou * (iou > np.float32(thresh)).astype(np.float32)).sum(-1, dtype=np.float32)
+    keep = np.nonzero(votes >= min_vote)[0]
+    return keep, votes[keep]
+
+
 def _resize_bilinear(x, size):
     return F.interpolate(torch.as_tensor(x), size, mode='bilinear', align_corners=False).numpy()
 

@@ -315,3 +315,31 @@ def test_compact_and_decode_vs_oracle(dev, shape, density):
                               score_thresh=thr, refinement_iterations=0, nms=False, scores_are_probabilities=True)
     for k in ('contours', 'boxes', 'contour_proposals'):
         np.testing.assert_array_equal(flat[k].cpu().numpy(), np.concatenate(exp[k]), err_msg='norefine ' + k)
+
+
+def test_box_voting_vs_oracle(dev):
+    """filter_by_box_voting (ops/boxes.py:52-83) vs the numpy restatement: votes to 1e-5 relative, same keep set
+    (boxes whose vote is within 1e-4 of the threshold are excluded from the set comparison)."""
+    import cpn_oracle as orc
+    from celldetection_amd import ops
+    g = torch.Generator().manual_seed(5)
+    xy = torch.rand(900, 2, generator=g) * 120
+    wh = torch.rand(900, 2, generator=g) * 30 + 1
+    boxes = torch.cat((xy, xy + wh), 1)
+    boxes[7] = boxes[6]
+    for thr, min_vote in ((.2, 2.), (.5, 1.5), (.1, 1.)):
+        keep, votes = ops.filter_by_box_voting(boxes.to(dev), thr, min_vote, return_votes=True)
+        ekeep, evotes = orc.filter_by_box_voting(boxes.numpy(), thr, min_vote)
+        all_votes = orc.filter_by_box_voting(boxes.numpy(), thr, -1.)[1]
+        sure = np.abs(all_votes - min_vote) > 1e-4
+        got = np.zeros(len(boxes), bool)
+        got[keep.cpu().numpy()] = True
+        exp = np.zeros(len(boxes), bool)
+        exp[ekeep] = True
+        np.testing.assert_array_equal(got[sure], exp[sure])
+        assert keep.dtype == torch.int32
+        both = got & exp
+        gv = np.zeros(len(boxes), np.float32)
+        gv[keep.cpu().numpy()] = votes.cpu().numpy()
+        np.testing.assert_allclose(gv[both], all_votes[both], rtol=1e-5, atol=1e-5)
+    assert ops.filter_by_box_voting(boxes[:0].to(dev), .2, 1.).numel() == 0

@@ -312,3 +312,40 @@ def test_variant_fp32_end_to_end_and_bf16_stack(dev, name):
     check_exact('nms', model(x), g, n, raw_atol=5e-4, flip_frac=1e-3)
     check_exact('nonms', model(x, nms=False), g, n, raw_atol=5e-4, flip_frac=1e-3)
     check_exact('offs', model(x, offsets=torch.as_tensor(g['offsets'])), g, n, raw_atol=5e-4, flip_frac=1e-3)
+
+
+def test_ensemble_inference_and_inference_wrapper(dev):
+    """Two models on one slide: per-model tiled results -> concat -> box voting -> final NMS
+    (cpn_inference.py:419-427), checked against the oracle's voting + NMS applied to the same per-model results."""
+    import cpn_oracle as orc
+    import celldetection_amd as cda
+    from celldetection_amd import inference
+    from celldetection_amd.synth import synth_state_dict
+    m0, g = build('CpnU22', dev, fixture='stitch.npz')
+    m1, _ = build('CpnU22', dev, fixture='stitch.npz')
+    sd = m1.state_dict()  # second ensemble member: perturbed heads -> overlapping but different detections
+    for k in ('core.fourier_head.block.4.weight', 'core.location_head.block.4.weight'):
+        sd[k] = sd[k] * 1.05
+    m1.load_state_dict(sd)
+    m1 = m1.to(dev)
+    img = torch.as_tensor(g['img']).to(dev)
+    kw = dict(crop_size=(96, 96), strides=(64, 64))
+    parts = [inference.tiled_inference(m, img, **kw) for m in (m0, m1)]
+    boxes = torch.cat([p['boxes'] for p in parts]).cpu().numpy()
+    scores = torch.cat([p['scores'] for p in parts]).cpu().numpy()
+    for min_vote in (1, 1.5):
+        res = inference.ensemble_inference([m0, m1], img, min_vote=min_vote, **kw)
+        b, s = boxes, scores
+        if min_vote > 1:
+            keep, votes = orc.filter_by_box_voting(b, m1.nms_thresh, min_vote)
+            b, s = b[keep], s[keep]
+            assert 'votes' in res
+        keep = orc.nms(b, s, m1.nms_thresh)
+        np.testing.assert_array_equal(res['boxes'].cpu().numpy(), b[keep])
+        np.testing.assert_array_equal(res['scores'].cpu().numpy(), s[keep])
+    assert 0 < res['scores'].numel() < len(scores)
+    # cd.models.Inference mirror: HWC-free array in, numpy dict out
+    out = cda.models.Inference(m0)(g['img'][0])
+    assert isinstance(out['contours'][0], np.ndarray) and out['box_uncertainties'] is None
+    y = m0(img)
+    np.testing.assert_array_equal(out['boxes'][0], y['boxes'][0].cpu().numpy())
