@@ -22,9 +22,10 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16 peak of MI355X (MI355X_MICROARCH.md; 2:1-sparsity figures excluded)
 GFLOP_PER_TILE = {'CpnResNeXt101UNet': 2392.83, 'CpnResNet18FPN': 2124.85}  # SURVEY.md section 8a, 3x512x512 tiles
 # HBM bytes of ONE conv-graph execution (batch 16 x 3x512x512, CpnResNeXt101UNet) from the PMC passes committed in
-# profiles/r01_rocprofv3_summary.txt (tools/run_graph_only.py 5): 2 x FETCH_SIZE (gfx950 correction for wide
-# streaming reads, MI355X_MICROARCH.md section HBM) + WRITE_SIZE = 2 x 12.93 GB + 11.80 GB
-TRAFFIC_BYTES_PER_GRAPH_B16 = 37.66e9
+# profiles/r01_rocprofv3_summary.txt (tools/run_graph_only.py 5; sums over the conv/input/maxpool kernels / 5):
+# 2 x FETCH_SIZE (gfx950 correction for wide 16-B/lane streaming reads, MI355X_MICROARCH.md section HBM) + WRITE_SIZE
+# = 2 x 11.80 GB + 9.13 GB.  Algorithmic: 12.5 GB read + 9.1 GB written (every op reads/writes its tensors once).
+TRAFFIC_BYTES_PER_GRAPH_B16 = 32.73e9
 
 
 def build_model(name, dev, seed=0, tile=512, calib_tiles=2):
