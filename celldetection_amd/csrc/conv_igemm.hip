@@ -44,11 +44,13 @@ constexpr int TW = 32;   // output tile width in pixels (= one MFMA column fragm
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4];  // source of zero padding for the halo DMA
 
-__device__ __forceinline__ unsigned int f32_to_bf16_bits(float f) {
-    unsigned int u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;  // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);                                 // round to nearest even
-    return u >> 16;
+// two fp32 -> packed bf16 pair (lo, hi), round to nearest even: one v_cvt_pk_bf16_f32 on gfx950 (the software
+// sequence cost ~7 VALU per element and made the epilogue of the memory-bound layers VALU-bound)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned int b) { return __uint_as_float(b << 16); }
 
@@ -461,6 +463,73 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
             bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
             bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
         }
+        // fast path (whole tile inside the image and the channel range, residual at full resolution): the 1x1 /
+        // grouped layers are HBM-bound and their epilogue was VALU/issue-bound (~80 instructions per 16-B store: 64-bit
+        // address math, per-lane bounds, software bf16 rounding, a vmcnt(0) stall per residual load).  Here the row
+        // bases are wave-uniform, lane offsets are 32-bit, ALL residual loads of the wave are issued before the first
+        // staging pass, and a store costs ~25 instructions.
+        constexpr int NIT = 32 / PPI;
+        const bool full_tile = oy0 + TH <= a.Hout && ox0 + TW <= a.Wout && n0 + BN <= cout_b && !a.res_up;
+        if (full_tile) {
+            const unsigned lane_off = (unsigned) ((prow * a.dst_stride + a.dst_coff + co) * 2);
+            const unsigned step = (unsigned) (PPI * a.dst_stride * 2);
+            const bool has_res = a.res != nullptr;
+            u32x4 rr[WM][NIT];
+            if (has_res) {
+                const unsigned rlane_off = (unsigned) ((prow * a.res_stride + co) * 2);
+                const unsigned rstep = (unsigned) (PPI * a.res_stride * 2);
+#pragma unroll
+                for (int f = 0; f < WM; ++f) {
+                    const int oy = oy0 + wave_m * WM + f;
+                    const unsigned char *rrow = (const unsigned char *) a.res +
+                                                (((size_t) n * a.Hout + oy) * a.Wout + ox0) * (size_t) a.res_stride * 2;
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) rr[f][it] = *(const u32x4 *) (rrow + rlane_off + it * rstep);
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < WM; ++f) {
+                const int oy = oy0 + wave_m * WM + f;
+                unsigned char *drow = (unsigned char *) a.dst +
+                                      (((size_t) n * a.Hout + oy) * a.Wout + ox0) * (size_t) a.dst_stride * 2;
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float4 v;
+                        v.x = acc[j][f][q * 4 + 0]; v.y = acc[j][f][q * 4 + 1];
+                        v.z = acc[j][f][q * 4 + 2]; v.w = acc[j][f][q * 4 + 3];
+                        *(float4 *) (stg + l31 * SPITCH + (j * 32 + 8 * q + 4 * lhi) * 4) = v;
+                    }
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int p = it * PPI + prow;
+                    const float4 v0 = *(const float4 *) (stg + p * SPITCH + part * 32);
+                    const float4 v1 = *(const float4 *) (stg + p * SPITCH + part * 32 + 16);
+                    float v[8] = {v0.x + bias8[0], v0.y + bias8[1], v0.z + bias8[2], v0.w + bias8[3],
+                                  v1.x + bias8[4], v1.y + bias8[5], v1.z + bias8[6], v1.w + bias8[7]};
+                    if (has_res) {
+                        const unsigned r4[4] = {rr[f][it].x, rr[f][it].y, rr[f][it].z, rr[f][it].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[2 * e] += bf16_bits_to_f32(r4[e] & 0xffffu);
+                            v[2 * e + 1] += __uint_as_float(r4[e] & 0xffff0000u);
+                        }
+                    }
+                    if (a.act == ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)  // relu as one integer max (sign bit set -> 0; -0.0 -> +0.0)
+                            v[e] = __int_as_float(max(__float_as_int(v[e]), 0));
+                    }
+                    u32x4 o;
+                    o.x = pack_bf16x2(v[0], v[1]);
+                    o.y = pack_bf16x2(v[2], v[3]);
+                    o.z = pack_bf16x2(v[4], v[5]);
+                    o.w = pack_bf16x2(v[6], v[7]);
+                    *(u32x4 *) (drow + lane_off + it * step) = o;
+                }
+            }
+        } else
 #pragma unroll
         for (int f = 0; f < WM; ++f) {
             const int oy = oy0 + wave_m * WM + f;
@@ -499,10 +568,10 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
                 u32x4 o;
-                o.x = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
-                o.y = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
-                o.z = f32_to_bf16_bits(v[4]) | (f32_to_bf16_bits(v[5]) << 16);
-                o.w = f32_to_bf16_bits(v[6]) | (f32_to_bf16_bits(v[7]) << 16);
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
+                o.z = pack_bf16x2(v[4], v[5]);
+                o.w = pack_bf16x2(v[6], v[7]);
                 *(u32x4 *) ((unsigned short *) a.dst + pix * a.dst_stride + a.dst_coff + co) = o;
             }
         }
@@ -531,8 +600,8 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
                         if (a.act == ACT_RELU) v[e] = fmaxf(v[e], 0.f);
                     }
                     u32x2 o;
-                    o.x = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
-                    o.y = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
+                    o.x = pack_bf16x2(v[0], v[1]);
+                    o.y = pack_bf16x2(v[2], v[3]);
                     const int slot = cb >> 3;
                     *(u32x2 *) (smem + p * (BN * 2) + ((slot ^ fp) << 4) + lhi * 8) = o;
                 }
