@@ -82,6 +82,8 @@ def main():
     ap.add_argument('--tile', type=int, default=512)
     ap.add_argument('--model', default='CpnResNeXt101UNet')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--pipeline', action='store_true',
+                    help='two-stream throughput mode (CPN.forward_pipelined); default: synchronous forward() per step')
     ap.add_argument('--profile-layers', action='store_true', help='print per-op timings to stderr')
     args = ap.parse_args()
 
@@ -123,14 +125,21 @@ def main():
     if dist:
         td.barrier()
         torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = []  # HIP events around every conv-graph execution (the dominant kernel family), on its launch stream
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        # HIP events around the conv-graph execution (the dominant kernel family), on the stream it is launched on
-        ev[i][0].record()
-        maps = model.core_forward(x)
-        ev[i][1].record()
-        y = model.postprocess(*maps, (args.tile, args.tile), flag=model._last_flag)
+    if not args.pipeline:
+        for i in range(args.steps):
+            ev.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+            ev[i][0].record()
+            maps = model.core_forward(x)
+            ev[i][1].record()
+            y = model.postprocess(*maps, (args.tile, args.tile), flag=model._last_flag)
+    else:
+        # throughput mode of the tile loop: conv graph of step i+1 enqueued before the post-processing of step i
+        # (two HIP streams); every step's full work -- conv graph, decode, NMS, result tensors -- completes inside
+        # the timed region (final synchronize below)
+        for y in model.forward_pipelined((x for _ in range(args.steps)), _events=ev):
+            pass
     torch.cuda.synchronize()
     if dist:
         td.barrier()
@@ -158,7 +167,9 @@ def main():
             'config': {'workload': f'{args.model} full CPN path, batch {args.batch} x 3x{args.tile}x{args.tile} per GPU '
                                    f'(BASELINE.json configs[2]), synthetic ginoro-shaped weights',
                        'tiles_per_gpu_per_step': args.batch, 'detections_last_step': ndet,
-                       'parallelism': f'tile-sharded x{world}, no data-path collective'},
+                       'parallelism': f'tile-sharded x{world}, no data-path collective',
+                       'step_mode': 'forward() per step' if not args.pipeline else
+                       'forward_pipelined(): post-processing of step i overlaps the conv graph of step i+1'},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_BF16_TFLOPS,
                          'traffic': TRAFFIC_BYTES_PER_GRAPH_B16 if (args.model == 'CpnResNeXt101UNet' and args.batch == 16

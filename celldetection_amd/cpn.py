@@ -265,6 +265,63 @@ class CPN(nn.Module):
         return self.postprocess(scores, locations, refinement, fourier, original_size, nms=nms, flag=self._last_flag,
                                 uncertainty=self._last_uncertainty, **kwargs)
 
+    @torch.no_grad()
+    def forward_pipelined(self, batches, nms=True, _events=None, **kwargs):
+        """Throughput mode for streams of batches (the tile loop of celldetection_scripts/cpn_inference.py:357-388):
+        generator that yields ``forward(x, **kw)`` for every item of ``batches`` (``x`` or ``(x, kw_dict)``), in
+        order.  The conv graph of batch i+1 is enqueued on one HIP stream before the post-processing of batch i
+        (compaction -> decode -> NMS, incl. its host read-back of the proposal counts) runs on a second stream, so
+        the host latency and the small post-processing kernels hide behind the MFMA work.  Results are identical to
+        calling ``forward`` per batch."""
+        dev = self.order_weights_device()
+        s_conv, s_post = self._streams(dev)
+        caller = torch.cuda.current_stream(dev)
+        pending = None
+
+        def finish(item):
+            maps, unc, flag, size, kw, ev = item
+            with torch.cuda.stream(s_post):
+                s_post.wait_event(ev)
+                out = self.postprocess(*maps, size, nms=nms, flag=flag, uncertainty=unc, **dict(kwargs, **kw))
+                done = torch.cuda.Event()
+                done.record(s_post)
+            caller.wait_event(done)  # the caller's stream may consume the outputs
+            for v in out.values():
+                for t in (v or ()):
+                    t.record_stream(caller)
+            return out
+
+        for item in batches:
+            x, kw = item if isinstance(item, (tuple, list)) else (item, {})
+            if not x.is_cuda:
+                raise RuntimeError('celldetection_amd.CPN.forward needs GPU inputs (no CPU fallback).')
+            s_conv.wait_stream(caller)  # x was produced on the caller's stream
+            with torch.cuda.stream(s_conv):
+                if _events is not None:  # (start, end) HIP events around the conv graph, on its launch stream
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record(s_conv)
+                maps = self.core_forward(x)
+                ev = torch.cuda.Event(enable_timing=_events is not None)
+                ev.record(s_conv)
+                if _events is not None:
+                    _events.append((e0, ev))
+                for t in maps + (self._last_uncertainty, self._last_flag):
+                    if t is not None:
+                        t.record_stream(s_post)
+                x.record_stream(s_conv)
+            cur = (maps, self._last_uncertainty, self._last_flag, tuple(x.shape[-2:]), kw, ev)
+            if pending is not None:
+                yield finish(pending)
+            pending = cur
+        if pending is not None:
+            yield finish(pending)
+
+    def _streams(self, dev):
+        st = getattr(self, '_pipe_streams', None)
+        if st is None or st[0].device != dev:
+            st = self._pipe_streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        return st
+
     def forward_tiled(self, inputs, crop_size=1024, stride=512, **kwargs):
         """In-model tiling (celldetection/models/lightning_cpn.py:88-177); see ``inference.forward_tiled``."""
         from . import inference

@@ -349,3 +349,18 @@ def test_ensemble_inference_and_inference_wrapper(dev):
     assert isinstance(out['contours'][0], np.ndarray) and out['box_uncertainties'] is None
     y = m0(img)
     np.testing.assert_array_equal(out['boxes'][0], y['boxes'][0].cpu().numpy())
+
+
+def test_forward_pipelined_equals_forward(dev):
+    """Two-stream throughput mode returns exactly what forward() returns, batch by batch (incl. per-batch kwargs)."""
+    model, g = build('CpnU22', dev)
+    xs = [torch.rand(2, 3, 64, 96, generator=torch.Generator().manual_seed(s)).to(dev) for s in range(5)]
+    offs = [torch.tensor([[10 * i, 3 * i], [0, i]]) for i in range(5)]
+    ref = [model(x, offsets=o) for x, o in zip(xs, offs)]
+    got = list(model.forward_pipelined(((x, dict(offsets=o)) for x, o in zip(xs, offs))))
+    assert len(got) == len(ref)
+    for a, b in zip(got, ref):
+        for k in KEYS:
+            for ta, tb in zip(a[k], b[k]):
+                assert torch.equal(ta, tb), k
+    assert list(model.forward_pipelined([])) == []
