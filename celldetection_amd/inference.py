@@ -126,24 +126,33 @@ def tiled_inference(model, img: torch.Tensor, crop_size=(1024, 1024), strides=(7
         mask = mask.reshape(mask.shape[-2:])
         tile_ids = [i for i in tile_ids if bool(torch.any(mask[slices[i]]))]
     mine = [tile_ids[j] for j in shard_tiles(len(tile_ids), rank, world_size)]
-    fwd = forward_fn if forward_fn is not None else (lambda x, offsets, **kw: model(x, offsets=offsets, **kw))
     nms_thresh = model.nms_thresh if nms_thresh is None else nms_thresh
     rules = stitching_rule.split(',')
     coll: Dict[str, List[torch.Tensor]] = {k: [] for k in KEYS}
     samples = order = None
-    for b0 in range(0, len(mine), batch_size):
-        idxs = mine[b0:b0 + batch_size]
-        tiles = torch.stack([img[(...,) + slices[i]] for i in idxs])  # cropped on the device
-        offs = torch.tensor([[slices[i][1].start, slices[i][0].start] for i in idxs], dtype=torch.int64)
-        if mask is not None:
-            ub = torch.stack([mask[slices[i]] for i in idxs])[:, None].to(device=tiles.device, dtype=torch.float32)
-            y = fwd(tiles, offs, scores_upper_bound=ub)
-        else:
-            y = fwd(tiles, offs)
+    meta = []  # FIFO of (tile ids, offsets, tile size) of the batches handed to the model
+
+    def batches():
+        for b0 in range(0, len(mine), batch_size):
+            idxs = mine[b0:b0 + batch_size]
+            tiles = torch.stack([img[(...,) + slices[i]] for i in idxs])  # cropped on the device
+            offs = torch.tensor([[slices[i][1].start, slices[i][0].start] for i in idxs], dtype=torch.int64)
+            kw = dict(offsets=offs)
+            if mask is not None:
+                kw['scores_upper_bound'] = torch.stack([mask[slices[i]] for i in idxs])[:, None].to(
+                    device=tiles.device, dtype=torch.float32)
+            meta.append((idxs, offs, tuple(tiles.shape[-2:])))
+            yield tiles, kw
+
+    if forward_fn is None:  # conv graph of batch i+1 overlaps the post-processing / border filtering of batch i
+        results = model.forward_pipelined(batches())
+    else:
+        results = (forward_fn(t, kw.pop('offsets'), **kw) for t, kw in batches())
+    for y in results:
+        idxs, offs, size = meta.pop(0)
         for n, i in enumerate(idxs):
             h_i, w_i = np.unravel_index(i, shape)
             con = y['contours'][n]
-            size = tuple(tiles.shape[-2:])
             keep = remove_border(con, size, border_removal, top=h_i > 0, right=w_i < (w_tiles - 1),
                                  bottom=h_i < (h_tiles - 1), left=w_i > 0, offsets=-offs[n])
             if 'ex_br' in rules:
