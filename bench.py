@@ -76,8 +76,8 @@ def cpu_baseline(sd, tile, seconds_budget=20.):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--tile', type=int, default=512)
     ap.add_argument('--model', default='CpnResNeXt101UNet')
@@ -150,6 +150,8 @@ def main():
         td.all_reduce(t, op=td.ReduceOp.MAX)
         dt = float(t.item())
     conv_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    if args.profile_layers and rank == 0:
+        print('conv graph per step (ms): ' + ' '.join(f'{a.elapsed_time(b):.2f}' for a, b in ev), file=sys.stderr)
 
     if rank == 0:
         tiles = args.batch * args.steps * world

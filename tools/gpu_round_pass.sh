@@ -13,7 +13,7 @@ tests)
   timeout 900 python -m pytest tests -x -q -m gpu > gpurun_out/${TAG}_pytest_gpu.log 2>&1; tail -3 gpurun_out/${TAG}_pytest_gpu.log
   timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/${TAG}_smoke.log 2>&1; tail -1 gpurun_out/${TAG}_smoke.log;;
 bench)
-  timeout 600 python bench.py --steps 10 --warmup 3 --profile-layers > gpurun_out/${TAG}_bench_n1.json 2> gpurun_out/${TAG}_per_layer_timing.txt; cat gpurun_out/${TAG}_bench_n1.json;;
+  timeout 600 python bench.py --profile-layers > gpurun_out/${TAG}_bench_n1.json 2> gpurun_out/${TAG}_per_layer_timing.txt; cat gpurun_out/${TAG}_bench_n1.json;;
 profile)
   (timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -o b -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline) > $P/trace.log 2>&1
   (timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $P/gtrace -o b -- $G) > $P/gtrace.log 2>&1
