@@ -364,3 +364,58 @@ def test_forward_pipelined_equals_forward(dev):
             for ta, tb in zip(a[k], b[k]):
                 assert torch.equal(ta, tb), k
     assert list(model.forward_pipelined([])) == []
+
+
+def test_full_size_properties(dev):
+    """BASELINE.json configs[2] at full size (CpnResNeXt101UNet, 16 x 3x512x512, synthetic ginoro-shaped weights):
+    size-independent properties of the whole HIP path -- the oracle needs ~1 s per tile here, so only one tile is
+    compared with it (IoU-matched, bf16) and the rest is checked through invariants."""
+    import sys
+    import cpn_oracle as orc
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import build_model
+    model, sd = build_model('CpnResNeXt101UNet', dev)
+    x = torch.rand(16, 3, 512, 512, generator=torch.Generator().manual_seed(100)).to(dev)
+    y = model(x)
+    n_det = [len(s) for s in y['scores']]
+    assert min(n_det) > 20, n_det
+    # determinism
+    y2 = model(x)
+    for k in KEYS:
+        for a, b in zip(y[k], y2[k]):
+            assert torch.equal(a, b), k
+    # batch independence: a tile alone == the same tile inside the batch of 16 (other tile shapes / grid sizes are
+    # chosen for N=1, the per-pixel accumulation order must not change)
+    for i in (0, 7):
+        yi = model(x[i:i + 1])
+        for k in KEYS:
+            assert torch.equal(yi[k][0], y[k][i]), (k, i)
+    # uint8 input == float input / 255 (LitBase.prepare_inputs)
+    xu = (x[:2] * 255).round().to(torch.uint8)
+    ya, yb = model(xu), model(xu.float() / 255)
+    for k in KEYS:
+        for a, b in zip(ya[k], yb[k]):
+            assert torch.equal(a, b), k
+    # per image: scores sorted descending (NMS keep order) and above the threshold, boxes = min/max of the contours,
+    # contours inside the image, NMS idempotent (no kept pair overlaps above the threshold)
+    for i in range(16):
+        s, c, b = y['scores'][i], y['contours'][i], y['boxes'][i]
+        assert bool((s[:-1] >= s[1:]).all()) and float(s.min()) > model.score_thresh
+        assert torch.equal(b, torch.cat((c.min(1).values, c.max(1).values), 1))
+        assert float(c.min()) >= 0 and float(c[..., 0].max()) <= 511 and float(c[..., 1].max()) <= 511
+    for i in (0, 15):
+        b, s = y['boxes'][i].cpu().numpy(), y['scores'][i].cpu().numpy()
+        np.testing.assert_array_equal(orc.nms(b, s, model.nms_thresh), np.arange(len(s)))
+    # offsets translate exactly (integer offsets, fp32 adds)
+    offs = torch.tensor([[384 * i, 768] for i in range(16)])
+    yo = model(x, offsets=offs)
+    for i in (3, 12):
+        assert torch.equal(yo['boxes'][i], y['boxes'][i] + offs[i].repeat(2).to(dev))
+    # one tile against the fp32 CPU oracle (bf16 conv stack => IoU-matched proposals)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    ref = orc.cpn_forward({k: v.cpu() for k, v in sd.items()}, x[:1].cpu(), nms=False)
+    got = model(x[:1], nms=False)
+    rate = _iou_match_rate(got['boxes'][0].cpu().numpy(), ref['boxes'][0])
+    n_ref, n_got = len(ref['scores'][0]), len(got['scores'][0])
+    print('full size tile 0: proposals', n_got, 'oracle', n_ref, 'IoU>0.5 match rate', rate)
+    assert abs(n_ref - n_got) <= 0.1 * n_ref and rate > .9
