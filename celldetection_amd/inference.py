@@ -86,7 +86,8 @@ def _default_ops():
 def tiled_inference(model, img: torch.Tensor, crop_size=(1024, 1024), strides=(768, 768), batch_size: int = 8,
                     border_removal: int = 4, stitching_rule: str = 'nms', rank: Optional[int] = None,
                     world_size: Optional[int] = None, group=None, nms_thresh: Optional[float] = None,
-                    forward_fn: Optional[Callable] = None, ops_fns=None, mask: Optional[torch.Tensor] = None):
+                    forward_fn: Optional[Callable] = None, ops_fns=None, mask: Optional[torch.Tensor] = None,
+                    point_mask: Optional[torch.Tensor] = None, point_mask_exclusive: bool = False):
     """Slide-level CPN inference.
 
     Args:
@@ -101,6 +102,9 @@ def tiled_inference(model, img: torch.Tensor, crop_size=(1024, 1024), strides=(7
         forward_fn / ops_fns: injection points used by the CPU (gloo) tests of the sharding/gather logic.
         mask: optional [H, W] (or [1, H, W]) foreground mask: tiles whose mask crop is empty are skipped and the crop
             is passed as ``scores_upper_bound`` (TileLoader semantics, cpn_inference.py:94-100).
+        point_mask: optional [H, W] map of seed points: tiles without seeds are skipped, ``clip(crop, 0, 1)`` is passed
+            as ``scores_lower_bound`` and, with ``point_mask_exclusive``, also as ``scores_upper_bound``
+            (cpn_inference.py:102-113).
 
     Returns:
         OrderedDict of flat tensors (contours [K,S,2], boxes [K,4], scores [K], classes [K], locations [K,2],
@@ -125,6 +129,9 @@ def tiled_inference(model, img: torch.Tensor, crop_size=(1024, 1024), strides=(7
     if mask is not None:
         mask = mask.reshape(mask.shape[-2:])
         tile_ids = [i for i in tile_ids if bool(torch.any(mask[slices[i]]))]
+    if point_mask is not None:
+        point_mask = point_mask.reshape(point_mask.shape[-2:])
+        tile_ids = [i for i in tile_ids if bool(torch.any(point_mask[slices[i]]))]
     mine = [tile_ids[j] for j in shard_tiles(len(tile_ids), rank, world_size)]
     nms_thresh = model.nms_thresh if nms_thresh is None else nms_thresh
     rules = stitching_rule.split(',')
@@ -141,6 +148,12 @@ def tiled_inference(model, img: torch.Tensor, crop_size=(1024, 1024), strides=(7
             if mask is not None:
                 kw['scores_upper_bound'] = torch.stack([mask[slices[i]] for i in idxs])[:, None].to(
                     device=tiles.device, dtype=torch.float32)
+            if point_mask is not None:
+                lb = torch.stack([point_mask[slices[i]] for i in idxs])[:, None].to(
+                    device=tiles.device, dtype=torch.float32).clamp(0., 1.)
+                kw['scores_lower_bound'] = lb
+                if point_mask_exclusive:
+                    kw['scores_upper_bound'] = lb
             meta.append((idxs, offs, tuple(tiles.shape[-2:])))
             yield tiles, kw
 

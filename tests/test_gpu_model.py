@@ -258,6 +258,15 @@ def test_forward_tiled_and_mask(dev):
     full = inference.tiled_inference(model, img, (96, 96), (64, 64))
     assert 0 < out['scores'].numel() <= full['scores'].numel()
     assert float(out['locations'][:, 0].max()) < 112 + 8
+    # point mask: seeds force detections (scores_lower_bound = 1 at the seed pixels); exclusive -> only the seeds
+    pm = torch.zeros(160, 224, device=dev)
+    pm[40:44, 60:64] = 1  # 4x4 blobs: the bilinear resize to the stride-2 score grid keeps 1.0 inside
+    pm[120:124, 180:184] = 1
+    seeded = inference.tiled_inference(model, img, (96, 96), (64, 64), point_mask=pm, stitching_rule='')
+    only = inference.tiled_inference(model, img, (96, 96), (64, 64), point_mask=pm, point_mask_exclusive=True,
+                                     stitching_rule='')
+    assert only['scores'].numel() >= 2 and bool((only['scores'] == 1).all())
+    assert seeded['scores'].numel() > only['scores'].numel()
 
 
 # ---- CPN.forward variants: bucketed refinement, uncertainty head, multi-class scores, head options --------------------
