@@ -51,6 +51,9 @@ _SIGNATURES = [
                                           POINTER(c_void_p), c_void_p, c_void_p, POINTER(c_float), POINTER(c_double)]),
     ('cpn_conv2d', ctypes.c_int, [POINTER(OpDesc), c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p,
                                   c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    ('cpn_conv2d_fp8', ctypes.c_int, [POINTER(OpDesc), c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p,
+                                      c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_float, c_float,
+                                      c_void_p]),
     ('cpn_maxpool2d', ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                      c_int32, c_void_p]),
     ('cpn_resize_bilinear', ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,

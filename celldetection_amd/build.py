@@ -17,13 +17,14 @@ ARCH = 'gfx950'
 SOURCES = {
     # file: extra flags
     'conv_igemm.hip': [],
+    'conv_fp8.hip': [],  # the same source with CPN_FP8 = 1 (e4m3 operands)
     'misc_kernels.hip': [],
     'conv_f32.hip': [],
     # decode/NMS must reproduce the reference's fp32 operation order bit-for-bit: no FMA contraction
     'decode_nms.hip': ['-ffp-contract=off'],
     'cpn_abi.hip': [],
 }
-HEADERS = ['cpn_kernels.h', 'cpn_error.h', os.path.join('..', '..', 'include', 'cpn_hip.h')]
+HEADERS = ['cpn_kernels.h', 'cpn_error.h', 'conv_igemm.hip', os.path.join('..', '..', 'include', 'cpn_hip.h')]
 
 
 def _hipcc():

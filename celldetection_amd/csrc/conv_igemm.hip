@@ -32,12 +32,42 @@
 
 #include "cpn_kernels.h"
 
-namespace cpn {
+// This source is compiled twice: as is (bf16 operands, v_mfma_f32_32x32x16_bf16) and through csrc/conv_fp8.hip with
+// CPN_FP8 = 1 (OCP e4m3 operands, v_mfma_scale_f32_32x32x64_f8f6f4: a 64-byte LDS record holds 64 channels instead
+// of 32, ONE K=64 MFMA consumes both 16-byte parts of a lane's record half, i.e. twice the MACs per staged byte,
+// LDS read and MFMA cycle).  Everything that is not marked CPN_FP8 is shared.
+#ifndef CPN_FP8
+#define CPN_FP8 0
+#endif
+#if CPN_FP8
+#define CPN_NS cpn_fp8
+#else
+#define CPN_NS cpn
+#endif
+
+namespace CPN_NS {
+using namespace cpn;
+
+#if CPN_FP8
+typedef unsigned char elem_t;    // e4m3
+#else
+typedef unsigned short elem_t;   // bf16
+#endif
+constexpr int ES = (int) sizeof(elem_t);  // bytes per channel
+constexpr int CH = 64 / ES;               // channels per 64-byte LDS record (= K extent of one pipeline item)
+constexpr int EPP = 16 / ES;              // channels per 16-byte part
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+#if CPN_FP8
+typedef i32x4 frag_t;   // 16 e4m3 (one 16-byte part)
+#else
+typedef bf16x8 frag_t;  // 8 bf16
+#endif
 
 constexpr int REC = 64;  // LDS bytes per 32-channel record (pixel or weight row)
 constexpr int TW = 32;   // output tile width in pixels (= one MFMA column fragment)
@@ -53,6 +83,46 @@ __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned int b) { return __uint_as_float(b << 16); }
+
+// 8 consecutive channels of one pixel <-> memory (16 B of bf16 | 8 B of e4m3 scaled by 1/out_scale)
+#if CPN_FP8
+typedef u32x2 store8_t;
+__device__ __forceinline__ store8_t pack8(const float (&v)[8], float inv_scale) {
+    float q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) q[e] = __builtin_amdgcn_fmed3f(v[e] * inv_scale, -448.f, 448.f);  // saturate (e4m3fn)
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(q[4], q[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], hi, true);
+    store8_t o;
+    o.x = (unsigned) lo; o.y = (unsigned) hi;
+    return o;
+}
+__device__ __forceinline__ void add_res8(float (&v)[8], const store8_t r, float scale) {
+    v[0] += __builtin_amdgcn_cvt_f32_fp8((int) r.x, 0) * scale; v[1] += __builtin_amdgcn_cvt_f32_fp8((int) r.x, 1) * scale;
+    v[2] += __builtin_amdgcn_cvt_f32_fp8((int) r.x, 2) * scale; v[3] += __builtin_amdgcn_cvt_f32_fp8((int) r.x, 3) * scale;
+    v[4] += __builtin_amdgcn_cvt_f32_fp8((int) r.y, 0) * scale; v[5] += __builtin_amdgcn_cvt_f32_fp8((int) r.y, 1) * scale;
+    v[6] += __builtin_amdgcn_cvt_f32_fp8((int) r.y, 2) * scale; v[7] += __builtin_amdgcn_cvt_f32_fp8((int) r.y, 3) * scale;
+}
+#else
+typedef u32x4 store8_t;
+__device__ __forceinline__ store8_t pack8(const float (&v)[8], float) {
+    store8_t o;
+    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+    o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+    return o;
+}
+__device__ __forceinline__ void add_res8(float (&v)[8], const store8_t r, float) {
+    const unsigned r4[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[2 * e] += bf16_bits_to_f32(r4[e] & 0xffffu);
+        v[2 * e + 1] += __uint_as_float(r4[e] & 0xffff0000u);
+    }
+}
+#endif
 
 __device__ __forceinline__ void dma16(const void *gsrc, unsigned char *lds_wave_base) {
     // 64 lanes x 16 B -> LDS [lds_wave_base + lane*16]; the LDS base must be wave-uniform
@@ -99,8 +169,8 @@ __device__ __forceinline__ void halo_src_offsets(const HaloGeo &G, int q, int la
     if (valid) {
         const int y0 = G.up0 ? (iy >> 1) : iy, x0 = G.up0 ? (ix >> 1) : ix;
         const int y1 = G.up1 ? (iy >> 1) : iy, x1 = G.up1 ? (ix >> 1) : ix;
-        o0 = ((G.n * G.Hs0 + y0) * G.Ws0 + x0) * G.c0_stride + part * 8;
-        o1 = ((G.n * G.Hs1 + y1) * G.Ws1 + x1) * G.c1_stride + part * 8;
+        o0 = ((G.n * G.Hs0 + y0) * G.Ws0 + x0) * G.c0_stride + part * EPP;
+        o1 = ((G.n * G.Hs1 + y1) * G.Ws1 + x1) * G.c1_stride + part * EPP;
     }
 }
 
@@ -110,11 +180,11 @@ __device__ __forceinline__ void halo_src_offsets(const HaloGeo &G, int q, int la
 // The fragment reads are therefore inline asm (invisible to the compiler's counters) and every MFMA group is
 // preceded by OUR counted wait, which names the fragment registers as "+v" so that no use can be scheduled above it.
 template <int IMM>
-__device__ __forceinline__ void ds_read16(bf16x8 &d, unsigned addr) {
+__device__ __forceinline__ void ds_read16(frag_t &d, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(IMM));
 }
 template <int N, int WN, int WM>
-__device__ __forceinline__ void wait_frags(bf16x8 (&w)[WN], bf16x8 (&p)[WM]) {
+__device__ __forceinline__ void wait_frags(frag_t (&w)[WN], frag_t (&p)[WM]) {
     static_assert((WN == 2 && (WM == 4 || WM == 2 || WM == 1)) || (WN == 1 && (WM == 2 || WM == 1)), "frag shape");
     if constexpr (WN == 2 && WM == 4)
         asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(w[0]), "+v"(w[1]), "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]) : "n"(N));
@@ -129,7 +199,7 @@ __device__ __forceinline__ void wait_frags(bf16x8 (&w)[WN], bf16x8 (&p)[WM]) {
 }
 // step boundary: all my DMA landed + all my LDS reads returned (fragment set named "+v" as above)
 template <int WN, int WM>
-__device__ __forceinline__ void wait_all(bf16x8 (&w)[WN], bf16x8 (&p)[WM]) {
+__device__ __forceinline__ void wait_all(frag_t (&w)[WN], frag_t (&p)[WM]) {
     if constexpr (WN == 2 && WM == 4)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]) :: "memory");
     else if constexpr (WN == 2 && WM == 2)
@@ -142,7 +212,7 @@ __device__ __forceinline__ void wait_all(bf16x8 (&w)[WN], bf16x8 (&p)[WM]) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(w[0]), "+v"(p[0]) :: "memory");
 }
 template <int WN, int WM, int FRAG_STRIDE>
-__device__ __forceinline__ void load_frags(bf16x8 (&w)[WN], bf16x8 (&p)[WM], unsigned paddr, unsigned waddr) {
+__device__ __forceinline__ void load_frags(frag_t (&w)[WN], frag_t (&p)[WM], unsigned paddr, unsigned waddr) {
     ds_read16<0>(w[0], waddr);
     if constexpr (WN > 1) ds_read16<32 * REC>(w[1], waddr);
     ds_read16<0>(p[0], paddr);
@@ -202,13 +272,19 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     const int HH = (TH - 1) * S + KH;                 // halo rows
     const int hinstr = (HH * PITCH * 4 + 63) >> 6;    // 1-KiB DMA instructions per halo tile
     const int halo_buf = hinstr << 10;
-    const int nchunks = a.cin_b >> 5;
+    const int nchunks = a.cin_b / CH;
     const int ntaps = KH * KW;
     const bool pw = ntaps == 1;                        // one item per chunk (1x1, any stride): PW-style halo schedule
     const int nhb = pw ? 4 : (nchunks > 1 ? 2 : 1);   // halo ring size (chunk c lives in buffer c & (nhb-1))
     const int nhb_mask = nhb - 1;
-    const int nitems = nchunks * ntaps;               // flattened K items; a pipeline step covers two of them
-    const int nsteps = (nitems + 1) >> 1;             // (only the very last step may hold a single item)
+    const int nreal = nchunks * ntaps;                // flattened K items; a pipeline step covers two of them
+#if CPN_FP8
+    const int nitems = nreal + (nreal & 1);           // + one all-zero weight slab: every step holds two items
+#else
+    const int nitems = nreal;
+#endif
+    const int nsteps = (nitems + 1) >> 1;             // (only the very last step may hold a single item; the fp8
+                                                      // weight blob pads an odd item count with one all-zero slab)
     const int cout_b = a.cout_b;
     const int cin0 = g * a.cin_b;
     const int c0_used = a.c0_used;
@@ -227,8 +303,8 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
 
     // halo DMA instruction q (0..hinstr) is issued by wave q % NWAVES; the source offsets are recomputed per issue
     // (a few VALU per 1-KiB DMA; keeping them in registers cost 10 VGPRs of a kernel that sits at the 256 limit)
-    const unsigned short *const src0 = (const unsigned short *) a.src0;
-    const unsigned short *const src1 = (const unsigned short *) a.src1;
+    const elem_t *const src0 = (const elem_t *) a.src0;
+    const elem_t *const src1 = (const elem_t *) a.src1;
     const unsigned char *const zero_src = (const unsigned char *) g_zero16;
 
     // weight DMA: instruction q = wave + it*NWAVES of a step covers item k = q / W_INSTR_ITEM, rows qi*16..+15 of
@@ -250,7 +326,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     }
     const size_t item_bytes = (size_t) cout_b * REC;
     // slab of the first item of the NEXT step to be staged (steps are staged in order, two items each)
-    const unsigned char *wptr = (const unsigned char *) a.weights + ((size_t) g * nchunks * ntaps * cout_b + n0) * REC;
+    const unsigned char *wptr = (const unsigned char *) a.weights + ((size_t) g * nitems * cout_b + n0) * REC;
 
     // 1x1 fast path of the activation-tile DMA: single full-resolution source -> per-lane offsets are loop constants;
     // out-of-image lanes are masked off (their LDS bytes stay stale: they only feed output pixels never stored)
@@ -263,15 +339,15 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
         int o0 = -1, o1 = -1;
         if (PW) halo_src_offsets<PITCH>(G, wave + it * C::NWAVES, lane, o0, o1);
         a_ok[it] = o0 >= 0 && (wave + it * C::NWAVES) < hinstr;
-        a_voff[it] = (unsigned) (o0 < 0 ? 0 : o0) * 2u;
+        a_voff[it] = (unsigned) (o0 < 0 ? 0 : o0) * (unsigned) ES;
     }
 
 #define HALO_DMA(CHUNK)                                                                                        \
     {                                                                                                          \
         const int c_ = (CHUNK);                                                                                \
-        const int cin_ = cin0 + c_ * 32;                                                                       \
+        const int cin_ = cin0 + c_ * CH;                                                                       \
         const bool from0_ = cin_ < c0_used;                                                                    \
-        const unsigned short *base_ = from0_ ? src0 + cin_ : src1 + (cin_ - c0_used);                          \
+        const elem_t *base_ = from0_ ? src0 + cin_ : src1 + (cin_ - c0_used);                                  \
         unsigned char *dstb_ = smem + (c_ & nhb_mask) * halo_buf;                                              \
         for (int q_ = wave; q_ < hinstr; q_ += C::NWAVES) {                                                    \
             int o0_, o1_;                                                                                      \
@@ -285,7 +361,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
 #define PW_HALO_DMA(CHUNK)                                                                                     \
     {                                                                                                          \
         const int c_ = (CHUNK);                                                                                \
-        const unsigned char *base_ = (const unsigned char *) (src0 + cin0 + c_ * 32);                          \
+        const unsigned char *base_ = (const unsigned char *) (src0 + cin0 + c_ * CH);                          \
         unsigned char *dstb_ = smem + (c_ & nhb_mask) * halo_buf;                                              \
         _Pragma("unroll") for (int it = 0; it < A_INSTR_WAVE; ++it)                                            \
             if (a_ok[it]) dma16(base_ + a_voff[it], dstb_ + ((wave + it * C::NWAVES) << 10));                  \
@@ -312,7 +388,8 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     const int l31 = lane & 31, lhi = lane >> 5;
     // weight fragment: row = wave_n*WN*32 + j*32 + l31 -> (row>>2)&3 == (l31>>2)&3 is lane-constant; the k-half is
     // an XOR 32 on the byte address (records are 64-B aligned, the swizzled part index lives in bits 4-5)
-    const unsigned w_lane = (unsigned) ((wave_n * WN * 32 + l31) * REC + ((lhi ^ ((l31 >> 2) & 3)) << 4));
+    constexpr int PSEL = CPN_FP8 ? 2 : 1;  // first 16-byte part of lane half lhi: lhi (bf16 k-half 0) | 2*lhi (fp8)
+    const unsigned w_lane = (unsigned) ((wave_n * WN * 32 + l31) * REC + (((PSEL * lhi) ^ ((l31 >> 2) & 3)) << 4));
     const int x_lane = l31 * S;                            // halo column of this lane's pixel for tap column 0
     const int row_wave = wave_m * WM * S;                  // halo row of fragment 0 for tap row 0
     constexpr int FRAG_STRIDE = S * PITCH * REC;           // bytes between the halo rows of consecutive fragments
@@ -344,8 +421,8 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
 
     // byte address (within smem) of this lane's k-half-0 pixel / weight fragment of an item
 #define ITEM_PADDR(C_, KY_, KX_)                                                                               \
-    ((unsigned) (((C_) & nhb_mask) * halo_buf + (row_wave + (KY_)) * (PITCH * REC)) +                          \
-     (unsigned) ((x_lane + (KX_)) * REC) + (unsigned) ((lhi ^ (((x_lane + (KX_)) >> 2) & 3)) << 4))
+    ((unsigned) ((min((C_), nchunks - 1) & nhb_mask) * halo_buf + (row_wave + (KY_)) * (PITCH * REC)) +        \
+     (unsigned) ((x_lane + (KX_)) * REC) + (unsigned) (((PSEL * lhi) ^ (((x_lane + (KX_)) >> 2) & 3)) << 4))
     const unsigned lds0 = (unsigned) (size_t) (__attribute__((address_space(3))) unsigned char *) smem;
 #define LOAD_GROUP(WF, PF, PADDR, WADDR) load_frags<WN, WM, FRAG_STRIDE>(WF, PF, lds0 + (PADDR), lds0 + (WADDR))
     // MFMAs of a group whose reads were followed by PENDING younger ds_reads (the next group's prefetch)
@@ -363,11 +440,11 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
         if (idx2_ < nitems) {                                                                                  \
             const bool two_nn_ = idx2_ + 1 < nitems;                                                           \
             if (pw_fast) {                                                                                     \
-                CPN_EXP_H(PW_HALO_DMA(idx2_));                                                                 \
-                if (two_nn_) CPN_EXP_H(PW_HALO_DMA(idx2_ + 1));                                                \
+                if (idx2_ < nreal) CPN_EXP_H(PW_HALO_DMA(idx2_));                                              \
+                if (idx2_ + 1 < nreal) CPN_EXP_H(PW_HALO_DMA(idx2_ + 1));                                      \
             } else if (pw) {                                                                                   \
-                CPN_EXP_H(HALO_DMA(idx2_));                                                                    \
-                if (two_nn_) CPN_EXP_H(HALO_DMA(idx2_ + 1));                                                   \
+                if (idx2_ < nreal) CPN_EXP_H(HALO_DMA(idx2_));                                                 \
+                if (idx2_ + 1 < nreal) CPN_EXP_H(HALO_DMA(idx2_ + 1));                                         \
             }                                                                                                  \
             CPN_EXP_W(W_DMA(two_nn_, ((ST1) + 1) & 1));                                                        \
         }                                                                                                      \
@@ -386,7 +463,58 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     __builtin_amdgcn_s_barrier();
     ISSUE_AT_TRANSITION(i0, 0, true);
 
-    bf16x8 wA[WN], pA[WM], wB[WN], pB[WM];
+#if CPN_FP8
+    // fp8: an item = 64 channels x 1 tap.  A lane's operand is the 32 contiguous bytes of its record half = two
+    // 16-byte parts X (part 2*lhi) and Y (the next part = byte address ^ 16); ONE K=64 MFMA consumes X|Y.  Two
+    // operand sets (item 0 / item 1 of the step) alternate so that the reads of item i+1 are in flight while the
+    // MFMAs of item i issue; the step boundary sits in front of the MFMAs of item 1, whose operands are in registers.
+    frag_t wX0[WN], pX0[WM], wY0[WN], pY0[WM], wX1[WN], pX1[WM], wY1[WN], pY1[WM];
+    constexpr int NF = WN + WM;  // ds_reads per part set
+#define CAT8(LO, HI) __builtin_shufflevector(LO, HI, 0, 1, 2, 3, 4, 5, 6, 7)
+#define MMA8(WX, WY, PX, PY, PENDING)                                                                          \
+    {                                                                                                          \
+        wait_frags<PENDING, WN, WM>(WY, PY);                                                                   \
+        _Pragma("unroll") for (int j = 0; j < WN; ++j)                                                         \
+            _Pragma("unroll") for (int f = 0; f < WM; ++f)                                                     \
+                acc[j][f] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                   \
+                    CAT8(WX[j], WY[j]), CAT8(PX[f], PY[f]), acc[j][f], 0, 0, 0, 127, 0, 127);                  \
+    }
+    unsigned pa = ITEM_PADDR(i0.c, i0.ky, i0.kx);
+    unsigned wa = (unsigned) ldsW_off + w_lane;
+    LOAD_GROUP(wX0, pX0, pa, wa);
+    wait_frags<0, WN, WM>(wX0, pX0);
+    for (int st = 0; st + 1 < nsteps; ++st) {
+        LOAD_GROUP(wY0, pY0, pa ^ 16u, wa ^ 16u);     // item 0, second part
+        const unsigned pa1 = ITEM_PADDR(i1.c, i1.ky, i1.kx), wa1 = wa + WITEM;
+        LOAD_GROUP(wX1, pX1, pa1, wa1);               // item 1, first part
+        MMA8(wX0, wY0, pX0, pY0, NF);                 // item 0
+        LOAD_GROUP(wY1, pY1, pa1 ^ 16u, wa1 ^ 16u);   // item 1, second part
+        const ItemState n0i = next_item(i1, KH, KW);  // first item of step st+1
+        wait_all<WN, WM>(wY1, pY1);                   // my DMA for step st+1 landed, all my LDS reads returned
+        wait_frags<0, WN, WM>(wX1, pX1);              // (names the X set of item 1 as complete, too)
+        __builtin_amdgcn_s_barrier();
+        ISSUE_AT_TRANSITION(n0i, st + 1, n0i.c != i0.c);
+        pa = ITEM_PADDR(n0i.c, n0i.ky, n0i.kx);
+        wa = (unsigned) (ldsW_off + ((st + 1) & 1) * WBUF) + w_lane;
+        LOAD_GROUP(wX0, pX0, pa, wa);                 // first part of step st+1
+        MMA8(wX1, wY1, pX1, pY1, NF);                 // item 1 (operands already in registers)
+        wait_frags<0, WN, WM>(wX0, pX0);
+        i0 = n0i;
+        i1 = next_item(n0i, KH, KW);
+    }
+    {   // last step (two items: an odd item count was padded with a zero slab)
+        LOAD_GROUP(wY0, pY0, pa ^ 16u, wa ^ 16u);
+        const unsigned pa1 = ITEM_PADDR(i1.c, i1.ky, i1.kx), wa1 = wa + WITEM;
+        LOAD_GROUP(wX1, pX1, pa1, wa1);
+        MMA8(wX0, wY0, pX0, pY0, NF);
+        LOAD_GROUP(wY1, pY1, pa1 ^ 16u, wa1 ^ 16u);
+        wait_frags<NF, WN, WM>(wX1, pX1);
+        MMA8(wX1, wY1, pX1, pY1, 0);
+    }
+#undef MMA8
+#undef CAT8
+#else
+    frag_t wA[WN], pA[WM], wB[WN], pB[WM];
     constexpr int NF = WN + WM;  // ds_reads per group
     unsigned pa = ITEM_PADDR(i0.c, i0.ky, i0.kx);
     unsigned wa = (unsigned) ldsW_off + w_lane;
@@ -428,6 +556,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
         MMA_GROUP(wA, pA, NF);
     }
     MMA_GROUP(wB, pB, 0);
+#endif
 #undef HALO_DMA
 #undef PW_HALO_DMA
 #undef W_DMA
@@ -463,6 +592,25 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
             bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
             bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
         }
+#if CPN_FP8
+        // fp8: acc = sum of e4m3 code products; mult = per-output-channel weight scale (the input scale is folded into
+        // the weights before they are quantised); outputs are stored as e4m3 codes of value * out_inv_scale
+        float mult8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mult8[e] = 1.f;
+        if (a.mult && ch_ok) {
+            const float4 m0 = *(const float4 *) (a.mult + co), m1 = *(const float4 *) (a.mult + co + 4);
+            mult8[0] = m0.x; mult8[1] = m0.y; mult8[2] = m0.z; mult8[3] = m0.w;
+            mult8[4] = m1.x; mult8[5] = m1.y; mult8[6] = m1.z; mult8[7] = m1.w;
+        }
+#define CPN_V8(V0, V1)                                                                                              \
+    {V0.x * mult8[0] + bias8[0], V0.y * mult8[1] + bias8[1], V0.z * mult8[2] + bias8[2], V0.w * mult8[3] + bias8[3],    \
+     V1.x * mult8[4] + bias8[4], V1.y * mult8[5] + bias8[5], V1.z * mult8[6] + bias8[6], V1.w * mult8[7] + bias8[7]}
+#else
+#define CPN_V8(V0, V1)                                                                                              \
+    {V0.x + bias8[0], V0.y + bias8[1], V0.z + bias8[2], V0.w + bias8[3],                                            \
+     V1.x + bias8[4], V1.y + bias8[5], V1.z + bias8[6], V1.w + bias8[7]}
+#endif
         // fast path (whole tile inside the image and the channel range, residual at full resolution): the 1x1 /
         // grouped layers are HBM-bound and their epilogue was VALU/issue-bound (~80 instructions per 16-B store: 64-bit
         // address math, per-lane bounds, software bf16 rounding, a vmcnt(0) stall per residual load).  Here the row
@@ -471,27 +619,27 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
         constexpr int NIT = 32 / PPI;
         const bool full_tile = oy0 + TH <= a.Hout && ox0 + TW <= a.Wout && n0 + BN <= cout_b && !a.res_up;
         if (full_tile) {
-            const unsigned lane_off = (unsigned) ((prow * a.dst_stride + a.dst_coff + co) * 2);
-            const unsigned step = (unsigned) (PPI * a.dst_stride * 2);
+            const unsigned lane_off = (unsigned) ((prow * a.dst_stride + a.dst_coff + co) * ES);
+            const unsigned step = (unsigned) (PPI * a.dst_stride * ES);
             const bool has_res = a.res != nullptr;
-            u32x4 rr[WM][NIT];
+            store8_t rr[WM][NIT];
             if (has_res) {
-                const unsigned rlane_off = (unsigned) ((prow * a.res_stride + co) * 2);
-                const unsigned rstep = (unsigned) (PPI * a.res_stride * 2);
+                const unsigned rlane_off = (unsigned) ((prow * a.res_stride + co) * ES);
+                const unsigned rstep = (unsigned) (PPI * a.res_stride * ES);
 #pragma unroll
                 for (int f = 0; f < WM; ++f) {
                     const int oy = oy0 + wave_m * WM + f;
                     const unsigned char *rrow = (const unsigned char *) a.res +
-                                                (((size_t) n * a.Hout + oy) * a.Wout + ox0) * (size_t) a.res_stride * 2;
+                                                (((size_t) n * a.Hout + oy) * a.Wout + ox0) * (size_t) a.res_stride * ES;
 #pragma unroll
-                    for (int it = 0; it < NIT; ++it) rr[f][it] = *(const u32x4 *) (rrow + rlane_off + it * rstep);
+                    for (int it = 0; it < NIT; ++it) rr[f][it] = *(const store8_t *) (rrow + rlane_off + it * rstep);
                 }
             }
 #pragma unroll
             for (int f = 0; f < WM; ++f) {
                 const int oy = oy0 + wave_m * WM + f;
                 unsigned char *drow = (unsigned char *) a.dst +
-                                      (((size_t) n * a.Hout + oy) * a.Wout + ox0) * (size_t) a.dst_stride * 2;
+                                      (((size_t) n * a.Hout + oy) * a.Wout + ox0) * (size_t) a.dst_stride * ES;
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
 #pragma unroll
@@ -506,27 +654,14 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
                     const int p = it * PPI + prow;
                     const float4 v0 = *(const float4 *) (stg + p * SPITCH + part * 32);
                     const float4 v1 = *(const float4 *) (stg + p * SPITCH + part * 32 + 16);
-                    float v[8] = {v0.x + bias8[0], v0.y + bias8[1], v0.z + bias8[2], v0.w + bias8[3],
-                                  v1.x + bias8[4], v1.y + bias8[5], v1.z + bias8[6], v1.w + bias8[7]};
-                    if (has_res) {
-                        const unsigned r4[4] = {rr[f][it].x, rr[f][it].y, rr[f][it].z, rr[f][it].w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[2 * e] += bf16_bits_to_f32(r4[e] & 0xffffu);
-                            v[2 * e + 1] += __uint_as_float(r4[e] & 0xffff0000u);
-                        }
-                    }
+                    float v[8] = CPN_V8(v0, v1);
+                    if (has_res) add_res8(v, rr[f][it], a.res_scale);
                     if (a.act == ACT_RELU) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e)  // relu as one integer max (sign bit set -> 0; -0.0 -> +0.0)
                             v[e] = __int_as_float(max(__float_as_int(v[e]), 0));
                     }
-                    u32x4 o;
-                    o.x = pack_bf16x2(v[0], v[1]);
-                    o.y = pack_bf16x2(v[2], v[3]);
-                    o.z = pack_bf16x2(v[4], v[5]);
-                    o.w = pack_bf16x2(v[6], v[7]);
-                    *(u32x4 *) (drow + lane_off + it * step) = o;
+                    *(store8_t *) (drow + lane_off + it * step) = pack8(v, a.out_inv_scale);
                 }
             }
         } else
@@ -549,30 +684,18 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
                 const float4 v0 = *(const float4 *) (stg + p * SPITCH + part * 32);
                 const float4 v1 = *(const float4 *) (stg + p * SPITCH + part * 32 + 16);
                 if (!(ch_ok && oy < a.Hout && ox < a.Wout)) continue;
-                float v[8] = {v0.x + bias8[0], v0.y + bias8[1], v0.z + bias8[2], v0.w + bias8[3],
-                              v1.x + bias8[4], v1.y + bias8[5], v1.z + bias8[6], v1.w + bias8[7]};
+                float v[8] = CPN_V8(v0, v1);
                 const size_t pix = ((size_t) n * a.Hout + oy) * a.Wout + ox;
                 if (a.res) {
                     size_t rpix = pix;
                     if (a.res_up) rpix = ((size_t) n * (a.Hout >> 1) + (oy >> 1)) * (a.Wout >> 1) + (ox >> 1);
-                    const u32x4 r = *(const u32x4 *) ((const unsigned short *) a.res + rpix * a.res_stride + co);
-                    const unsigned rr[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[2 * e] += bf16_bits_to_f32(rr[e] & 0xffffu);
-                        v[2 * e + 1] += bf16_bits_to_f32(rr[e] >> 16);
-                    }
+                    add_res8(v, *(const store8_t *) ((const elem_t *) a.res + rpix * a.res_stride + co), a.res_scale);
                 }
                 if (a.act == ACT_RELU) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
-                u32x4 o;
-                o.x = pack_bf16x2(v[0], v[1]);
-                o.y = pack_bf16x2(v[2], v[3]);
-                o.z = pack_bf16x2(v[4], v[5]);
-                o.w = pack_bf16x2(v[6], v[7]);
-                *(u32x4 *) ((unsigned short *) a.dst + pix * a.dst_stride + a.dst_coff + co) = o;
+                *(store8_t *) ((elem_t *) a.dst + pix * a.dst_stride + a.dst_coff + co) = pack8(v, a.out_inv_scale);
             }
         }
     } else if (a.out_mode == OUT_FUSED_HEAD) {
@@ -596,7 +719,8 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[j][f][q * 4 + e] + (a.bias ? a.bias[g * cout_b + cb + e] : 0.f);
+                        v[e] = acc[j][f][q * 4 + e] * (CPN_FP8 && a.mult ? a.mult[g * cout_b + cb + e] : 1.f) +
+                               (a.bias ? a.bias[g * cout_b + cb + e] : 0.f);
                         if (a.act == ACT_RELU) v[e] = fmaxf(v[e], 0.f);
                     }
                     u32x2 o;
@@ -654,7 +778,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
                     for (int e = 0; e < 4; ++e) {
                         const int ce = co + e;
                         if (ce >= a.cout_real) continue;
-                        float x = acc[j][f][q * 4 + e] + (a.bias ? a.bias[ce] : 0.f);
+                        float x = acc[j][f][q * 4 + e] * (CPN_FP8 && a.mult ? a.mult[ce] : 1.f) + (a.bias ? a.bias[ce] : 0.f);
                         if (a.act == ACT_RELU) x = fmaxf(x, 0.f);
                         else if (a.act == ACT_SIGMOID) x = 1.f / (1.f + expf(-x));
                         else if (a.act == ACT_TANH_SCALED) x = tanhf(x) * a.act_scale;
@@ -740,7 +864,7 @@ static TileChoice choose_tile(const ConvArgs &a) {
 }
 
 int launch_conv(const ConvArgs &a, hipStream_t stream) {
-    if (a.cin_b % 32 || a.cout_b % 32 || a.c0_used % 32) return (int) hipErrorInvalidValue;
+    if (a.cin_b % CH || a.cout_b % 32 || a.c0_used % CH) return (int) hipErrorInvalidValue;
     if (a.stride != 1 && a.stride != 2) return (int) hipErrorInvalidValue;
     if ((a.stride == 1 && a.KW > 17) || (a.stride == 2 && a.KW > 18)) return (int) hipErrorInvalidValue;
     TileChoice c = choose_tile(a);
@@ -773,4 +897,10 @@ double conv_executed_flops(const ConvArgs &a) {
     return 2.0 * a.N * a.Hout * a.Wout * (double) a.bundles * a.cout_b * a.cin_b * a.KH * a.KW;
 }
 
+}  // namespace CPN_NS
+
+#if CPN_FP8
+namespace cpn {
+int launch_conv_fp8(const ConvArgs &a, hipStream_t stream) { return cpn_fp8::launch_conv(a, stream); }
 }  // namespace cpn
+#endif

@@ -315,6 +315,29 @@ int cpn_conv2d(const cpn_op_desc *op, const void *src0, int32_t c0_stride, const
     return check_hip((hipError_t) launch_conv(a, (hipStream_t) stream), "cpn_conv2d");
 }
 
+int cpn_conv2d_fp8(const cpn_op_desc *op, const void *src0, int32_t c0_stride, const void *src1, int32_t c1_stride,
+                   const void *res, int32_t res_stride, void *dst, int32_t dst_stride, int32_t N, int32_t Hin,
+                   int32_t Win, const void *weights, const float *bias, const float *mult, float res_scale,
+                   float out_inv_scale, void *stream) {
+    if (!op || !src0 || !dst || !weights) return fail(CPN_E_INVALID, "cpn_conv2d_fp8: null pointer");
+    if (op->cin_b % 64 || op->c0_used % 64 || c0_stride % 64 || (src1 && c1_stride % 64))
+        return fail(CPN_E_INVALID, "cpn_conv2d_fp8: input channel counts / strides must be multiples of 64");
+    ConvArgs a;
+    int rc = build_conv_args(nullptr, *op, N, 0, 0, a, src0, c0_stride, src1, c1_stride, res, res_stride, dst,
+                             dst_stride, Hin, Win);
+    if (rc) return rc;
+    a.weights = (const unsigned char *) weights + op->weight_offset;
+    a.bias = (bias && op->bias_offset >= 0) ? bias + op->bias_offset : nullptr;
+    a.mult = (mult && op->bias_offset >= 0) ? mult + op->bias_offset : mult;
+    a.res_scale = res_scale;
+    a.out_inv_scale = out_inv_scale;
+    if (op->fuse_cout > 0) {
+        a.fuse_w = (const unsigned char *) weights + op->fuse_weight_offset;
+        a.fuse_b = (bias && op->fuse_bias_offset >= 0) ? bias + op->fuse_bias_offset : nullptr;
+    }
+    return check_hip((hipError_t) launch_conv_fp8(a, (hipStream_t) stream), "cpn_conv2d_fp8");
+}
+
 int cpn_maxpool2d(const void *src, void *dst, int32_t N, int32_t Hin, int32_t Win, int32_t C, int32_t k, int32_t stride,
                   int32_t pad, void *stream) {
     if (C % 8) return fail(CPN_E_INVALID, "cpn_maxpool2d: C must be a multiple of 8");

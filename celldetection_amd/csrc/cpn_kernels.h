@@ -42,10 +42,15 @@ struct ConvArgs {
     const float *fuse_b;
     int fuse_cout, fuse_act;
     float fuse_scale;
+    // fp8 (e4m3) variant only (csrc/conv_fp8.hip): activations / weights are e4m3 codes, 64 channels per record;
+    // value = acc * mult[cout] + bias (+ residual code * res_scale); NHWC outputs are stored as e4m3(value * out_inv_scale)
+    const float *mult;
+    float res_scale, out_inv_scale;
 };
 
 // picks a tile configuration and launches; returns hipError_t as int
 int launch_conv(const ConvArgs &a, hipStream_t stream);
+int launch_conv_fp8(const ConvArgs &a, hipStream_t stream);  // e4m3 operands, v_mfma_scale_f32_32x32x64_f8f6f4
 // algorithmic FLOPs actually executed by the MFMA loop of that launch (for utilisation reports)
 double conv_executed_flops(const ConvArgs &a);
 

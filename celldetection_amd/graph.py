@@ -360,28 +360,45 @@ def _fold(sd, op):
     return w, b
 
 
-def _bundle_geometry(cin, cout, groups):
-    """(bundles, cin_b, cout_b, groups_per_bundle) or None when the grouped conv must be densified."""
+def _bundle_geometry(cin, cout, groups, kc=32):
+    """(bundles, cin_b, cout_b, groups_per_bundle) or None when the grouped conv must be densified
+    (kc = channels per weight record: 32 bf16 | 64 fp8)."""
     if groups == 1:
         return None
     cig, cog = cin // groups, cout // groups
     if cig != cog:
         return None
-    bw = cig if cig % 32 == 0 else (32 if 32 % cig == 0 else None)
+    bw = cig if cig % kc == 0 else (kc if kc % cig == 0 else None)
     if bw is None or cin % bw:
         return None
     return cin // bw, bw, bw, bw // cig
 
 
-def pack(plan: Plan, state_dict, device, precision: str = 'bf16'):
+def _pad64(c):
+    return (c + 63) // 64 * 64
+
+
+def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=None):
     """-> (tensor_descs, op_descs, weight_blob[bf16 | f32, device], bias_blob[f32, device]).
 
-    bf16: weights [bundle][cin_b/32][k*k][cout_b][32]; fp32 (verification path): [bundle][k*k][cin_b][cout_b]."""
+    bf16: weights [bundle][cin_b/32][k*k][cout_b][32]; fp32 (verification path): [bundle][k*k][cin_b][cout_b].
+    fp8 (e4m3, groundwork for BASELINE configs[4]): ``act_scales[tensor id]`` = value per activation code; channels
+    are padded to 64; weights [bundle][cin_b/64][k*k (+1 zero slab if odd)][cout_b][64] as e4m3 codes of
+    ``w * input_scale / weight_scale[cout]``; returns additionally (mult_blob[f32] = weight_scale per output channel,
+    [(res_scale, out_inv_scale)] per op); the weight blob is a byte tensor."""
     f32 = precision == 'fp32'
+    fp8 = precision == 'fp8'
+    if fp8 and act_scales is None:
+        raise ValueError('fp8 packing needs the per-tensor activation scales')
+    _pad = _pad64 if fp8 else _pad32
+    KC = 64 if fp8 else 32  # channels per weight record
     wdt, wsz = (torch.float32, 4) if f32 else (torch.bfloat16, 2)
+    if fp8:
+        wsz = 1
+    mparts, op_scales = [], []
     tens = (_lib.TensorDesc * len(plan.tensors))()
     for i, t in enumerate(plan.tensors):
-        tens[i].channels, tens[i].down = _pad32(t['c']), t['down']
+        tens[i].channels, tens[i].down = _pad(t['c']), t['down']
     ops = (_lib.OpDesc * len(plan.ops))()
     wparts, bparts = [], []
     woff = boff = 0
@@ -389,6 +406,7 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16'):
         d = ops[i]
         d.src0 = d.src1 = d.res = d.dst = -1
         d.bias_offset = -1
+        op_scales.append((0., 0.))
         if op['op'] == 'input':
             d.op, d.dst, d.in_channels = _lib.OP_INPUT, op['dst'], op['in_channels']
             continue
@@ -404,11 +422,18 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16'):
         w, b = _fold(state_dict, op)
         k, groups, cin, cout = op['k'], op['groups'], op['cin'], op['cout']
         c0 = plan.tensors[op['src0']]['c']
-        c0p = _pad32(c0)
+        c0p = _pad(c0)
         c1 = plan.tensors[op['src1']]['c'] if op['src1'] is not None else 0
-        cinp = c0p + (_pad32(c1) if op['src1'] is not None else 0)
-        coutp = _pad32(cout)
-        geo = _bundle_geometry(cin, cout, groups)
+        cinp = c0p + (_pad(c1) if op['src1'] is not None else 0)
+        coutp = _pad(cout) if op['dst'] is not None else _pad32(cout)
+        if fp8:  # fold the input scales into the weights: the MFMA then accumulates real-valued units / weight scale
+            w = w.clone()
+            if groups == 1 and c1:
+                w[:, :c0] *= act_scales[op['src0']]
+                w[:, c0:] *= act_scales[op['src1']]
+            else:
+                w *= act_scales[op['src0']]
+        geo = _bundle_geometry(cin, cout, groups, KC)
         if geo is None:
             dense = torch.zeros(coutp, cinp, k, k, dtype=torch.float64)
             if groups == 1:
@@ -421,7 +446,7 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16'):
                     dense[g * cog:(g + 1) * cog, g * cig:(g + 1) * cig] = w[g * cog:(g + 1) * cog]
             bundles, cin_b, cout_b = 1, cinp, coutp
             packed = dense.reshape(1, coutp, cinp, k * k).permute(0, 3, 2, 1) if f32 else \
-                dense.reshape(1, coutp, cinp // 32, 32, k * k).permute(0, 2, 4, 1, 3)
+                dense.reshape(1, coutp, cinp // KC, KC, k * k).permute(0, 2, 4, 1, 3)
             bias = torch.zeros(coutp, dtype=torch.float64)
             bias[:cout] = b
         else:
@@ -432,9 +457,20 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16'):
             for g in range(gpb):
                 dense[:, g * cig:(g + 1) * cig, g * cig:(g + 1) * cig] = wg[:, g]
             packed = dense.reshape(bundles, cout_b, cin_b, k * k).permute(0, 3, 2, 1) if f32 else \
-                dense.reshape(bundles, cout_b, cin_b // 32, 32, k * k).permute(0, 2, 4, 1, 3)
+                dense.reshape(bundles, cout_b, cin_b // KC, KC, k * k).permute(0, 2, 4, 1, 3)
             bias = b.clone()
-        wparts.append(packed.contiguous().reshape(-1).to(wdt))
+        if fp8:
+            packed = packed.contiguous().reshape(bundles, -1, cout_b, KC)  # [bundle][item][cout][64]
+            wscale = (packed.abs().amax((1, 3)) / 448.).clamp_min(1e-30)      # [bundle][cout]
+            codes = (packed / wscale[:, None, :, None]).to(torch.float32).to(torch.float8_e4m3fn).view(torch.uint8)
+            if codes.shape[1] % 2:  # the kernel's pipeline step holds two items
+                codes = torch.cat((codes, torch.zeros_like(codes[:, :1])), 1)
+            wparts.append(codes.contiguous().reshape(-1))
+            mparts.append(wscale.reshape(-1).to(torch.float32))
+            op_scales[-1] = (float(act_scales[op['res']]) if op['res'] is not None else 0.,
+                             1. / float(act_scales[op['dst']]) if op['dst'] is not None else 0.)
+        else:
+            wparts.append(packed.contiguous().reshape(-1).to(wdt))
         bparts.append(bias.to(torch.float32))
         d.op = _lib.OP_CONV
         d.src0 = op['src0']
@@ -455,9 +491,9 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16'):
         woff += wparts[-1].numel() * wsz
         boff += bparts[-1].numel()
         # keep blob offsets 16-byte aligned
-        padw = (-wparts[-1].numel()) % 8
+        padw = (-wparts[-1].numel()) % (16 if fp8 else 8)
         if padw:
-            wparts.append(torch.zeros(padw, dtype=wdt))
+            wparts.append(torch.zeros(padw, dtype=torch.uint8 if fp8 else wdt))
             woff += padw * wsz
         if op.get('fuse'):
             assert not f32, 'fused heads are a bf16-only feature'
@@ -468,8 +504,10 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16'):
             W2[:fz['cout'], :cout] = w2
             B2 = torch.zeros(32, dtype=torch.float64)
             B2[:fz['cout']] = b2
-            wparts.append(W2.reshape(-1).to(torch.bfloat16))
+            wparts.append(W2.reshape(-1).to(torch.bfloat16).view(torch.uint8) if fp8 else W2.reshape(-1).to(torch.bfloat16))
             bparts.append(B2.to(torch.float32))
+            if fp8:
+                mparts.append(torch.ones(32, dtype=torch.float32))  # keeps mult/bias indices aligned
             d.fuse_weight_offset, d.fuse_bias_offset = woff, boff
             d.fuse_cout, d.fuse_act, d.fuse_act_scale = fz['cout'], _ACT[fz['act']], float(fz['act_scale'])
             d.cout_real = fz['cout']
@@ -477,6 +515,8 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16'):
             boff += bparts[-1].numel()
     wblob = torch.cat(wparts).to(device)
     bblob = torch.cat(bparts).to(device)
+    if fp8:
+        return tens, ops, wblob, bblob, torch.cat(mparts).to(device), op_scales
     return tens, ops, wblob, bblob
 
 

@@ -116,6 +116,15 @@ int cpn_plan_run_timed(cpn_plan *plan, const void *input, int32_t in_dtype, int3
 int cpn_conv2d(const cpn_op_desc *op, const void *src0, int32_t c0_stride, const void *src1, int32_t c1_stride,
                const void *res, int32_t res_stride, void *dst, int32_t dst_stride, int32_t N, int32_t Hin, int32_t Win,
                const void *weights, const float *bias, void *stream);
+/* fp8 (OCP e4m3) variant of cpn_conv2d on v_mfma_scale_f32_32x32x64_f8f6f4 (BASELINE.json configs[4] groundwork; no
+ * reference counterpart): activations and residual are e4m3 codes (NHWC, channel strides multiples of 64, value =
+ * code * tensor scale), weights are e4m3 codes packed [bundle][cin/64][kh*kw (+1 zero slab when the item count is
+ * odd)][cout][64] with the input-tensor scale folded in before quantisation; value = acc * mult[cout] + bias
+ * (+ residual code * res_scale) -> act -> e4m3(value * out_inv_scale) (NHWC outputs) or the fp32 head outputs. */
+int cpn_conv2d_fp8(const cpn_op_desc *op, const void *src0, int32_t c0_stride, const void *src1, int32_t c1_stride,
+                   const void *res, int32_t res_stride, void *dst, int32_t dst_stride, int32_t N, int32_t Hin,
+                   int32_t Win, const void *weights, const float *bias, const float *mult, float res_scale,
+                   float out_inv_scale, void *stream);
 int cpn_maxpool2d(const void *src, void *dst, int32_t N, int32_t Hin, int32_t Win, int32_t C, int32_t k, int32_t stride,
                   int32_t pad, void *stream);
 int cpn_resize_bilinear(const void *src, void *dst, int32_t N, int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout,

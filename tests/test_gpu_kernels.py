@@ -343,3 +343,143 @@ def test_box_voting_vs_oracle(dev):
         gv[keep.cpu().numpy()] = votes.cpu().numpy()
         np.testing.assert_allclose(gv[both], all_votes[both], rtol=1e-5, atol=1e-5)
     assert ops.filter_by_box_voting(boxes[:0].to(dev), .2, 1.).numel() == 0
+
+
+# ---- fp8 (e4m3) conv kernel: v_mfma_scale_f32_32x32x64_f8f6f4 ---------------------------------------------------------
+def _to_nhwc_fp8(x, scale, cpad):
+    """NCHW fp32 -> (NHWC e4m3 codes as uint8 with zero-padded channels, dequantised NCHW fp32)."""
+    n, c, h, w = x.shape
+    q = (x / scale).clamp(-448, 448).to(torch.float8_e4m3fn)
+    out = torch.zeros(n, h, w, cpad, dtype=torch.uint8, device=x.device)
+    out[..., :c] = q.view(torch.uint8).permute(0, 2, 3, 1)
+    return out.contiguous(), q.float() * scale
+
+
+FP8_CASES = {
+    '3x3_64_64': dict(n=2, h=32, w=32, cin=64, cout=64, k=3),
+    '1x1_128_256': dict(n=2, h=32, w=32, cin=128, cout=256, k=1),
+    '1x1_odd_chunks_res': dict(n=1, h=32, w=64, cin=192, cout=128, k=1, res=True),
+    '3x3_odd_channels': dict(n=1, h=32, w=64, cin=24, cout=40, k=3),
+    '3x3_s2': dict(n=2, h=64, w=64, cin=64, cout=128, k=3, stride=2),
+    '7x7_256_big_tile': dict(n=1, h=64, w=64, cin=128, cout=256, k=7),
+    '3x3_concat_up': dict(n=2, h=32, w=32, cin=64, cout=64, k=3, cin1=128, up1=True),
+    '3x3_grouped_cpg8': dict(n=1, h=32, w=32, cin=256, cout=256, k=3, groups=32),
+    '7x7_stem_s2': dict(n=2, h=64, w=64, cin=3, cout=64, k=7, stride=2, bias=False),
+    'final_f32': dict(n=1, h=32, w=32, cin=128, cout=20, k=1, bn=False, act='none', out_f32=True),
+    'fused_head_64': dict(n=1, h=32, w=64, cin=64, cout=64, k=7, fuse_cout=20, fuse_act='none'),
+}
+
+
+@pytest.mark.parametrize('name', list(FP8_CASES))
+def test_conv_fp8_vs_dequantised_reference(dev, name):
+    """fp8 conv kernel vs an fp32 PyTorch conv on the SAME e4m3-quantised operands (products of e4m3 values are exact
+    in fp32, so only the summation order and the output rounding differ): fp32 outputs to 2e-3 of the output range,
+    e4m3 outputs within one code step (2^-3 relative) + the subnormal step."""
+    from celldetection_amd import _lib, graph
+    cfg = dict(FP8_CASES[name])
+    n, h, w, cin, cout, k = (cfg[x] for x in ('n', 'h', 'w', 'cin', 'cout', 'k'))
+    stride, groups, cin1, up1 = cfg.get('stride', 1), cfg.get('groups', 1), cfg.get('cin1', 0), cfg.get('up1', False)
+    res, act, out_f32, fuse_cout = cfg.get('res', False), cfg.get('act', 'relu'), cfg.get('out_f32', False), \
+        cfg.get('fuse_cout', 0)
+    g = torch.Generator().manual_seed(11)
+    P = graph.Plan()
+    s0 = P.tensor(cin, 1)
+    s1 = P.tensor(cin1, 2 if up1 else 1) if cin1 else None
+    r = P.tensor(cout, stride) if res else None
+    P.conv(s0, cout, k, w='c.', bn='b.' if cfg.get('bn', True) else None, bias=cfg.get('bias', True), stride=stride,
+           groups=groups, act=act, src1=s1, up1=up1, res=r,
+           out_index=_lib.OUT_SCORES if (out_f32 or fuse_cout) else None,
+           fuse=dict(w='f.', cout=fuse_cout, act=cfg.get('fuse_act', 'none'), act_scale=3.) if fuse_cout else None)
+    out_f32 = out_f32 or bool(fuse_cout)
+    sd = {}
+    for key, shape, kind in P.entries:
+        if key.endswith('running_var'):
+            sd[key] = torch.rand(shape, generator=g) + .5
+        elif key.endswith('num_batches_tracked'):
+            sd[key] = torch.zeros((), dtype=torch.long)
+        elif len(shape) == 4:
+            sd[key] = torch.randn(shape, generator=g) / np.sqrt(np.prod(shape[1:]))
+        else:
+            sd[key] = torch.randn(shape, generator=g) * .5 + (1. if key.endswith('b.weight') else 0.)
+    x0 = torch.randn(n, cin, h, w, generator=g)
+    x1 = torch.randn(n, cin1, h // 2 if up1 else h, w // 2 if up1 else w, generator=g) * 2 if cin1 else None
+    ho, wo = (h + 2 * (k // 2) - k) // stride + 1, (w + 2 * (k // 2) - k) // stride + 1
+    xr = torch.randn(n, cout, ho, wo, generator=g) if res else None
+    p64 = lambda c: (c + 63) // 64 * 64
+    scales = {s0: float(x0.abs().max()) / 448}
+    if cin1:
+        scales[s1] = float(x1.abs().max()) / 448
+    if res:
+        scales[r] = float(xr.abs().max()) / 448
+    d0, x0q = _to_nhwc_fp8(x0.to(dev), scales[s0], p64(cin))
+    d1, x1q = _to_nhwc_fp8(x1.to(dev), scales[s1], p64(cin1)) if cin1 else (None, None)
+    dr, xrq = _to_nhwc_fp8(xr.to(dev), scales[r], p64(cout)) if res else (None, None)
+    # reference on the dequantised operands; the weight codes come from the packer (dequantised through mult)
+    wf, bf = graph._fold(sd, P.ops[0])
+    xin = x0q.cpu()
+    if cin1:
+        xin = torch.cat((xin, F.interpolate(x1q.cpu(), scale_factor=2, mode='nearest') if up1 else x1q.cpu()), 1)
+    # output scale from an fp32 dry run
+    ref_full = F.conv2d(xin, wf.float(), bf.float(), stride, k // 2, 1, groups)
+    if res:
+        ref_full = ref_full + xrq.cpu()
+    if act == 'relu':
+        ref_full = F.relu(ref_full)
+    dst_id = P.ops[0]['dst']
+    if dst_id is not None:
+        scales[dst_id] = float(ref_full.abs().max()) / 448
+    tens, ops, wblob, bblob, mblob, op_scales = graph.pack(P, sd, dev, precision='fp8', act_scales=scales)
+    op = ops[0]
+    lib = _lib.load()
+    if out_f32:
+        dst = torch.full((n, fuse_cout or cout, ho, wo), float('nan'), dtype=torch.float32, device=dev)
+        dstride = 0
+    else:
+        dst = torch.full((n, ho, wo, p64(cout)), 0x7f, dtype=torch.uint8, device=dev)
+        dstride = p64(cout)
+    _lib.check(lib.cpn_conv2d_fp8(op, _lib.ptr(d0), d0.shape[-1], _lib.ptr(d1), 0 if d1 is None else d1.shape[-1],
+                                  _lib.ptr(dr), 0 if dr is None else dr.shape[-1], _lib.ptr(dst), dstride, n, h, w,
+                                  _lib.ptr(wblob), _lib.ptr(bblob), _lib.ptr(mblob), op_scales[0][0], op_scales[0][1],
+                                  _lib.stream_ptr()), 'conv2d_fp8')
+    torch.cuda.synchronize()
+    # dequantised weights exactly as the kernel sees them: e4m3(w * s_in / s_w) * s_w / s_in
+    cig = (cin + cin1) // groups
+    wq = torch.empty_like(wf)
+    for co in range(cout):
+        row = wf[co].clone()
+        if cin1:
+            row[:cin] *= scales[s0]
+            row[cin:] *= scales[s1]
+        else:
+            row *= scales[s0]
+        sw = max(float(row.abs().max()) / 448., 1e-30)
+        # per-(bundle, cout) scale = max over the whole packed row, which equals the row max here
+        rq = (row / sw).float().to(torch.float8_e4m3fn).float() * sw
+        if cin1:
+            rq[:cin] /= scales[s0]
+            rq[cin:] /= scales[s1]
+        else:
+            rq /= scales[s0]
+        wq[co] = rq
+    ref = F.conv2d(xin.double(), wq.double(), bf.double(), stride, k // 2, 1, groups).float()
+    if res:
+        ref = ref + xrq.cpu()
+    if act == 'relu':
+        ref = F.relu(ref)
+    if fuse_cout:
+        w2 = sd['f.weight'].to(torch.bfloat16).float()
+        ref = F.conv2d(ref.to(torch.bfloat16).float(), w2, sd['f.bias'])
+    if out_f32:
+        got = dst.cpu()
+        tol = (5e-2 if fuse_cout else 2e-3) * float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= tol, (name, float((got - ref).abs().max()), tol)
+    else:
+        codes = dst.cpu()[..., :cout].permute(0, 3, 1, 2).contiguous()
+        got = codes.view(torch.float8_e4m3fn).float() * scales[dst_id]
+        assert not bool(torch.isnan(got).any()), name
+        err = (got - ref).abs()
+        bound = ref.abs() * 0.0725 + scales[dst_id] * 2 ** -9 * 1.01  # half a code step (RNE) + margin, subnormal step
+        bad = float((err > bound).float().mean())
+        assert bad <= 1e-3, (name, bad, float(err.max()))
+        if p64(cout) > cout:  # padded output channels must be exact zeros
+            assert int(dst.cpu()[..., cout:].max()) in (0, 0x80) or int(dst.cpu()[..., cout:].max()) == 0
