@@ -82,6 +82,9 @@ def main():
     ap.add_argument('--tile', type=int, default=512)
     ap.add_argument('--model', default='CpnResNeXt101UNet')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp8'],
+                    help="conv-graph precision; 'fp8' (e4m3, K=64 scaled MFMA) is BASELINE.json configs[4] groundwork, "
+                         'the headline metric is quoted on bf16')
     ap.add_argument('--pipeline', action='store_true',
                     help='two-stream throughput mode (CPN.forward_pipelined); default: synchronous forward() per step')
     ap.add_argument('--profile-layers', action='store_true', help='print per-op timings to stderr')
@@ -101,6 +104,9 @@ def main():
     model, sd = build_model(args.model, dev, tile=args.tile)
     g = torch.Generator().manual_seed(100 + rank)
     x = torch.rand(args.batch, 3, args.tile, args.tile, generator=g).to(dev)  # resident in HBM before timing
+    if args.precision == 'fp8':
+        model.precision = 'fp8'
+        model.calibrate_fp8(x[:2])  # static activation scales from a bf16 run on two tiles
 
     state = {}
 
@@ -175,17 +181,18 @@ def main():
         achieved = gf * args.batch / conv_ms  # GFLOP / ms = TFLOP/s
         ndet = sum(len(s) for s in y['scores'])
         out = {
-            'metric': 'tiles/sec (3x512x512) CpnResNeXt101UNet', 'value': value, 'unit': 'tiles/s', 'n_gpus': world,
+            'metric': f'tiles/sec (3x{args.tile}x{args.tile}) {args.model}', 'value': value, 'unit': 'tiles/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
             'config': {'workload': f'{args.model} full CPN path, batch {args.batch} x 3x{args.tile}x{args.tile} per GPU '
                                    f'(BASELINE.json configs[2]), synthetic ginoro-shaped weights',
                        'tiles_per_gpu_per_step': args.batch, 'detections_last_step': ndet,
                        'parallelism': f'tile-sharded x{world}, no data-path collective',
                        'step_mode': 'forward() per step' if not args.pipeline else
                        'forward_pipelined(): post-processing of step i overlaps the conv graph of step i+1'},
-            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_BF16_TFLOPS,
+            'roofline': {'bound': 'mfma', 'achieved': achieved,
+                         'peak': PEAK_BF16_TFLOPS * (2 if args.precision == 'fp8' else 1), 'unit': 'TFLOP/s',
+                         'frac': achieved / (PEAK_BF16_TFLOPS * (2 if args.precision == 'fp8' else 1)),
                          'traffic': TRAFFIC_BYTES_PER_GRAPH_B16 if (args.model == 'CpnResNeXt101UNet' and args.batch == 16
                                                                     and args.tile == 512) else None,
                          'kernel': 'conv_igemm_kernel: one conv-graph execution = 126 convs in 122 launches of the kernel '

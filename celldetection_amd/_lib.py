@@ -10,8 +10,8 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CPN_HIP_LIB') or os.path.join(HERE, 'libcpn_hip.so')  # env: kernel A/B tuning only
 
-ABI_VERSION = 4
-PRECISION_BF16, PRECISION_F32 = 0, 1
+ABI_VERSION = 5
+PRECISION_BF16, PRECISION_F32, PRECISION_FP8 = 0, 1, 2
 
 OP_INPUT, OP_CONV, OP_MAXPOOL, OP_BILINEAR = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH_SCALED = 0, 1, 2, 3
@@ -20,7 +20,7 @@ NUM_OUTPUTS = 5
 
 
 class TensorDesc(Structure):
-    _fields_ = [('channels', c_int32), ('down', c_int32)]
+    _fields_ = [('channels', c_int32), ('down', c_int32), ('scale', c_float)]
 
 
 class OpDesc(Structure):
@@ -32,7 +32,7 @@ class OpDesc(Structure):
                 ('act', c_int32), ('act_scale', c_float), ('out_index', c_int32), ('cout_real', c_int32),
                 ('dst_coff', c_int32), ('in_channels', c_int32),
                 ('fuse_weight_offset', c_int64), ('fuse_bias_offset', c_int64), ('fuse_cout', c_int32),
-                ('fuse_act', c_int32), ('fuse_act_scale', c_float), ('reserved_', c_int32)]
+                ('fuse_act', c_int32), ('fuse_act_scale', c_float), ('mult_offset', c_int32)]
 
 
 # every symbol include/cpn_hip.h declares: (name, restype, argtypes)
@@ -46,6 +46,8 @@ _SIGNATURES = [
     ('cpn_plan_executed_flops', c_double, [c_void_p, c_int32, c_int32, c_int32]),
     ('cpn_plan_run', ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64,
                                     POINTER(c_void_p), c_void_p, c_void_p]),
+    ('cpn_plan_run_stats', ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64,
+                                          POINTER(c_void_p), c_void_p, c_void_p, c_void_p]),
     ('cpn_plan_num_ops', ctypes.c_int, [c_void_p]),
     ('cpn_plan_run_timed', ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64,
                                           POINTER(c_void_p), c_void_p, c_void_p, POINTER(c_float), POINTER(c_double)]),

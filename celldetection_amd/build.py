@@ -19,6 +19,7 @@ SOURCES = {
     'conv_igemm.hip': [],
     'conv_fp8.hip': [],  # the same source with CPN_FP8 = 1 (e4m3 operands)
     'misc_kernels.hip': [],
+    'misc_fp8.hip': [],
     'conv_f32.hip': [],
     # decode/NMS must reproduce the reference's fp32 operation order bit-for-bit: no FMA contraction
     'decode_nms.hip': ['-ffp-contract=off'],

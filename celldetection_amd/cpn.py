@@ -62,16 +62,20 @@ def _register(root: nn.Module, key: str, shape, kind: str):
 class _Engine:
     """Packed weights + native plan for one device."""
 
-    def __init__(self, plan: graph.Plan, state_dict, device, precision: str = 'bf16'):
+    def __init__(self, plan: graph.Plan, state_dict, device, precision: str = 'bf16', act_scales=None):
         lib = _lib.load()
         self.device = device
         self.precision = precision
-        self.tens, self.ops_desc, self.wblob, self.bblob = graph.pack(plan, state_dict, device, precision)
+        if precision == 'fp8':
+            self.tens, self.ops_desc, self.wblob, self.bblob, _, _ = graph.pack(plan, state_dict, device, 'fp8',
+                                                                               act_scales=act_scales)
+        else:
+            self.tens, self.ops_desc, self.wblob, self.bblob = graph.pack(plan, state_dict, device, precision)
         handle = c_void_p()
+        code = dict(bf16=_lib.PRECISION_BF16, fp32=_lib.PRECISION_F32, fp8=_lib.PRECISION_FP8)[precision]
         _lib.check(lib.cpn_plan_create(handle, self.tens, len(self.tens), self.ops_desc, len(self.ops_desc),
                                        _lib.ptr(self.wblob), self.wblob.numel() * self.wblob.element_size(),
-                                       _lib.ptr(self.bblob), self.bblob.numel(),
-                                       _lib.PRECISION_F32 if precision == 'fp32' else _lib.PRECISION_BF16), 'plan_create')
+                                       _lib.ptr(self.bblob), self.bblob.numel(), code), 'plan_create')
         self.handle = handle
         self.plan = plan
         self._ws = None
@@ -110,7 +114,13 @@ class _Engine:
                             stride=op.get('stride')))
         return out
 
-    def run(self, x: torch.Tensor, order_total: int, refinement: bool, _timed=None):
+    def activation_absmax(self, x: torch.Tensor, order_total: int, refinement: bool):
+        """Calibration run (bf16 plans): max |value| of every activation tensor of the graph for the batch ``x``."""
+        absmax = torch.zeros(len(self.tens), dtype=torch.float32, device=self.device)
+        self.run(x, order_total, refinement, _absmax=absmax)
+        return absmax.cpu()
+
+    def run(self, x: torch.Tensor, order_total: int, refinement: bool, _timed=None, _absmax=None):
         """x: [N,C,H,W] float32 in [0,1] (or uint8) on self.device -> (scores, locations, refinement, fourier, flag)."""
         lib = _lib.load()
         n, c, h, w = x.shape
@@ -136,7 +146,10 @@ class _Engine:
         outs = (c_void_p * _lib.NUM_OUTPUTS)(scores.data_ptr(), locations.data_ptr(), fourier.data_ptr(),
                                              0 if ref is None else ref.data_ptr(),
                                              0 if self.last_uncertainty is None else self.last_uncertainty.data_ptr())
-        if _timed is not None:
+        if _absmax is not None:
+            _lib.check(lib.cpn_plan_run_stats(self.handle, _lib.ptr(x), dt, n, h, w, _lib.ptr(ws), need, outs,
+                                              _lib.ptr(flag), _lib.ptr(_absmax), _lib.stream_ptr()), 'plan_run_stats')
+        elif _timed is not None:
             _lib.check(lib.cpn_plan_run_timed(self.handle, _lib.ptr(x), dt, n, h, w, _lib.ptr(ws), need, outs,
                                               _lib.ptr(flag), _lib.stream_ptr(), _timed[0], _timed[1]), 'plan_run_timed')
         else:
@@ -193,7 +206,11 @@ class CPN(nn.Module):
                                  contour_head_channels=kwargs.get('contour_head_channels'),
                                  refinement_head_channels=kwargs.get('refinement_head_channels'),
                                  kernel_sizes=kernel_sizes)
-        self.precision = 'bf16'  # 'bf16' (MFMA performance path) | 'fp32' (verification path, ~100x slower)
+        # 'bf16' (MFMA performance path) | 'fp32' (verification path, ~100x slower) | 'fp8' (e4m3 activations and
+        # weights on the K=64 scaled MFMA, 2x the bf16 rate; static activation scales from ``calibrate_fp8`` or, if
+        # that was not called, from the first batch that is forwarded)
+        self.precision = 'bf16'
+        self._fp8_scales = None
         self._plan = graph.build_plan(**self._plan_kwargs)
         for key, shape, kind in self._plan.entries:
             _register(self, key, shape, kind)
@@ -214,6 +231,7 @@ class CPN(nn.Module):
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         self._engine = None  # weights change -> repack on next forward
+        self._fp8_scales = None
         return super().load_state_dict(state_dict, strict=strict, **kw)
 
     def repack(self):
@@ -229,17 +247,36 @@ class CPN(nn.Module):
             raise NotImplementedError('celldetection_amd.CPN is an inference engine; training is out of scope.')
         return super().train(False)
 
-    def engine(self, device=None) -> _Engine:
+    def engine(self, device=None, calibration_input=None) -> _Engine:
         device = torch.device(device) if device is not None else self.order_weights_device()
         if device.type != 'cuda':
             raise RuntimeError('celldetection_amd runs on the MI355X (HIP) only: move the model and inputs to a GPU. '
                                'There is no CPU fallback in the product path.')
-        if self.precision not in ('bf16', 'fp32'):
-            raise ValueError("precision must be 'bf16' or 'fp32'")
+        if self.precision not in ('bf16', 'fp32', 'fp8'):
+            raise ValueError("precision must be 'bf16', 'fp32' or 'fp8'")
         if self._engine is None or self._engine.device != device or self._engine.precision != self.precision:
-            plan = self._plan if self.precision == 'bf16' else graph.build_plan(**self._plan_kwargs, fuse_readout=False)
-            self._engine = _Engine(plan, self.state_dict(), device, self.precision)
+            if self.precision == 'fp8':
+                if self._fp8_scales is None:
+                    if calibration_input is None:
+                        raise RuntimeError("precision 'fp8' needs activation scales: call calibrate_fp8(batch) first")
+                    self.calibrate_fp8(calibration_input)
+                self._engine = _Engine(self._plan, self.state_dict(), device, 'fp8', act_scales=self._fp8_scales)
+            else:
+                plan = self._plan if self.precision == 'bf16' else graph.build_plan(**self._plan_kwargs,
+                                                                                   fuse_readout=False)
+                self._engine = _Engine(plan, self.state_dict(), device, self.precision)
         return self._engine
+
+    @torch.no_grad()
+    def calibrate_fp8(self, inputs: torch.Tensor):
+        """Static e4m3 activation scales (one per tensor of the conv graph) from ONE bf16 run on ``inputs``:
+        scale = max|x| / 448.  Weight scales are per output channel and need no data."""
+        eng = _Engine(self._plan, self.state_dict(), inputs.device, 'bf16')
+        absmax = eng.activation_absmax(inputs, self.core.order, self.refinement)
+        self._fp8_scales = [max(float(v), 1e-12) / 448. for v in absmax.tolist()]
+        if self._engine is not None and self._engine.precision == 'fp8':
+            self._engine = None
+        return self._fp8_scales
 
     def order_weights_device(self):
         return next(self.parameters()).device
@@ -248,7 +285,7 @@ class CPN(nn.Module):
     @torch.no_grad()
     def core_forward(self, inputs: torch.Tensor):
         """CPNCore.forward (cpn.py:238-283) -> (scores(sigmoid applied), locations, refinement, fourier)."""
-        eng = self.engine(inputs.device)
+        eng = self.engine(inputs.device, calibration_input=inputs)
         scores, locations, refinement, fourier, flag = eng.run(inputs, self.core.order, self.refinement)
         self._last_flag = flag
         self._last_uncertainty = eng.last_uncertainty  # fifth CPNCore output (cpn.py:283), [N,4,h,w] or None

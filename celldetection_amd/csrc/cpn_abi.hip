@@ -44,7 +44,7 @@ struct cpn_plan {
     size_t weight_bytes = 0;
     const float *bias = nullptr;
     size_t bias_count = 0;
-    int precision = 0;  // CPN_PRECISION_BF16 / CPN_PRECISION_F32
+    int precision = 0;  // CPN_PRECISION_BF16 / CPN_PRECISION_F32 / CPN_PRECISION_FP8
     std::map<std::tuple<int, int, int>, cpn::ShapePlan> shape_plans;
 };
 
@@ -76,7 +76,7 @@ static const ShapePlan &get_shape_plan(cpn_plan *p, int N, int H, int W) {
     std::sort(order.begin(), order.end(), [&](int a, int b) { return def[a] < def[b]; });
     std::vector<int> placed;
     for (int t : order) {
-        const int elem = p->precision == CPN_PRECISION_F32 ? 4 : 2;
+        const int elem = p->precision == CPN_PRECISION_F32 ? 4 : (p->precision == CPN_PRECISION_FP8 ? 1 : 2);
         const int64_t sz = tensor_bytes(p->tensors[t], N, H, W, elem);
         // candidate offsets: 0 and the end of every conflicting placed tensor; take the lowest that fits
         std::vector<std::pair<int64_t, int64_t>> busy;  // [begin, end) of live-overlapping tensors
@@ -125,8 +125,14 @@ static int build_conv_args(const cpn_plan *p, const cpn_op_desc &o, int N, int H
     }
     a.dst = dst; a.dst_stride = ds; a.dst_coff = o.dst_coff;
     a.cout_real = o.cout_real;
-    if (o.cin_b <= 0 || o.cin_b % 32 || o.cout_b <= 0 || o.cout_b % 32 || o.c0_used % 32 || o.bundles < 1)
-        return fail(CPN_E_INVALID, "conv: channel counts must be positive multiples of 32");
+    const int kc = (p && p->precision == CPN_PRECISION_FP8) ? 64 : 32;  // input channels per packed weight record
+    if (o.cin_b <= 0 || o.cin_b % kc || o.cout_b <= 0 || o.cout_b % 32 || o.c0_used % kc || o.bundles < 1)
+        return fail(CPN_E_INVALID, "conv: channel counts must be positive multiples of 32 (64 input channels for fp8)");
+    if (p && p->precision == CPN_PRECISION_FP8) {
+        a.mult = o.mult_offset >= 0 ? p->bias + o.mult_offset : nullptr;
+        a.res_scale = o.res >= 0 ? p->tensors[o.res].scale : 0.f;
+        a.out_inv_scale = o.dst >= 0 ? 1.f / p->tensors[o.dst].scale : 0.f;
+    }
     if (o.bundles > 1 && s1) return fail(CPN_E_INVALID, "conv: grouped conv with two sources");
     if (!s1 && o.c0_used < o.bundles * o.cin_b) return fail(CPN_E_INVALID, "conv: c0_used smaller than input channels");
     if ((int64_t) N * Hin * Win * std::max(c0s, c1s) >= (1ll << 31) || (int64_t) N * a.Hout * a.Wout * std::max(ds, 1) >= (1ll << 31))
@@ -155,7 +161,7 @@ int cpn_abi_version(void) { return CPN_ABI_VERSION; }
 int cpn_plan_create(cpn_plan **plan, const cpn_tensor_desc *tensors, int32_t n_tensors, const cpn_op_desc *ops,
                     int32_t n_ops, const void *weights, size_t weight_bytes, const float *bias, size_t bias_count,
                     int32_t precision) {
-    if (precision != CPN_PRECISION_BF16 && precision != CPN_PRECISION_F32)
+    if (precision != CPN_PRECISION_BF16 && precision != CPN_PRECISION_F32 && precision != CPN_PRECISION_FP8)
         return fail(CPN_E_INVALID, "cpn_plan_create: unknown precision");
     if (!plan || !tensors || !ops || n_tensors <= 0 || n_ops <= 0) return fail(CPN_E_INVALID, "cpn_plan_create: null/empty");
     cpn_plan *p = new cpn_plan();
@@ -167,9 +173,11 @@ int cpn_plan_create(cpn_plan **plan, const cpn_tensor_desc *tensors, int32_t n_t
     p->bias_count = bias_count;
     p->precision = precision;
     for (const auto &t : p->tensors)
-        if (t.channels <= 0 || t.channels % 32 || t.down < 1 || (t.down & (t.down - 1)) || t.down > 32) {
+        if (t.channels <= 0 || t.channels % (precision == CPN_PRECISION_FP8 ? 64 : 32) || t.down < 1 ||
+            (t.down & (t.down - 1)) || t.down > 32 || (precision == CPN_PRECISION_FP8 && !(t.scale > 0.f))) {
             delete p;
-            return fail(CPN_E_INVALID, "cpn_plan_create: tensor channels must be multiples of 32, down a power of two <= 32");
+            return fail(CPN_E_INVALID, "cpn_plan_create: tensor channels must be multiples of 32 (fp8: 64, with a "
+                                       "positive scale), down a power of two <= 32");
         }
     for (const auto &o : p->ops) {
         for (int s : {o.src0, o.src1, o.res, o.dst})
@@ -178,7 +186,15 @@ int cpn_plan_create(cpn_plan **plan, const cpn_tensor_desc *tensors, int32_t n_t
                 return fail(CPN_E_INVALID, "cpn_plan_create: tensor id out of range");
             }
         if (o.op == CPN_OP_CONV) {
-            const size_t wbytes = (size_t) o.bundles * o.cin_b * o.kh * o.kw * o.cout_b * (precision == CPN_PRECISION_F32 ? 4 : 2);
+            size_t wbytes = (size_t) o.bundles * o.cin_b * o.kh * o.kw * o.cout_b * (precision == CPN_PRECISION_F32 ? 4 : 2);
+            if (precision == CPN_PRECISION_FP8) {  // [bundle][items (+1 zero slab if odd)][cout_b][64] bytes
+                const size_t items = (size_t) (o.cin_b / 64) * o.kh * o.kw;
+                wbytes = (size_t) o.bundles * (items + (items & 1)) * o.cout_b * 64;
+                if (o.cin_b % 64 || (o.mult_offset >= 0 && (size_t) o.mult_offset + (size_t) o.bundles * o.cout_b > bias_count)) {
+                    delete p;
+                    return fail(CPN_E_INVALID, "cpn_plan_create: fp8 conv needs cin_b % 64 == 0 and a valid mult_offset");
+                }
+            }
             if (precision == CPN_PRECISION_F32 && o.fuse_cout > 0) {
                 delete p;
                 return fail(CPN_E_INVALID, "cpn_plan_create: fused heads are a bf16-only feature");
@@ -206,12 +222,14 @@ int64_t cpn_plan_workspace_bytes(cpn_plan *plan, int32_t N, int32_t H, int32_t W
 
 static int run_or_count(cpn_plan *plan, const void *input, int32_t in_dtype, int32_t N, int32_t H, int32_t W,
                         void *workspace, int64_t workspace_bytes, float *const *outputs, int32_t *range_flag,
-                        hipStream_t st, double *flops, hipEvent_t *events = nullptr, double *op_flops = nullptr) {
+                        hipStream_t st, double *flops, hipEvent_t *events = nullptr, double *op_flops = nullptr,
+                        float *absmax = nullptr) {
     if (!plan || N <= 0 || H <= 0 || W <= 0 || H % 32 || W % 32)
         return fail(CPN_E_INVALID, "cpn_plan_run: H and W must be positive multiples of 32");
     const ShapePlan &sp = get_shape_plan(plan, N, H, W);
     if (!flops && sp.total > workspace_bytes) return fail(CPN_E_WORKSPACE, "cpn_plan_run: workspace too small");
-    const bool f32 = plan->precision == CPN_PRECISION_F32;
+    const bool f32 = plan->precision == CPN_PRECISION_F32, fp8 = plan->precision == CPN_PRECISION_FP8;
+    if (absmax && plan->precision != CPN_PRECISION_BF16) return fail(CPN_E_INVALID, "cpn_plan_run_stats: bf16 plans only");
     char *ws = (char *) workspace;
     auto tptr = [&](int t) -> void * { return t >= 0 ? (void *) (ws + sp.offsets[t]) : nullptr; };
     auto tch = [&](int t) -> int { return t >= 0 ? plan->tensors[t].channels : 0; };
@@ -223,21 +241,25 @@ static int run_or_count(cpn_plan *plan, const void *input, int32_t in_dtype, int
             case CPN_OP_INPUT: {
                 if (flops) break;
                 InputArgs a{input, tptr(o.dst), N, o.in_channels, H, W, tch(o.dst), in_dtype, range_flag};
-                rc = check_hip((hipError_t) (f32 ? launch_input_f32(a, st) : launch_input(a, st)), "input kernel");
+                rc = check_hip((hipError_t) (f32 ? launch_input_f32(a, st)
+                                                 : fp8 ? launch_input_fp8(a, 1.f / plan->tensors[o.dst].scale, st)
+                                                       : launch_input(a, st)), "input kernel");
                 break;
             }
             case CPN_OP_MAXPOOL: {
                 if (flops) break;
                 const int din = plan->tensors[o.src0].down, dout = plan->tensors[o.dst].down;
                 PoolArgs a{tptr(o.src0), tptr(o.dst), N, H / din, W / din, H / dout, W / dout, tch(o.src0), o.kh, o.stride, o.pad};
-                rc = check_hip((hipError_t) (f32 ? launch_maxpool_f32(a, st) : launch_maxpool(a, st)), "maxpool kernel");
+                rc = check_hip((hipError_t) (f32 ? launch_maxpool_f32(a, st) : fp8 ? launch_maxpool_fp8(a, st)
+                                                                                  : launch_maxpool(a, st)), "maxpool kernel");
                 break;
             }
             case CPN_OP_BILINEAR: {
                 if (flops) break;
                 const int din = plan->tensors[o.src0].down, dout = plan->tensors[o.dst].down;
                 ResizeArgs a{tptr(o.src0), tptr(o.dst), N, H / din, W / din, H / dout, W / dout, tch(o.src0)};
-                rc = check_hip((hipError_t) (f32 ? launch_bilinear_f32(a, st) : launch_bilinear(a, st)), "bilinear kernel");
+                rc = check_hip((hipError_t) (f32 ? launch_bilinear_f32(a, st) : fp8 ? launch_bilinear_fp8(a, st)
+                                                                                   : launch_bilinear(a, st)), "bilinear kernel");
                 break;
             }
             case CPN_OP_CONV: {
@@ -256,12 +278,19 @@ static int run_or_count(cpn_plan *plan, const void *input, int32_t in_dtype, int
                 if (op_flops) op_flops[i] = conv_executed_flops(a);
                 if (flops) { *flops += conv_executed_flops(a); break; }
                 if (!dst) return fail(CPN_E_INVALID, "cpn_plan_run: missing external output buffer");
-                rc = check_hip((hipError_t) (f32 ? launch_conv_f32(a, st) : launch_conv(a, st)), "conv kernel");
+                rc = check_hip((hipError_t) (f32 ? launch_conv_f32(a, st) : fp8 ? launch_conv_fp8(a, st) : launch_conv(a, st)),
+                               "conv kernel");
                 break;
             }
             default: return fail(CPN_E_INVALID, "cpn_plan_run: unknown op");
         }
         if (rc) return rc;
+        if (absmax && o.dst >= 0) {  // calibration: max |x| of the tensor this op produced
+            const cpn_tensor_desc &t = plan->tensors[o.dst];
+            const long count = (long) N * (H / t.down) * (W / t.down) * t.channels;
+            rc = check_hip((hipError_t) launch_absmax_bf16(tptr(o.dst), count, absmax + o.dst, st), "absmax kernel");
+            if (rc) return rc;
+        }
     }
     if (events) (void) hipEventRecord(events[plan->ops.size()], st);
     return 0;
@@ -290,6 +319,14 @@ int cpn_plan_run(cpn_plan *plan, const void *input, int32_t in_dtype, int32_t N,
                  void *workspace, int64_t workspace_bytes, float *const *outputs, int32_t *range_flag, void *stream) {
     return run_or_count(plan, input, in_dtype, N, H, W, workspace, workspace_bytes, outputs, range_flag,
                         (hipStream_t) stream, nullptr);
+}
+
+int cpn_plan_run_stats(cpn_plan *plan, const void *input, int32_t in_dtype, int32_t N, int32_t H, int32_t W,
+                       void *workspace, int64_t workspace_bytes, float *const *outputs, int32_t *range_flag,
+                       float *absmax, void *stream) {
+    if (!absmax) return fail(CPN_E_INVALID, "cpn_plan_run_stats: null absmax");
+    return run_or_count(plan, input, in_dtype, N, H, W, workspace, workspace_bytes, outputs, range_flag,
+                        (hipStream_t) stream, nullptr, nullptr, nullptr, absmax);
 }
 
 double cpn_plan_executed_flops(cpn_plan *plan, int32_t N, int32_t H, int32_t W) {

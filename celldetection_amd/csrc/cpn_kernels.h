@@ -82,4 +82,10 @@ int launch_input_f32(const InputArgs &a, hipStream_t stream);
 int launch_maxpool_f32(const PoolArgs &a, hipStream_t stream);
 int launch_bilinear_f32(const ResizeArgs &a, hipStream_t stream);
 
+// fp8 (e4m3) helper kernels (csrc/misc_fp8.hip) and the calibration reduction
+int launch_input_fp8(const InputArgs &a, float inv_scale, hipStream_t stream);
+int launch_maxpool_fp8(const PoolArgs &a, hipStream_t stream);
+int launch_bilinear_fp8(const ResizeArgs &a, hipStream_t stream);
+int launch_absmax_bf16(const void *x, long count, float *out, hipStream_t stream);
+
 }  // namespace cpn

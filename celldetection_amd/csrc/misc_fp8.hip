@@ -1,0 +1,164 @@
+// fp8 (OCP e4m3) variants of the HBM-bound helper kernels of the conv graph + the calibration reduction
+// (groundwork for BASELINE.json configs[4]; no reference counterpart -- the reference has no fp8 path):
+//   * input conversion f32/u8 NCHW -> e4m3 NHWC codes of value / scale (+ [0,1] range check)
+//   * MaxPool2d, bilinear x2 resize on e4m3 codes (decode -> fp32 -> encode with the SAME tensor scale)
+//   * max |x| of a bf16 NHWC tensor (static activation scales are taken from one bf16 run of the graph)
+#include "cpn_kernels.h"
+
+namespace cpn {
+
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+__device__ __forceinline__ float sat448(float v) { return __builtin_amdgcn_fmed3f(v, -448.f, 448.f); }
+
+__device__ __forceinline__ u32x2 encode8(const float (&v)[8]) {
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(sat448(v[0]), sat448(v[1]), lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(sat448(v[2]), sat448(v[3]), lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(sat448(v[4]), sat448(v[5]), hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(sat448(v[6]), sat448(v[7]), hi, true);
+    u32x2 o;
+    o.x = (unsigned) lo; o.y = (unsigned) hi;
+    return o;
+}
+__device__ __forceinline__ void decode8(const u32x2 r, float (&v)[8]) {
+    v[0] = __builtin_amdgcn_cvt_f32_fp8((int) r.x, 0); v[1] = __builtin_amdgcn_cvt_f32_fp8((int) r.x, 1);
+    v[2] = __builtin_amdgcn_cvt_f32_fp8((int) r.x, 2); v[3] = __builtin_amdgcn_cvt_f32_fp8((int) r.x, 3);
+    v[4] = __builtin_amdgcn_cvt_f32_fp8((int) r.y, 0); v[5] = __builtin_amdgcn_cvt_f32_fp8((int) r.y, 1);
+    v[6] = __builtin_amdgcn_cvt_f32_fp8((int) r.y, 2); v[7] = __builtin_amdgcn_cvt_f32_fp8((int) r.y, 3);
+}
+
+static int grid_for(long total) {
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    return (int) (blocks < 1 ? 1 : blocks);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void input_fp8_kernel(const InputArgs a, float inv_scale) {
+    const int groups = a.Cpad >> 3;
+    const long total = (long) a.N * a.H * a.W * groups;
+    const long HW = (long) a.H * a.W;
+    int bad = 0;
+    for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < total; i += (long) gridDim.x * blockDim.x) {
+        const int gidx = (int) (i % groups);
+        const long pix = i / groups;
+        const long n = pix / HW, p = pix - n * HW;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = gidx * 8 + e;
+            float x = 0.f;
+            if (c < a.C) {
+                const long si = (n * a.C + c) * HW + p;
+                if (a.dtype == 0) x = ((const float *) a.src)[si];
+                else x = (float) ((const unsigned char *) a.src)[si] / 255.f;
+                if (!(x >= 0.f && x <= 1.f)) bad = 1;
+            }
+            v[e] = x * inv_scale;
+        }
+        *(u32x2 *) ((unsigned char *) a.dst + pix * a.Cpad + gidx * 8) = encode8(v);
+    }
+    if (bad && a.range_flag) atomicOr(a.range_flag, 1);
+}
+
+int launch_input_fp8(const InputArgs &a, float inv_scale, hipStream_t stream) {
+    const long total = (long) a.N * a.H * a.W * (a.Cpad >> 3);
+    hipLaunchKernelGGL(input_fp8_kernel, dim3(grid_for(total)), dim3(256), 0, stream, a, inv_scale);
+    return (int) hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_fp8_kernel(const PoolArgs a) {
+    const int groups = a.C >> 3;
+    const long total = (long) a.N * a.Hout * a.Wout * groups;
+    for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < total; i += (long) gridDim.x * blockDim.x) {
+        const int gidx = (int) (i % groups);
+        long pix = i / groups;
+        const int ox = (int) (pix % a.Wout);
+        pix /= a.Wout;
+        const int oy = (int) (pix % a.Hout);
+        const int n = (int) (pix / a.Hout);
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = -__builtin_inff();
+        for (int ky = 0; ky < a.k; ++ky) {
+            const int iy = oy * a.stride - a.pad + ky;
+            if (iy < 0 || iy >= a.Hin) continue;
+            for (int kx = 0; kx < a.k; ++kx) {
+                const int ix = ox * a.stride - a.pad + kx;
+                if (ix < 0 || ix >= a.Win) continue;
+                float v[8];
+                decode8(*(const u32x2 *) ((const unsigned char *) a.src +
+                                          (((long) n * a.Hin + iy) * a.Win + ix) * a.C + gidx * 8), v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
+            }
+        }
+        *(u32x2 *) ((unsigned char *) a.dst + (((long) n * a.Hout + oy) * a.Wout + ox) * a.C + gidx * 8) = encode8(m);
+    }
+}
+
+int launch_maxpool_fp8(const PoolArgs &a, hipStream_t stream) {
+    const long total = (long) a.N * a.Hout * a.Wout * (a.C >> 3);
+    hipLaunchKernelGGL(maxpool_fp8_kernel, dim3(grid_for(total)), dim3(256), 0, stream, a);
+    return (int) hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bilinear_fp8_kernel(const ResizeArgs a) {
+    const int groups = a.C >> 3;
+    const long total = (long) a.N * a.Hout * a.Wout * groups;
+    const float sy = (float) a.Hin / (float) a.Hout, sx = (float) a.Win / (float) a.Wout;
+    for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < total; i += (long) gridDim.x * blockDim.x) {
+        const int gidx = (int) (i % groups);
+        long pix = i / groups;
+        const int ox = (int) (pix % a.Wout);
+        pix /= a.Wout;
+        const int oy = (int) (pix % a.Hout);
+        const int n = (int) (pix / a.Hout);
+        const float fy = fmaxf(sy * ((float) oy + 0.5f) - 0.5f, 0.f);
+        const float fx = fmaxf(sx * ((float) ox + 0.5f) - 0.5f, 0.f);
+        const int y0 = (int) fy, x0 = (int) fx;
+        const int y1 = y0 + (y0 < a.Hin - 1 ? 1 : 0), x1 = x0 + (x0 < a.Win - 1 ? 1 : 0);
+        const float ly = fy - (float) y0, lx = fx - (float) x0;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const unsigned char *base = (const unsigned char *) a.src + (long) n * a.Hin * a.Win * a.C + gidx * 8;
+        float v00[8], v01[8], v10[8], v11[8], o[8];
+        decode8(*(const u32x2 *) (base + ((long) y0 * a.Win + x0) * a.C), v00);
+        decode8(*(const u32x2 *) (base + ((long) y0 * a.Win + x1) * a.C), v01);
+        decode8(*(const u32x2 *) (base + ((long) y1 * a.Win + x0) * a.C), v10);
+        decode8(*(const u32x2 *) (base + ((long) y1 * a.Win + x1) * a.C), v11);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]);
+        *(u32x2 *) ((unsigned char *) a.dst + (((long) n * a.Hout + oy) * a.Wout + ox) * a.C + gidx * 8) = encode8(o);
+    }
+}
+
+int launch_bilinear_fp8(const ResizeArgs &a, hipStream_t stream) {
+    const long total = (long) a.N * a.Hout * a.Wout * (a.C >> 3);
+    hipLaunchKernelGGL(bilinear_fp8_kernel, dim3(grid_for(total)), dim3(256), 0, stream, a);
+    return (int) hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// max |x| over a bf16 tensor -> atomicMax on the float bits of *out (values are >= 0: integer order == float order)
+__global__ __launch_bounds__(256) void absmax_bf16_kernel(const unsigned short *__restrict__ x, long count,
+                                                         unsigned int *__restrict__ out) {
+    float m = 0.f;
+    for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < count; i += (long) gridDim.x * blockDim.x) {
+        const float v = fabsf(__uint_as_float((unsigned int) x[i] << 16));
+        m = v > m ? v : m;  // NaN never wins
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+
+int launch_absmax_bf16(const void *x, long count, float *out, hipStream_t stream) {
+    hipLaunchKernelGGL(absmax_bf16_kernel, dim3(grid_for(count)), dim3(256), 0, stream, (const unsigned short *) x, count,
+                       (unsigned int *) out);
+    return (int) hipGetLastError();
+}
+
+}  // namespace cpn

@@ -399,13 +399,14 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=Non
     tens = (_lib.TensorDesc * len(plan.tensors))()
     for i, t in enumerate(plan.tensors):
         tens[i].channels, tens[i].down = _pad(t['c']), t['down']
+        tens[i].scale = float(act_scales[i]) if fp8 else 0.
     ops = (_lib.OpDesc * len(plan.ops))()
     wparts, bparts = [], []
     woff = boff = 0
     for i, op in enumerate(plan.ops):
         d = ops[i]
         d.src0 = d.src1 = d.res = d.dst = -1
-        d.bias_offset = -1
+        d.bias_offset = d.mult_offset = -1
         op_scales.append((0., 0.))
         if op['op'] == 'input':
             d.op, d.dst, d.in_channels = _lib.OP_INPUT, op['dst'], op['in_channels']
@@ -511,12 +512,17 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=Non
             d.fuse_weight_offset, d.fuse_bias_offset = woff, boff
             d.fuse_cout, d.fuse_act, d.fuse_act_scale = fz['cout'], _ACT[fz['act']], float(fz['act_scale'])
             d.cout_real = fz['cout']
-            woff += wparts[-1].numel() * 2
+            woff += wparts[-1].numel() * (1 if fp8 else 2)
             boff += bparts[-1].numel()
     wblob = torch.cat(wparts).to(device)
     bblob = torch.cat(bparts).to(device)
-    if fp8:
-        return tens, ops, wblob, bblob, torch.cat(mparts).to(device), op_scales
+    if fp8:  # multipliers live behind the biases in ONE float blob (cpn_op_desc.mult_offset); bias and multiplier
+        nb = bblob.numel()  # entries share their relative offsets
+        for d in ops:
+            if d.op == _lib.OP_CONV and d.bias_offset >= 0:
+                d.mult_offset = nb + d.bias_offset
+        allb = torch.cat((bblob, torch.cat(mparts).to(device)))
+        return tens, ops, wblob, allb, allb[nb:], op_scales
     return tens, ops, wblob, bblob
 
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CPN_ABI_VERSION 4
+#define CPN_ABI_VERSION 5
 
 #define CPN_E_INVALID (-1)
 #define CPN_E_UNSUPPORTED (-2)
@@ -42,8 +42,9 @@ int cpn_abi_version(void);
 
 /* activation tensors of the graph (NHWC bf16, channel count padded to a multiple of 32) */
 typedef struct {
-    int32_t channels;  /* padded channel count (multiple of 32)                                   */
+    int32_t channels;  /* padded channel count (multiple of 32; 64 for CPN_PRECISION_FP8 plans)   */
     int32_t down;      /* spatial size = input size / down (down in 1,2,4,...,32)                 */
+    float scale;       /* CPN_PRECISION_FP8: value of one e4m3 code unit of this tensor; else unused */
 } cpn_tensor_desc;
 
 enum { CPN_OP_INPUT = 0, CPN_OP_CONV = 1, CPN_OP_MAXPOOL = 2, CPN_OP_BILINEAR = 3 };
@@ -73,7 +74,8 @@ typedef struct {
     int64_t fuse_weight_offset, fuse_bias_offset;
     int32_t fuse_cout, fuse_act;
     float fuse_act_scale;
-    int32_t reserved_;
+    int32_t mult_offset;      /* CPN_PRECISION_FP8: float offset into the bias blob of the per-output-channel
+                               * multipliers (weight scales), -1 = none; unused by the other precisions        */
 } cpn_op_desc;
 
 typedef struct cpn_plan cpn_plan;
@@ -82,7 +84,12 @@ typedef struct cpn_plan cpn_plan;
  * verification path (fp32 activations/weights/FMA on the vector ALUs; weights packed [bundle][kh*kw][cin_b][cout_b]
  * fp32, weight_offset in bytes of that blob; no fused heads) used to check the whole path against the reference's
  * fp32 CPU forward at 1e-4 */
-enum { CPN_PRECISION_BF16 = 0, CPN_PRECISION_F32 = 1 };
+enum { CPN_PRECISION_BF16 = 0, CPN_PRECISION_F32 = 1, CPN_PRECISION_FP8 = 2 };
+/* CPN_PRECISION_FP8 (groundwork for BASELINE.json configs[4], no reference counterpart): activations are OCP e4m3
+ * codes with one static scale per tensor (cpn_tensor_desc.scale, taken from a bf16 run through cpn_plan_run_stats),
+ * weights e4m3 codes with one scale per output channel and the input-tensor scale folded in (see cpn_conv2d_fp8),
+ * accumulation in fp32 on v_mfma_scale_f32_32x32x64_f8f6f4 (2x the bf16 MFMA rate); the fused ReadOut tails stay
+ * bf16, the head outputs fp32. */
 
 /* Creates a plan (host-side object; copies the descriptors).  `weights` / `bias` are DEVICE pointers to the packed
  * blobs and must stay alive as long as the plan. */
@@ -104,6 +111,12 @@ double cpn_plan_executed_flops(cpn_plan *plan, int32_t N, int32_t H, int32_t W);
  * (the caller raises the reference's AssertionError, models/commons.py:696-697). */
 int cpn_plan_run(cpn_plan *plan, const void *input, int32_t in_dtype, int32_t N, int32_t H, int32_t W,
                  void *workspace, int64_t workspace_bytes, float *const *outputs, int32_t *range_flag, void *stream);
+
+/* Calibration run of a CPN_PRECISION_BF16 plan: like cpn_plan_run, additionally writes max|x| of every activation
+ * tensor to absmax[tensor id] (device float[n_tensors], zeroed by the caller). */
+int cpn_plan_run_stats(cpn_plan *plan, const void *input, int32_t in_dtype, int32_t N, int32_t H, int32_t W,
+                       void *workspace, int64_t workspace_bytes, float *const *outputs, int32_t *range_flag,
+                       float *absmax, void *stream);
 
 /* Profiling variant: brackets every op with HIP events on `stream`, synchronises, and returns the per-op duration
  * (ms, op_ms[cpn_plan_num_ops]) and the executed MFMA FLOPs per op (op_flops, may be NULL). */

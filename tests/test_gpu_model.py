@@ -428,3 +428,29 @@ def test_full_size_properties(dev):
     n_ref, n_got = len(ref['scores'][0]), len(got['scores'][0])
     print('full size tile 0: proposals', n_got, 'oracle', n_ref, 'IoU>0.5 match rate', rate)
     assert abs(n_ref - n_got) <= 0.1 * n_ref and rate > .9
+
+
+@pytest.mark.parametrize('name', ['CpnU22', 'CpnU22_wide', 'CpnResNeXt101UNet', 'CpnResNet18FPN', 'CpnResNet50FPN'])
+def test_fp8_precision_vs_reference_maps(dev, name):
+    """fp8 (e4m3 activations + weights, K=64 scaled MFMA) conv stack against the reference's fp32 head maps: e4m3 has a
+    3-bit mantissa (2^-4 relative rounding per value), so the check is a relative L2 bound per head map plus an
+    IoU-matched proposal comparison -- there is no reference fp8 path to be exact against."""
+    model, g = build(name, dev)
+    x = torch.as_tensor(g['x']).to(dev)
+    model.precision = 'fp8'
+    scales = model.calibrate_fp8(x)
+    assert len(scales) == len(model._plan.tensors) and min(scales) > 0
+    s, l, r, f = [t.cpu() for t in model.core_forward(x)]
+    exp = dict(scores=torch.sigmoid(torch.as_tensor(g['core.scores'])), locations=torch.as_tensor(g['core.locations']),
+               refinement=torch.as_tensor(g['core.refinement']), fourier=torch.as_tensor(g['core.fourier']))
+    rep = {}
+    for key, got in (('scores', s), ('locations', l), ('refinement', r), ('fourier', f)):
+        e = exp[key]
+        assert got.shape == e.shape and torch.isfinite(got).all(), key
+        rep[key] = ((got - e).norm() / (e.norm() + 1e-12)).item()
+    print(name, 'fp8 relL2', {k: f'{v:.3f}' for k, v in rep.items()})
+    assert max(rep.values()) < 0.5, rep  # measured 0.08 .. 0.45 on the synthetic-weight tiny models
+    y = model(x, nms=False)
+    rates = [_iou_match_rate(y['boxes'][i].cpu().numpy(), g[f'nonms.boxes.{i}']) for i in range(x.shape[0])]
+    print(name, 'fp8 proposal IoU>0.5 match rates', rates)
+    assert min(rates) > .5, rates

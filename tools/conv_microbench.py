@@ -28,6 +28,44 @@ CASES = {
 ZERO = bool(int(os.environ.get('CPN_MB_ZERO', '0')))  # all-zero operands: DVFS ceiling probe (power vs issue bound)
 
 
+FP8 = bool(int(os.environ.get('CPN_MB_FP8', '0')))   # e4m3 kernel (cpn_conv2d_fp8) instead of bf16
+
+
+def run_fp8(name, P, sd, cfg, reps):
+    dev = torch.device('cuda:0')
+    n, h, w, cin, cout, k = (cfg[x] for x in ('n', 'h', 'w', 'cin', 'cout', 'k'))
+    cin1, groups = cfg.get('cin1', 0), cfg.get('groups', 1)
+    p64 = lambda c: (c + 63) // 64 * 64
+    scales = {i: 1. / 64 for i in range(len(P.tensors))}
+    tens, ops, wblob, bblob, mblob, op_scales = graph.pack(P, sd, dev, precision='fp8', act_scales=scales)
+
+    def codes(*shape):
+        return torch.randn(*shape, device=dev).mul_(64).clamp_(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+
+    x0 = codes(n, h, w, p64(cin))
+    x1 = codes(n, h // 2, w // 2, p64(cin1)) if cin1 else None
+    dst = torch.empty(n, h, w, p64(cout), dtype=torch.uint8, device=dev)
+    lib = _lib.load()
+
+    def launch():
+        _lib.check(lib.cpn_conv2d_fp8(ops[0], _lib.ptr(x0), x0.shape[-1], _lib.ptr(x1), 0 if x1 is None else x1.shape[-1],
+                                      _lib.ptr(None), 0, _lib.ptr(dst), dst.shape[-1], n, h, w, _lib.ptr(wblob),
+                                      _lib.ptr(bblob), _lib.ptr(mblob), 0., 64., _lib.stream_ptr()))
+
+    for _ in range(3):
+        launch()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    gf = 2. * n * h * w * cout * ((cin + cin1) // groups) * k * k / 1e9
+    print(f'{name:8s} {ms:8.3f} ms  {gf / ms:8.1f} TF/s  ({gf:.1f} GF)  [fp8]', flush=True)
+
+
 def run(name, reps=20):
     cfg = dict(CASES[name])
     dev = torch.device('cuda:0')
@@ -40,6 +78,8 @@ def run(name, reps=20):
     sd = {'c.weight': torch.randn(cout, (cin + cin1) // groups, k, k) * .05, 'c.bias': torch.randn(cout) * .1}
     if ZERO:
         sd = {k_: torch.zeros_like(v_) for k_, v_ in sd.items()}
+    if FP8:
+        return run_fp8(name, P, sd, cfg, reps)
     tens, ops, wblob, bblob = graph.pack(P, sd, dev)
     p32 = lambda c: (c + 31) // 32 * 32
     x0 = torch.randn(n, h, w, p32(cin), device=dev).to(torch.bfloat16)
