@@ -45,7 +45,8 @@ def build_model(name, dev, seed=0, tile=512, calib_tiles=2):
         return torch.log(s / (1 - s)), l, r, f
 
     # ~1.3 % of the 256x256 head grid above threshold -> O(1e3) proposals per tile, contours of a few px radius
-    sd, _ = calibrate_heads(sd, core_fn, score_shift=-4.5, score_gain=3., fourier_std=1.5, location_std=.5)
+    for _ in range(2):  # second pass: the first one only sees clamped logits when the raw heads saturate the sigmoid
+        sd, _ = calibrate_heads(sd, core_fn, score_shift=-4.5, score_gain=3., fourier_std=1.5, location_std=.5)
     model.load_state_dict(sd)
     return model.to(dev), sd
 
@@ -184,8 +185,10 @@ def main():
             'metric': f'tiles/sec (3x{args.tile}x{args.tile}) {args.model}', 'value': value, 'unit': 'tiles/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
-            'config': {'workload': f'{args.model} full CPN path, batch {args.batch} x 3x{args.tile}x{args.tile} per GPU '
-                                   f'(BASELINE.json configs[2]), synthetic ginoro-shaped weights',
+            'config': {'workload': f'{args.model} full CPN path, batch {args.batch} x 3x{args.tile}x{args.tile} per GPU'
+                                   + (' (BASELINE.json configs[2])' if (args.model, args.batch, args.tile, args.precision)
+                                      == ('CpnResNeXt101UNet', 16, 512, 'bf16') else '')
+                                   + ', synthetic weights of the reference shapes',
                        'tiles_per_gpu_per_step': args.batch, 'detections_last_step': ndet,
                        'parallelism': f'tile-sharded x{world}, no data-path collective',
                        'step_mode': 'forward() per step' if not args.pipeline else

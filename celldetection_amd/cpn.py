@@ -142,19 +142,29 @@ class _Engine:
         ref = torch.empty((n, 2 * meta.get('refinement_buckets', 1), h, w), **f32) if refinement else None
         self.last_uncertainty = torch.empty((n, 4, h // d, w // d), **f32) if meta.get('uncertainty_head') else None
         flag = torch.zeros(1, dtype=torch.int32, device=self.device)
-        ws, need = self.workspace(n, h, w)
-        outs = (c_void_p * _lib.NUM_OUTPUTS)(scores.data_ptr(), locations.data_ptr(), fourier.data_ptr(),
-                                             0 if ref is None else ref.data_ptr(),
-                                             0 if self.last_uncertainty is None else self.last_uncertainty.data_ptr())
-        if _absmax is not None:
-            _lib.check(lib.cpn_plan_run_stats(self.handle, _lib.ptr(x), dt, n, h, w, _lib.ptr(ws), need, outs,
-                                              _lib.ptr(flag), _lib.ptr(_absmax), _lib.stream_ptr()), 'plan_run_stats')
-        elif _timed is not None:
-            _lib.check(lib.cpn_plan_run_timed(self.handle, _lib.ptr(x), dt, n, h, w, _lib.ptr(ws), need, outs,
-                                              _lib.ptr(flag), _lib.stream_ptr(), _timed[0], _timed[1]), 'plan_run_timed')
-        else:
-            _lib.check(lib.cpn_plan_run(self.handle, _lib.ptr(x), dt, n, h, w, _lib.ptr(ws), need, outs, _lib.ptr(flag),
-                                        _lib.stream_ptr()), 'plan_run')
+        # the kernels address activation tensors with 32-bit element offsets: split the batch when a tensor of the
+        # graph would reach 2^31 elements (e.g. 8 x 256 ch x 1024^2 in front of an FPN refinement head)
+        per_image = max((h // t.down) * (w // t.down) * t.channels for t in self.tens)
+        nb = max(1, min(n, (2 ** 31 - 1) // per_image))
+        if _timed is not None and nb < n:
+            raise ValueError('per-op profiling needs a batch whose tensors stay below 2^31 elements')
+        ws, need = self.workspace(nb, h, w)
+        outputs = (scores, locations, fourier, ref, self.last_uncertainty)
+        for i0 in range(0, n, nb):
+            m = min(nb, n - i0)
+            xi = x[i0:i0 + m]
+            outs = (c_void_p * _lib.NUM_OUTPUTS)(*[0 if t is None else t[i0:i0 + m].data_ptr() for t in outputs])
+            if _absmax is not None:
+                _lib.check(lib.cpn_plan_run_stats(self.handle, _lib.ptr(xi), dt, m, h, w, _lib.ptr(ws), need, outs,
+                                                  _lib.ptr(flag), _lib.ptr(_absmax), _lib.stream_ptr()),
+                           'plan_run_stats')
+            elif _timed is not None:
+                _lib.check(lib.cpn_plan_run_timed(self.handle, _lib.ptr(xi), dt, m, h, w, _lib.ptr(ws), need, outs,
+                                                  _lib.ptr(flag), _lib.stream_ptr(), _timed[0], _timed[1]),
+                           'plan_run_timed')
+            else:
+                _lib.check(lib.cpn_plan_run(self.handle, _lib.ptr(xi), dt, m, h, w, _lib.ptr(ws), need, outs,
+                                            _lib.ptr(flag), _lib.stream_ptr()), 'plan_run')
         return scores, locations, ref, fourier, flag
 
 

@@ -141,3 +141,32 @@ def test_pack_unpack_empty_detections():
     assert tuple(buf.shape) == (0, 32 * 2 + 4 + 1 + 1 + 2 + 20 + 64)
     out = unpack_detections(buf, 32, 5)
     assert all(tuple(out[k].shape) == tuple(d[k].shape) for k in d)
+
+
+@pytest.mark.parametrize('name', list(ALL_SPECS))
+def test_fp8_packing_passes_plan_validation(name):
+    """fp8 weight/bias/multiplier blobs of every model: sizes and offsets satisfy the native plan's validation (host-side
+    object only, no kernel runs), weight codes are finite e4m3, multipliers are positive."""
+    from ctypes import c_void_p
+    spec = ALL_SPECS[name]
+    model = getattr(cda.models, spec['cls'])(**spec['kwargs'])
+    plan = model._plan
+    tens, ops, wblob, bblob, mblob, op_scales = graph.pack(plan, model.state_dict(), 'cpu', precision='fp8',
+                                                           act_scales=[0.01 + 0.001 * i for i in range(len(plan.tensors))])
+    assert wblob.dtype == torch.uint8 and all(t.channels % 64 == 0 for t in tens)
+    assert float(mblob.min()) > 0
+    lib = _lib.load()
+    h = c_void_p()
+    rc = lib.cpn_plan_create(h, tens, len(tens), ops, len(ops), _lib.ptr(wblob), wblob.numel(), _lib.ptr(bblob),
+                             bblob.numel(), _lib.PRECISION_FP8)
+    assert rc == 0, lib.cpn_last_error()
+    assert lib.cpn_plan_workspace_bytes(h, 2, 64, 64) > 0
+    lib.cpn_plan_destroy(h)
+    for d, op in zip(ops, plan.ops):
+        if d.op != _lib.OP_CONV:
+            continue
+        items = (d.cin_b // 64) * d.kh * d.kw
+        codes = wblob[d.weight_offset:d.weight_offset + d.bundles * (items + items % 2) * d.cout_b * 64]
+        assert not bool(((codes & 0x7f) == 0x7f).any()), op['w']  # no e4m3 NaN codes
+        if items % 2:  # the padding slab of the last item is all zero
+            assert int(codes.reshape(d.bundles, items + 1, -1)[:, -1].max()) == 0

@@ -1,4 +1,5 @@
-"""Times the post-processing (compaction + decode + refinement + NMS + gathers) of the bench workload on fixed head maps."""
+"""Times the post-processing (compaction + decode + refinement + NMS + gathers) on fixed head maps, with a breakdown.
+    python tools/post_microbench.py [model=CpnResNeXt101UNet] [tile=512] [batch=16]"""
 import os
 import sys
 import time
@@ -8,17 +9,42 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import build_model  # noqa: E402
+from celldetection_amd import ops  # noqa: E402
 
+name = sys.argv[1] if len(sys.argv) > 1 else 'CpnResNeXt101UNet'
+tile = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 dev = torch.device('cuda:0')
-model, _ = build_model('CpnResNeXt101UNet', dev)
-x = torch.rand(16, 3, 512, 512, generator=torch.Generator().manual_seed(100)).to(dev)
+model, _ = build_model(name, dev, tile=tile)
+x = torch.rand(batch, 3, tile, tile, generator=torch.Generator().manual_seed(100)).to(dev)
 maps = model.core_forward(x)
-for _ in range(3):
-    y = model.postprocess(*maps, (512, 512))
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(20):
-    y = model.postprocess(*maps, (512, 512))
-torch.cuda.synchronize()
-print('postprocess %.3f ms per batch of 16 (%d detections)' % ((time.perf_counter() - t0) / 20 * 1e3,
-                                                              sum(len(s) for s in y['scores'])))
+
+
+def timed(fn, n=10):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        r = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3, r
+
+
+ms, y = timed(lambda: model.postprocess(*maps, (tile, tile)))
+print(f'{name} {batch}x{tile}^2 postprocess {ms:.3f} ms ({sum(len(s) for s in y["scores"])} kept)')
+scores, locations, refinement, fourier = maps
+ms, (idx, counts, _) = timed(lambda: ops.compact_scores(scores, model.score_thresh))
+print(f'  compact   {ms:8.3f} ms  proposals per image {counts}')
+ms, flat = timed(lambda: ops.decode_proposals(idx, scores, locations, fourier, refinement, size=(tile, tile),
+                                              order=model.order, samples=model.samples,
+                                              iterations=model.refinement_iterations))
+print(f'  decode    {ms:8.3f} ms')
+offs = [0]
+for c in counts:
+    offs.append(offs[-1] + c)
+ms, (keep, kc) = timed(lambda: ops._nms_segments(flat['boxes'], flat['scores'], offs, model.nms_thresh))
+print(f'  nms       {ms:8.3f} ms  kept {sum(kc)}')
+sel = torch.cat([keep[offs[i]:offs[i] + kc[i]] for i in range(batch)])
+ms, _ = timed(lambda: {k: flat[k].index_select(0, sel) for k in ('contours', 'boxes', 'scores', 'locations', 'fourier',
+                                                                  'contour_proposals')})
+print(f'  gathers   {ms:8.3f} ms')
