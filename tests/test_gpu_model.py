@@ -428,6 +428,13 @@ def test_full_size_properties(dev):
     n_ref, n_got = len(ref['scores'][0]), len(got['scores'][0])
     print('full size tile 0: proposals', n_got, 'oracle', n_ref, 'IoU>0.5 match rate', rate)
     assert abs(n_ref - n_got) <= 0.1 * n_ref and rate > .9
+    # fp8 graph at full size: proposals IoU-matched against the fp32 oracle's (e4m3 activations: 3-bit mantissa)
+    model.precision = 'fp8'
+    model.calibrate_fp8(x[:2])
+    got8 = model(x[:1], nms=False)
+    rate8 = _iou_match_rate(got8['boxes'][0].cpu().numpy(), ref['boxes'][0])
+    print('full size tile 0 fp8: proposals', len(got8['scores'][0]), 'IoU>0.5 match rate', rate8)
+    assert abs(n_ref - len(got8['scores'][0])) <= 0.25 * n_ref and rate8 > .75
 
 
 @pytest.mark.parametrize('name', ['CpnU22', 'CpnU22_wide', 'CpnResNeXt101UNet', 'CpnResNet18FPN', 'CpnResNet50FPN'])

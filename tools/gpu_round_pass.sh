@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-end GPU pass (run on the MI355X box through gpurun, from the repo root):
-#   tools/gpu_round_pass.sh <tag> [tests] [bench] [profile]
+#   tools/gpu_round_pass.sh <tag> [tests] [bench] [profile] [fp8]
 # writes everything under gpurun_out/ (the summaries that should be judged are then copied into profiles/).
 TAG=${1:-r01}; shift
 WHAT=${*:-tests bench profile}
@@ -26,4 +26,9 @@ profile)
    python tools/summarize_rocprof.py $P/gtrace $P/fetch $P/write $P/mfma) > gpurun_out/${TAG}_rocprofv3_summary.txt 2>&1
   grep -h "^{" $P/trace.log > gpurun_out/${TAG}_bench_lines_under_rocprof.txt
   grep -A8 "run_graph_only" gpurun_out/${TAG}_rocprofv3_summary.txt | cut -c1-150;;
+fp8)
+  timeout 600 python bench.py --precision fp8 --no-cpu-baseline > gpurun_out/${TAG}_bench_fp8_n1.json 2> gpurun_out/${TAG}_bench_fp8.err; cat gpurun_out/${TAG}_bench_fp8_n1.json | cut -c1-300
+  (timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $P/f8trace -o b -- python bench.py --precision fp8 --steps 5 --warmup 2 --no-cpu-baseline) > $P/f8trace.log 2>&1
+  (echo "### bench.py --precision fp8 --steps 5 --warmup 2 under rocprofv3 --kernel-trace --stats"; python tools/summarize_rocprof.py $P/f8trace) > gpurun_out/${TAG}_fp8_rocprofv3_summary.txt 2>&1
+  head -12 gpurun_out/${TAG}_fp8_rocprofv3_summary.txt | cut -c1-150;;
 esac; done
