@@ -12,7 +12,7 @@ csv.field_size_limit(1 << 30)
 
 def short(name):
     name = re.sub(r'^void ', '', name)
-    m = re.match(r'(?:cpn::|\(anonymous namespace\)::)?(\w+)(<[^>]*>)?', name)
+    m = re.match(r'(?:cpn::|\(anonymous namespace\)::)?((?:cpn_fp8::)?\w+)(<[^>]*>)?', name)
     if m and ('cpn' in name or 'anonymous' in name):
         return m.group(1) + (m.group(2) or '')
     return name[:70]
