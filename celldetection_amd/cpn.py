@@ -284,6 +284,9 @@ class CPN(nn.Module):
         eng = _Engine(self._plan, self.state_dict(), inputs.device, 'bf16')
         absmax = eng.activation_absmax(inputs, self.core.order, self.refinement)
         self._fp8_scales = [max(float(v), 1e-12) / 448. for v in absmax.tolist()]
+        for op in self._plan.ops:  # max-pool / bilinear kernels work on the codes: output scale == input scale
+            if op['op'] in ('maxpool', 'bilinear'):
+                self._fp8_scales[op['dst']] = self._fp8_scales[op['src0']]
         if self._engine is not None and self._engine.precision == 'fp8':
             self._engine = None
         return self._fp8_scales

@@ -378,14 +378,16 @@ def _pad64(c):
     return (c + 63) // 64 * 64
 
 
-def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=None):
+def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=None, effective_weights: list = None):
     """-> (tensor_descs, op_descs, weight_blob[bf16 | f32, device], bias_blob[f32, device]).
 
     bf16: weights [bundle][cin_b/32][k*k][cout_b][32]; fp32 (verification path): [bundle][k*k][cin_b][cout_b].
     fp8 (e4m3, groundwork for BASELINE configs[4]): ``act_scales[tensor id]`` = value per activation code; channels
     are padded to 64; weights [bundle][cin_b/64][k*k (+1 zero slab if odd)][cout_b][64] as e4m3 codes of
     ``w * input_scale / weight_scale[cout]``; returns additionally (mult_blob[f32] = weight_scale per output channel,
-    [(res_scale, out_inv_scale)] per op); the weight blob is a byte tensor."""
+    [(res_scale, out_inv_scale)] per op); the weight blob is a byte tensor.  ``effective_weights`` (tests): a list that
+    receives, per conv op, the dequantised weights the fp8 kernel effectively applies to real-valued inputs
+    (``[cout, cin/groups, k, k]`` float64) and the bias."""
     f32 = precision == 'fp32'
     fp8 = precision == 'fp8'
     if fp8 and act_scales is None:
@@ -470,6 +472,26 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=Non
             mparts.append(wscale.reshape(-1).to(torch.float32))
             op_scales[-1] = (float(act_scales[op['res']]) if op['res'] is not None else 0.,
                              1. / float(act_scales[op['dst']]) if op['dst'] is not None else 0.)
+            if effective_weights is not None:
+                dq = codes[:, :packed.shape[1]].view(torch.float8_e4m3fn).to(torch.float64) * wscale[:, None, :, None]
+                dq = dq.reshape(bundles, cin_b // KC, k * k, cout_b, KC).permute(0, 3, 1, 4, 2)  # [B][cout][chunk][64][tap]
+                dq = dq.reshape(bundles, cout_b, cin_b, k, k)
+                if geo is None:
+                    weff = torch.zeros_like(w)
+                    if groups == 1:
+                        weff[:, :c0] = dq[0, :cout, :c0] / act_scales[op['src0']]
+                        if c1:
+                            weff[:, c0:] = dq[0, :cout, c0p:c0p + c1] / act_scales[op['src1']]
+                    else:
+                        cig_, cog_ = cin // groups, cout // groups
+                        for g_ in range(groups):
+                            weff[g_ * cog_:(g_ + 1) * cog_] = dq[0, g_ * cog_:(g_ + 1) * cog_, g_ * cig_:(g_ + 1) * cig_]
+                        weff /= act_scales[op['src0']]
+                else:
+                    cig_ = cin // groups
+                    weff = torch.stack([dq[:, g_ * cig_:(g_ + 1) * cig_, g_ * cig_:(g_ + 1) * cig_] for g_ in range(gpb)], 1)
+                    weff = weff.reshape(cout, cig_, k, k) / act_scales[op['src0']]
+                effective_weights.append(dict(w=weff, b=b.clone()))
         else:
             wparts.append(packed.contiguous().reshape(-1).to(wdt))
         bparts.append(bias.to(torch.float32))

@@ -1,0 +1,63 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE ONLY: simulator of the fp8 (e4m3) conv graph of celldetection_amd.
+
+The reference has no fp8 path (BASELINE.json configs[4] asks for one), so there is nothing of the reference to restate
+here: this module restates OUR fp8 algorithm ("fp8 precision") in plain torch-CPU so that the HIP kernels
+can be pinned against something tighter than "close to fp32": every activation tensor is an e4m3 code times a static
+per-tensor scale, weights are e4m3 codes times a per-output-channel scale (``graph.pack(..., effective_weights=)``
+returns them dequantised), accumulation is fp32/fp64, ReadOut tails are bf16.  Only ``tests/`` import it.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def _q(t, scale):
+    """value -> nearest e4m3 code * scale (saturating), computed like the kernels: fp32 multiply by 1/scale."""
+    inv = torch.tensor(1.0 / scale, dtype=torch.float32)
+    return (t.float() * inv).clamp(-448, 448).to(torch.float8_e4m3fn).float() * scale
+
+
+def _act(t, act, act_scale):
+    if act == 'relu':
+        return F.relu(t)
+    if act == 'sigmoid':
+        return torch.sigmoid(t)
+    if act == 'tanh_scaled':
+        return torch.tanh(t) * act_scale
+    return t
+
+
+def simulate(plan, state_dict, effective_weights, act_scales, x):
+    """-> dict out_index -> fp32 NCHW head map.  ``plan``: graph.Plan; ``effective_weights``: list filled by
+    ``graph.pack(plan, sd, 'cpu', 'fp8', act_scales, effective_weights=...)``; ``x``: fp32 NCHW input in [0, 1]."""
+    T, outs, ei = {}, {}, 0
+    up = lambda t: F.interpolate(t, scale_factor=2, mode='nearest')
+    for op in plan.ops:
+        kind = op['op']
+        if kind == 'input':
+            T[op['dst']] = _q(x, act_scales[op['dst']])
+        elif kind == 'maxpool':
+            T[op['dst']] = F.max_pool2d(T[op['src0']], op['k'], op['stride'], op['pad'])  # codes unchanged
+        elif kind == 'bilinear':
+            t = T[op['src0']]
+            s = act_scales[op['src0']]
+            T[op['dst']] = _q(F.interpolate(t, scale_factor=2, mode='bilinear', align_corners=False), s)
+        else:
+            e = effective_weights[ei]
+            ei += 1
+            xin = up(T[op['src0']]) if op['up0'] else T[op['src0']]
+            if op['src1'] is not None:
+                xin = torch.cat((xin, up(T[op['src1']]) if op['up1'] else T[op['src1']]), 1)
+            y = F.conv2d(xin.double(), e['w'], e['b'], op['stride'], op['pad'], 1, op['groups']).float()
+            if op['res'] is not None:
+                y = y + (up(T[op['res']]) if op['res_up'] else T[op['res']])
+            y = _act(y, op['act'], op['act_scale'])
+            if op['dst'] is not None:
+                T[op['dst']] = _q(y, act_scales[op['dst']])
+            elif op.get('fuse'):
+                fz = op['fuse']
+                w2 = state_dict[fz['w'] + 'weight'].float().to(torch.bfloat16).float()
+                z = F.conv2d(y.to(torch.bfloat16).float(), w2, state_dict[fz['w'] + 'bias'].float())
+                outs[op['out_index']] = _act(z, fz['act'], fz['act_scale'])
+            else:
+                outs[op['out_index']] = y
+    return outs

@@ -461,3 +461,21 @@ def test_fp8_precision_vs_reference_maps(dev, name):
     rates = [_iou_match_rate(y['boxes'][i].cpu().numpy(), g[f'nonms.boxes.{i}']) for i in range(x.shape[0])]
     print(name, 'fp8 proposal IoU>0.5 match rates', rates)
     assert min(rates) > .5, rates
+    # the same fp8 algorithm restated on the CPU (oracle/fp8_sim.py: identical codes, scales and weights).  A deep
+    # quantised graph is chaotic -- one e4m3 rounding that differs because of the fp32 summation order shifts ~1
+    # rounding decision in the next layer, so after 30..120 layers the two noise realisations are decorrelated
+    # (HIP vs simulation differ by about as much as either differs from fp32; the kernels themselves are pinned per
+    # layer by tests/test_gpu_kernels.py::test_conv_fp8_vs_dequantised_reference).  What must hold is that the HIP path is
+    # not noisier than the restated algorithm: same error level against the reference's fp32 maps, map by map.
+    import fp8_sim
+    from celldetection_amd import _lib, graph
+    eff = []
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    graph.pack(model._plan, sd, 'cpu', precision='fp8', act_scales=scales, effective_weights=eff)
+    sim = fp8_sim.simulate(model._plan, sd, eff, scales, torch.as_tensor(g['x']))
+    for key, got, idx in (('scores', s, _lib.OUT_SCORES), ('locations', l, _lib.OUT_LOCATIONS),
+                          ('fourier', f, _lib.OUT_FOURIER), ('refinement', r, _lib.OUT_REFINEMENT)):
+        e_sim = ((sim[idx] - exp[key]).norm() / (exp[key].norm() + 1e-12)).item()
+        d = ((got - sim[idx]).norm() / (sim[idx].norm() + 1e-12)).item()
+        print(f'{name} {key}: fp8 error vs fp32 reference: HIP {rep[key]:.3f}, CPU simulation {e_sim:.3f}; HIP vs sim {d:.3f}')
+        assert rep[key] < 1.5 * e_sim + 0.03, (key, rep[key], e_sim)
