@@ -109,6 +109,7 @@ def main():
         model.precision = 'fp8'
         model.calibrate_fp8(x[:2])  # static activation scales from a bf16 run on two tiles
 
+    model.engine(dev)  # pack the weights / create the native plan now (set-up, not a step), also when --warmup 0
     state = {}
 
     def run_step(events):
