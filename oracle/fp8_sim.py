@@ -26,10 +26,40 @@ def _act(t, act, act_scale):
     return t
 
 
-def simulate(plan, state_dict, effective_weights, act_scales, x):
+def calibrate(plan, state_dict, x):
+    """Per-tensor activation scales max|x|/448 from an un-quantised fp32 walk of the plan (the HIP path takes them from
+    a bf16 run, ``CPN.calibrate_fp8``); max-pool / bilinear outputs inherit the scale of their input."""
+    from celldetection_amd import graph
+    folded = [dict(zip(('w', 'b'), graph._fold(state_dict, op))) for op in plan.ops if op['op'] == 'conv']
+    absmax = {}
+    simulate(plan, state_dict, folded, None, x, _absmax=absmax)
+    scales = [max(absmax.get(i, 0.), 1e-12) / 448. for i in range(len(plan.tensors))]
+    for op in plan.ops:
+        if op['op'] in ('maxpool', 'bilinear'):
+            scales[op['dst']] = scales[op['src0']]
+    return scales
+
+
+def simulate(plan, state_dict, effective_weights, act_scales, x, _absmax=None):
     """-> dict out_index -> fp32 NCHW head map.  ``plan``: graph.Plan; ``effective_weights``: list filled by
-    ``graph.pack(plan, sd, 'cpu', 'fp8', act_scales, effective_weights=...)``; ``x``: fp32 NCHW input in [0, 1]."""
+    ``graph.pack(plan, sd, 'cpu', 'fp8', act_scales, effective_weights=...)``; ``x``: fp32 NCHW input in [0, 1].
+    (``_absmax``: dict -> no quantisation, records max|x| per tensor: the calibration walk.)"""
     T, outs, ei = {}, {}, 0
+    if _absmax is not None:
+        global _q
+        real_q = _q
+
+        def _q(t, scale):  # noqa: F811 -- identity during the calibration walk
+            return t.float()
+        act_scales = [1.] * len(plan.tensors)
+    try:
+        return _simulate(plan, state_dict, effective_weights, act_scales, x, T, outs, ei, _absmax)
+    finally:
+        if _absmax is not None:
+            _q = real_q
+
+
+def _simulate(plan, state_dict, effective_weights, act_scales, x, T, outs, ei, _absmax):
     up = lambda t: F.interpolate(t, scale_factor=2, mode='nearest')
     for op in plan.ops:
         kind = op['op']
@@ -60,4 +90,6 @@ def simulate(plan, state_dict, effective_weights, act_scales, x):
                 outs[op['out_index']] = _act(z, fz['act'], fz['act_scale'])
             else:
                 outs[op['out_index']] = y
+        if _absmax is not None and op.get('dst') is not None:
+            _absmax[op['dst']] = float(T[op['dst']].abs().max())
     return outs

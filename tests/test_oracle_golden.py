@@ -155,3 +155,32 @@ def test_stitch():
         exp = g[f'final.{k}']
         assert v.shape == exp.shape, k
         np.testing.assert_allclose(v, exp, rtol=0, atol=2e-4, err_msg=k)
+
+
+@pytest.mark.parametrize('name', ['CpnU22', 'CpnResNet18FPN', 'CpnResNeXt101UNet'])
+def test_fp8_simulator_against_reference_maps(name):
+    """The CPU restatement of OUR fp8 algorithm (oracle/fp8_sim.py + the packer's dequantised weights) stays within the
+    e4m3 error level of the reference's fp32 head maps, and its un-quantised walk reproduces them (i.e. the plan, the
+    BN folding and the effective-weight bookkeeping are right)."""
+    import celldetection_amd as cda
+    import fp8_sim
+    from celldetection_amd import _lib, graph
+    g, sd = _load_model_fixture(name)
+    spec = MODEL_SPECS[name]
+    plan = getattr(cda.models, spec['cls'])(**spec['kwargs'])._plan
+    x = torch.as_tensor(g['x'])
+    torch.set_num_threads(4)
+    exp = {_lib.OUT_SCORES: torch.sigmoid(torch.as_tensor(g['core.scores'])),
+           _lib.OUT_LOCATIONS: torch.as_tensor(g['core.locations']),
+           _lib.OUT_FOURIER: torch.as_tensor(g['core.fourier']), _lib.OUT_REFINEMENT: torch.as_tensor(g['core.refinement'])}
+    folded = [dict(zip(('w', 'b'), graph._fold(sd, op))) for op in plan.ops if op['op'] == 'conv']
+    flt = fp8_sim.simulate(plan, sd, folded, None, x, _absmax={})
+    for k, e in exp.items():  # un-quantised walk (bf16 only in the ReadOut tails): ~1e-2 of the map
+        assert ((flt[k] - e).norm() / (e.norm() + 1e-12)).item() < 3e-2, k
+    scales = fp8_sim.calibrate(plan, sd, x)
+    eff = []
+    graph.pack(plan, sd, 'cpu', precision='fp8', act_scales=scales, effective_weights=eff)
+    sim = fp8_sim.simulate(plan, sd, eff, scales, x)
+    for k, e in exp.items():
+        rel = ((sim[k] - e).norm() / (e.norm() + 1e-12)).item()
+        assert torch.isfinite(sim[k]).all() and 1e-3 < rel < 0.6, (k, rel)
