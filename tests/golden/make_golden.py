@@ -108,6 +108,16 @@ def gen_ops():
         if iters == 4:
             out['refine_all'] = np.stack(npy(all_res))
     out['refine_in'], out['refine_map'], out['refine_b'] = npy(con), npy(refinement), npy(b)
+    # G2b bucketed refinement (cpn.py:72-82) with the default sampling: bucket tables + refined contours
+    for nb, smp in ((6, 16), (3, 16)):
+        sampling = torch.linspace(0, 1.0, smp)
+        tab = rops.resolve_refinement_buckets(sampling, nb)
+        out[f'bucket_idx_{nb}'] = np.stack([npy(i) for i, _ in tab])
+        out[f'bucket_w_{nb}'] = np.stack([npy(w_) for _, w_ in tab])
+        ref_b = (torch.rand(n, 2 * nb, h, w, generator=torch.Generator().manual_seed(4321 + nb)) * 2 - 1) * 3
+        res, _ = local_refinement(con.clone(), ref_b, num_loops=3, num_buckets=nb, original_size=(h, w),
+                                  sampling=sampling, b=b)
+        out[f'refine_bucket_map_{nb}'], out[f'refine_bucket_out_{nb}'] = npy(ref_b), npy(res)
     # G3 locations / scaling
     loc = torch.randn(2, 2, 5, 7, generator=g)
     out['rel2abs_in'], out['rel2abs_out'] = npy(loc), npy(rops.rel_location2abs_location(loc))

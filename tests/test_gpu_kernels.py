@@ -483,3 +483,14 @@ def test_conv_fp8_vs_dequantised_reference(dev, name):
         assert bad <= 1e-3, (name, bad, float(err.max()))
         if p64(cout) > cout:  # padded output channels must be exact zeros
             assert int(dst.cpu()[..., cout:].max()) in (0, 0x80) or int(dst.cpu()[..., cout:].max()) == 0
+
+
+@pytest.mark.parametrize('nb', [6, 3])
+def test_bucketed_local_refinement_vs_reference_golden(dev, nb):
+    """ops.local_refinement(num_buckets=...) (refine_kernel with the bucket tables) bit-exact vs the reference's
+    bucketed local_refinement (cpn.py:72-82) on the golden vectors."""
+    from celldetection_amd import ops
+    g = np.load(os.path.join(G, 'ops.npz'))
+    got = ops.local_refinement(torch.as_tensor(g['refine_in']).to(dev), torch.as_tensor(g[f'refine_bucket_map_{nb}']).to(dev),
+                               3, torch.as_tensor(g['refine_b']).to(dev), num_buckets=nb)
+    np.testing.assert_array_equal(got.cpu().numpy(), g[f'refine_bucket_out_{nb}'])

@@ -184,3 +184,19 @@ def test_fp8_simulator_against_reference_maps(name):
     for k, e in exp.items():
         rel = ((sim[k] - e).norm() / (e.norm() + 1e-12)).item()
         assert torch.isfinite(sim[k]).all() and 1e-3 < rel < 0.6, (k, rel)
+
+
+@pytest.mark.parametrize('nb', [6, 3])
+def test_bucketed_refinement_bit_exact(ops, nb):
+    """resolve_refinement_buckets tables and bucketed local_refinement (cpn.py:72-82) vs the reference's outputs."""
+    tab = orc.refinement_buckets_table(16, nb)
+    np.testing.assert_array_equal(np.stack([i for i, _ in tab]), ops[f'bucket_idx_{nb}'])
+    np.testing.assert_array_equal(np.stack([w for _, w in tab]), ops[f'bucket_w_{nb}'])
+    got, _ = orc.local_refinement(ops['refine_in'], ops[f'refine_bucket_map_{nb}'], ops['refine_b'], 3, (24, 40),
+                                  num_buckets=nb)
+    np.testing.assert_array_equal(got, ops[f'refine_bucket_out_{nb}'])
+    # the product's host-side table builder (pure torch CPU arithmetic, no kernel involved)
+    from celldetection_amd.ops import bucket_tables
+    idx, wgt = bucket_tables(16, nb, 'cpu')
+    np.testing.assert_array_equal(idx.numpy(), ops[f'bucket_idx_{nb}'])
+    np.testing.assert_array_equal(wgt.numpy(), ops[f'bucket_w_{nb}'])
