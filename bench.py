@@ -1,16 +1,30 @@
 """Benchmark of the CPN inference hot path on MI355X: tiles/sec for 3x512x512 tiles with CpnResNeXt101UNet.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W [--workload tiles|slide]
 
-One *step* = one pass of the whole hot path (input conversion -> ResNeXt101-UNet conv stack -> 4 heads ->
-compaction -> Fourier decode + refinement + boxes -> per-image NMS) over one batch of 16 synthetic 3x512x512 tiles
-per GPU, inputs resident in HBM (BASELINE.json configs[2]: the configuration the metric is quoted on).
+``--gpus N`` with N > 1 and no torchrun environment re-launches itself as
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`` (one rank per GPU, RCCL);
+started BY torchrun it checks that WORLD_SIZE equals N and fails otherwise -- a 1-GPU number can never be reported
+for an N-GPU request.  Rank 0 prints ONE JSON line.
+
+Workloads
+  tiles (default; BASELINE.json configs[2], the configuration the metric is quoted on): one *step* = one pass of the
+      whole hot path (input conversion -> ResNeXt101-UNet conv stack -> 4 heads -> compaction -> Fourier decode +
+      refinement + boxes -> per-image NMS) over one batch of 16 synthetic 3x512x512 tiles per GPU, inputs resident in
+      HBM.  Tiles are independent: no data-path collective, weak scaling.
+  slide (BASELINE.json configs[3]): one *step* = the whole tiled-inference loop over a synthetic 3x16384x16384 uint8
+      slide resident on every rank (1849 tiles 512/384, strided tile -> rank sharding, on-device crops, border
+      removal, ONE packed all-gather of the per-rank detections over RCCL, global NMS on every rank).  Fixed total
+      work: strong scaling.  The line carries the gather and global-NMS milliseconds.
+
 Weights: seeded synthetic tensors of the exact ginoro/CpnResNeXt101UNet shapes (no network => no checkpoint), heads
-calibrated so that decode/NMS process a realistic number of detections.  Rank 0 prints ONE JSON line.
+calibrated so that decode/NMS process a realistic number of detections.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -20,12 +34,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16 peak of MI355X (MI355X_MICROARCH.md; 2:1-sparsity figures excluded)
-GFLOP_PER_TILE = {'CpnResNeXt101UNet': 2392.83, 'CpnResNet18FPN': 2124.85}  # SURVEY.md section 8a, 3x512x512 tiles
-# HBM bytes of ONE conv-graph execution (batch 16 x 3x512x512, CpnResNeXt101UNet) from the PMC passes committed in
-# profiles/r01_rocprofv3_summary.txt (tools/run_graph_only.py 5; sums over the conv/input/maxpool kernels / 5):
-# 2 x FETCH_SIZE (gfx950 correction for wide 16-B/lane streaming reads, MI355X_MICROARCH.md section HBM) + WRITE_SIZE
-# = 2 x 11.80 GB + 9.13 GB.  Algorithmic: 12.5 GB read + 9.1 GB written (every op reads/writes its tensors once).
-TRAFFIC_BYTES_PER_GRAPH_B16 = 32.73e9
+# SURVEY.md section 8a, 2*MAC of the reference graph per 3x512x512 tile; backbone stack = body + unet (the part the
+# >= 70 % MFMA target of BASELINE.json is stated on)
+GFLOP_PER_TILE = {'CpnResNeXt101UNet': 2392.83, 'CpnResNet18FPN': 2124.85}
+BACKBONE_GFLOP_PER_TILE = {'CpnResNeXt101UNet': 1024.04}
+TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'traffic.json')  # written by tools/gpu_round_pass.sh from the PMC passes
 
 
 def build_model(name, dev, seed=0, tile=512, calib_tiles=2):
@@ -51,37 +64,122 @@ def build_model(name, dev, seed=0, tile=512, calib_tiles=2):
     return model.to(dev), sd
 
 
-def cpu_baseline(sd, tile, seconds_budget=20.):
+def _physical_cores():
+    try:
+        import psutil
+        return int(psutil.cpu_count(logical=False) or 0)
+    except Exception:
+        return 0
+
+
+def _cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(sd, tile, seconds_budget=25.):
     """Oracle (torch-CPU fp32 restatement, oracle/cpn_oracle.py) timed on this host's cores on a bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import cpn_oracle as orc
-    # one tile does not scale past a few dozen oneDNN threads (256 threads measured 100x slower than 32 on the
-    # 256-core GPU host): use 32 threads and report that number as `cores`
-    cores = min(os.cpu_count() or 1, 32)
+    # BASELINE.md asks for n = physical cores.  oneDNN's conv does not scale a batch of <= 2 tiles past a few dozen
+    # threads on the 2-socket GPU hosts (256 threads measured ~100x SLOWER than 32: barrier/NUMA bound), and a sample
+    # has to fit ~25 s, so the thread count is min(physical cores, 32) and that number is reported as `cores`.
+    phys = _physical_cores() or (os.cpu_count() or 1)
+    cores = max(1, min(phys, 32))
     torch.set_num_threads(cores)
-    x = torch.rand(1, 3, tile, tile, generator=torch.Generator().manual_seed(2))
+    batch = 2
+    x = torch.rand(batch, 3, tile, tile, generator=torch.Generator().manual_seed(2))
     sd_cpu = {k: v.detach().cpu() for k, v in sd.items()}
     t0 = time.perf_counter()
-    orc.cpn_forward(sd_cpu, x)  # warm-up (also bounds the sample)
+    orc.cpn_forward(sd_cpu, x[:1])  # warm-up on one tile (also bounds the sample)
     warm = time.perf_counter() - t0
-    reps = max(1, min(3, int(seconds_budget / max(warm, 1e-3)) - 1))
+    if warm * batch * 2 > seconds_budget:
+        batch, x = 1, x[:1]
+    reps = max(1, min(5, int(seconds_budget / max(warm * batch, 1e-3))))
     best = float('inf')
     for _ in range(reps):
         t0 = time.perf_counter()
         orc.cpn_forward(sd_cpu, x)
         best = min(best, time.perf_counter() - t0)
-    return dict(value=1. / best, unit='tiles/s', cores=cores, kind='port',
-                sample=f'{reps + 1} x 1 tile 3x{tile}x{tile} fp32 full path (conv graph + decode + NMS), best of {reps}')
+    return dict(value=batch / best, unit='tiles/s', cores=cores, kind='port', physical_cores=phys,
+                cpu_model=_cpu_model(),
+                sample=f'1 warm-up tile + {reps} x batch of {batch} tile(s) 3x{tile}x{tile}, fp32 full path (conv graph + '
+                       f'decode + NMS) on {cores} threads, best of {reps}')
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """python bench.py --gpus N (N > 1) outside torchrun: start one rank per GPU and relay the JSON line."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.call(cmd, env=env)
+
+
+def load_traffic(model, batch, tile, precision):
+    """HBM bytes per conv-graph execution from the committed PMC passes (profiles/traffic.json), or None."""
+    try:
+        with open(TRAFFIC_FILE) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return None, None
+    key = f'{model}/b{batch}/t{tile}/{precision}'
+    e = t.get(key)
+    if not e:
+        return None, None
+    return float(e['traffic_bytes_per_graph']), e.get('source')
+
+
+def dry_run(args, world, rank):
+    """CPU exercise of the launch / rendezvous / sharding / packed all-gather plumbing (no GPU, no kernels): used by
+    tests/test_bench_launch.py with --backend gloo.  Prints a JSON line marked dry_run; NOT a measurement."""
+    import torch.distributed as td
+    from celldetection_amd import inference, util
+    S, O = 8, 3
+    n_tiles = len(list(util.get_tiling_slices((2048, 2048), (512, 512), (384, 384))[0]))
+    mine = inference.shard_tiles(n_tiles, rank, world)
+    k = 3 * len(mine) + rank  # deterministic fake detections: 3 per tile (+rank: ragged counts)
+    g = torch.Generator().manual_seed(rank)
+    d = dict(contours=torch.rand(k, S, 2, generator=g), boxes=torch.rand(k, 4, generator=g),
+             scores=torch.rand(k, generator=g), classes=torch.ones(k, dtype=torch.int64),
+             locations=torch.rand(k, 2, generator=g), fourier=torch.rand(k, O, 4, generator=g),
+             contour_proposals=torch.rand(k, S, 2, generator=g))
+    buf = inference.gather_detections(inference.pack_detections(d))
+    total = buf.shape[0]
+    expect = sum(3 * len(inference.shard_tiles(n_tiles, r, world)) + r for r in range(world))
+    assert total == expect, (total, expect)
+    if world > 1:
+        td.barrier()
+    if rank == 0:
+        print(json.dumps({'dry_run': True, 'n_gpus': world, 'world_size_seen': world, 'backend': args.backend,
+                          'tiles': n_tiles, 'gathered_detections': total}))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=None)
+    ap.add_argument('--warmup', type=int, default=None)
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--tile', type=int, default=512)
     ap.add_argument('--model', default='CpnResNeXt101UNet')
+    ap.add_argument('--workload', default='tiles', choices=['tiles', 'slide'])
+    ap.add_argument('--slide', type=int, default=16384, help='slide edge length of the slide workload')
+    ap.add_argument('--stride', type=int, default=384, help='tile stride of the slide workload')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help="'nccl' = RCCL; 'gloo' only with --dry-run")
+    ap.add_argument('--dry-run', action='store_true', help='CPU plumbing check of launch + sharding + gather (no GPU)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp8'],
                     help="conv-graph precision; 'fp8' (e4m3, K=64 scaled MFMA) is BASELINE.json configs[4] groundwork, "
@@ -90,26 +188,49 @@ def main():
                     help='two-stream throughput mode (CPN.forward_pipelined); default: synchronous forward() per step')
     ap.add_argument('--profile-layers', action='store_true', help='print per-op timings to stderr')
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 30 if args.workload == 'tiles' else 1
+    if args.warmup is None:
+        args.warmup = 5 if args.workload == 'tiles' else 1
 
+    in_torchrun = 'WORLD_SIZE' in os.environ and 'RANK' in os.environ
+    if args.gpus > 1 and not in_torchrun:
+        sys.exit(self_launch(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
     dist = world > 1
+    if args.dry_run:
+        if dist:
+            import torch.distributed as td
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            td.init_process_group(args.backend)
+        dry_run(args, world, rank)
+        if dist:
+            td.destroy_process_group()
+        return
+    if args.backend != 'nccl':
+        raise SystemExit('bench.py: measurements run on RCCL (--backend nccl); gloo is for --dry-run only')
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
     if dist:
         import torch.distributed as td
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         td.init_process_group('nccl', device_id=dev)
+        assert td.get_world_size() == args.gpus, (td.get_world_size(), args.gpus)
 
     model, sd = build_model(args.model, dev, tile=args.tile)
+    if args.workload == 'slide':
+        return slide_workload(args, model, dev, world, rank, dist)
     g = torch.Generator().manual_seed(100 + rank)
     x = torch.rand(args.batch, 3, args.tile, args.tile, generator=g).to(dev)  # resident in HBM before timing
     if args.precision == 'fp8':
         model.precision = 'fp8'
         model.calibrate_fp8(x[:2])  # static activation scales from a bf16 run on two tiles
 
-    model.engine(dev)  # pack the weights / create the native plan now (set-up, not a step), also when --warmup 0
+    eng = model.engine(dev)  # pack the weights / create the native plan now (set-up, not a step), also when --warmup 0
     state = {}
 
     def run_step(events):
@@ -154,24 +275,33 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         dt = float(t.item())
-    conv_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    conv_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
     if args.profile_layers and rank == 0:
         print('device allocations (hipMalloc) during the timed steps:',
               torch.cuda.memory_stats(dev).get('num_device_alloc', 0) - mem0, file=sys.stderr)
         print('conv graph per step (ms): ' + ' '.join(f'{a.elapsed_time(b):.2f}' for a, b in ev), file=sys.stderr)
 
-    if args.profile_layers and rank == 0:
-        eng = model.engine(dev)
+    # per-op timing of ONE more graph execution (outside the timed region): backbone-stack fraction of the roofline
+    backbone = None
+    if rank == 0 and args.precision == 'bf16':
         prof = eng.profile(x, model.core.order, True)
         tot = sum(p['ms'] for p in prof)
-        for p in prof:
-            if p['op'] == 'conv':
-                tf = p['gflop'] / max(p['ms'], 1e-6)
-                print(f"{p['index']:3d} conv k{p['k']} s{p['stride']} g{p['groups']:<2d} {p['cin']:5d}->{p['cout']:<5d} "
-                      f"{p['ms']:8.3f} ms {tf:8.1f} TF/s  {p['name']}", file=sys.stderr)
-            else:
-                print(f"{p['index']:3d} {p['op']:8s} {p['ms']:8.3f} ms", file=sys.stderr)
-        print(f'conv graph total {tot:.3f} ms', file=sys.stderr)
+        bb_ms = sum(p['ms'] for p in prof if p['op'] != 'conv' or 'backbone' in p['name'])
+        bb_gf = BACKBONE_GFLOP_PER_TILE.get(args.model) if args.tile == 512 else None
+        if bb_gf:
+            backbone = {'ms': bb_ms, 'achieved': bb_gf * args.batch / bb_ms, 'frac': bb_gf * args.batch / bb_ms / PEAK_BF16_TFLOPS,
+                        'algorithmic_gflop': bb_gf * args.batch,
+                        'note': 'backbone conv stack (body + unet incl. input/maxpool helpers) of one per-op-timed graph '
+                                'execution outside the timed region'}
+        if args.profile_layers:
+            for p in prof:
+                if p['op'] == 'conv':
+                    tf = p['gflop'] / max(p['ms'], 1e-6)
+                    print(f"{p['index']:3d} conv k{p['k']} s{p['stride']} g{p['groups']:<2d} {p['cin']:5d}->{p['cout']:<5d} "
+                          f"{p['ms']:8.3f} ms {tf:8.1f} TF/s  {p['name']}", file=sys.stderr)
+                else:
+                    print(f"{p['index']:3d} {p['op']:8s} {p['ms']:8.3f} ms", file=sys.stderr)
+            print(f'conv graph total {tot:.3f} ms', file=sys.stderr)
 
     if rank == 0:
         tiles = args.batch * args.steps * world
@@ -180,8 +310,12 @@ def main():
         if gf is None or args.tile != 512:
             from celldetection_amd.graph import reference_flops
             gf = reference_flops(model._plan, args.tile, args.tile) / 1e9
+        peak = PEAK_BF16_TFLOPS * (2 if args.precision == 'fp8' else 1)
         achieved = gf * args.batch / conv_ms  # GFLOP / ms = TFLOP/s
+        executed = eng.executed_flops(args.batch, args.tile, args.tile) / 1e9
+        traffic, traffic_src = load_traffic(args.model, args.batch, args.tile, args.precision)
         ndet = sum(len(s) for s in y['scores'])
+        n_launch = sum(1 for op in eng.plan.ops if op['op'] == 'conv')
         out = {
             'metric': f'tiles/sec (3x{args.tile}x{args.tile}) {args.model}', 'value': value, 'unit': 'tiles/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
@@ -191,20 +325,81 @@ def main():
                                       == ('CpnResNeXt101UNet', 16, 512, 'bf16') else '')
                                    + ', synthetic weights of the reference shapes',
                        'tiles_per_gpu_per_step': args.batch, 'detections_last_step': ndet,
-                       'parallelism': f'tile-sharded x{world}, no data-path collective',
+                       'world_size_seen_by_rccl': world,
+                       'parallelism': f'tile-sharded x{world}, one process per GPU, no data-path collective',
                        'step_mode': 'forward() per step' if not args.pipeline else
                        'forward_pipelined(): post-processing of step i overlaps the conv graph of step i+1'},
-            'roofline': {'bound': 'mfma', 'achieved': achieved,
-                         'peak': PEAK_BF16_TFLOPS * (2 if args.precision == 'fp8' else 1), 'unit': 'TFLOP/s',
-                         'frac': achieved / (PEAK_BF16_TFLOPS * (2 if args.precision == 'fp8' else 1)),
-                         'traffic': TRAFFIC_BYTES_PER_GRAPH_B16 if (args.model == 'CpnResNeXt101UNet' and args.batch == 16
-                                                                    and args.tile == 512) else None,
-                         'kernel': 'conv_igemm_kernel: one conv-graph execution = 126 convs in 122 launches of the kernel '
-                                   'family (+ input/maxpool helpers), timed with HIP events on the launch stream',
-                         'launch_ms': conv_ms, 'algorithmic_gflop_per_launch': gf * args.batch},
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+                         'traffic': traffic, 'traffic_source': traffic_src,
+                         'kernel': f'conv_igemm_kernel: one conv-graph execution = {n_launch} launches of the kernel family '
+                                   '(+ input/maxpool helpers), timed with HIP events on the launch stream',
+                         'launch_ms': conv_ms, 'algorithmic_gflop_per_launch': gf * args.batch,
+                         'executed_gflop_per_launch': executed, 'executed_frac': executed / conv_ms / peak,
+                         'backbone_stack': backbone},
         }
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(sd, args.tile)
+        print(json.dumps(out))
+    if dist:
+        td.destroy_process_group()
+
+
+def slide_workload(args, model, dev, world, rank, dist):
+    """BASELINE.json configs[3]: tiled inference over one synthetic slide, tiles sharded over the ranks."""
+    from celldetection_amd import inference, util
+    if dist:
+        import torch.distributed as td
+    S, crop, stride = args.slide, (args.tile, args.tile), (args.stride, args.stride)
+    # every rank holds the same slide (seeded) resident in HBM as uint8: 3 x 16384^2 = 805 MB
+    slide = torch.randint(0, 256, (3, S, S), dtype=torch.uint8, generator=torch.Generator().manual_seed(3)).to(dev)
+    ntiles = len(list(util.get_tiling_slices((S, S), crop, stride)[0]))
+    kw = dict(crop_size=crop, strides=stride, batch_size=args.batch)
+    warm = slide[:, :min(S, 4 * args.tile), :min(S, 4 * args.tile)]
+    for _ in range(max(args.warmup, 1)):  # small slide: allocator / RCCL communicator / kernels warm
+        inference.tiled_inference(model, warm, **kw)
+    torch.cuda.synchronize()
+    if dist:
+        td.barrier()
+        torch.cuda.synchronize()
+    tim = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        t = {}
+        res = inference.tiled_inference(model, slide, timings=t, **kw)
+        tim.append(t)
+    torch.cuda.synchronize()
+    if dist:
+        td.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([dt] + [sum(t[k] for t in tim) for k in ('tiles', 'gather', 'nms')], dtype=torch.float64, device=dev)
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        dt, t_tiles, t_gather, t_nms = (float(v) for v in tt.tolist())
+    else:
+        t_tiles, t_gather, t_nms = (sum(t[k] for t in tim) for k in ('tiles', 'gather', 'nms'))
+    if rank == 0:
+        gf = GFLOP_PER_TILE.get(args.model)
+        value = ntiles * args.steps / dt
+        peak = PEAK_BF16_TFLOPS
+        out = {
+            'metric': f'tiles/sec (3x{args.tile}x{args.tile}) {args.model}', 'value': value, 'unit': 'tiles/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
+            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': f'{args.model} tiled inference over a synthetic 1x3x{S}x{S} uint8 slide, {ntiles} tiles '
+                                   f'{args.tile}/{args.stride}, batch {args.batch}, tile-shard + RCCL gather + global NMS'
+                                   + (' (BASELINE.json configs[3])' if (S, args.tile, args.stride) == (16384, 512, 384) else ''),
+                       'tiles_total': ntiles, 'world_size_seen_by_rccl': world,
+                       'parallelism': f'tile i -> rank i mod {world}; one packed all-gather of the detections; global NMS on every rank',
+                       'tile_loop_ms': 1e3 * t_tiles / args.steps, 'gather_ms': 1e3 * t_gather / args.steps,
+                       'global_nms_ms': 1e3 * t_nms / args.steps,
+                       'detections_gathered': tim[-1].get('detections_gathered'),
+                       'detections_final': int(res['scores'].shape[0])},
+            'roofline': {'bound': 'mfma', 'achieved': value * gf / 1e3 if gf else None, 'peak': peak * world, 'unit': 'TFLOP/s',
+                         'frac': (value * gf / 1e3) / (peak * world) if gf else None, 'traffic': None,
+                         'kernel': 'whole slide loop (conv graphs + crops + post-processing + exchange): '
+                                   'tiles/s x algorithmic GFLOP per tile'},
+        }
         print(json.dumps(out))
     if dist:
         td.destroy_process_group()

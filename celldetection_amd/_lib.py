@@ -10,8 +10,9 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CPN_HIP_LIB') or os.path.join(HERE, 'libcpn_hip.so')  # env: kernel A/B tuning only
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 PRECISION_BF16, PRECISION_F32, PRECISION_FP8 = 0, 1, 2
+E_INVALID, E_UNSUPPORTED, E_WORKSPACE = -1, -2, -3
 
 OP_INPUT, OP_CONV, OP_MAXPOOL, OP_BILINEAR = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH_SCALED = 0, 1, 2, 3
@@ -43,6 +44,8 @@ _SIGNATURES = [
                                        c_void_p, c_size_t, c_void_p, c_size_t, c_int32]),
     ('cpn_plan_destroy', None, [c_void_p]),
     ('cpn_plan_workspace_bytes', c_int64, [c_void_p, c_int32, c_int32, c_int32]),
+    ('cpn_plan_output_dims', ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, POINTER(c_int32), POINTER(c_int32)]),
+    ('cpn_plan_max_tensor_elements', c_int64, [c_void_p, c_int32, c_int32]),
     ('cpn_plan_executed_flops', c_double, [c_void_p, c_int32, c_int32, c_int32]),
     ('cpn_plan_run', ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64,
                                     POINTER(c_void_p), c_void_p, c_void_p]),
@@ -85,6 +88,14 @@ _SIGNATURES = [
     ('cpn_box_votes', ctypes.c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p]),
     ('cpn_border_keep', ctypes.c_int, [c_void_p, c_int64, c_int32, c_float, c_float, c_float, c_float, c_float,
                                        c_int32, c_void_p, c_void_p]),
+    ('cpn_resize_bilinear_f32', ctypes.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
+                                               c_void_p]),
+    ('cpn_border_keep_batched', ctypes.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
+                                               c_float, c_float, c_float, c_void_p, c_void_p]),
+    ('cpn_nms_binned_workspace_bytes', c_int64, [c_int64, c_int64]),
+    ('cpn_nms_binned', ctypes.c_int, [c_void_p, c_void_p, c_int64, c_float, c_int64, c_void_p, c_void_p,
+                                      POINTER(c_int64), POINTER(c_int64), POINTER(c_int32), c_void_p, c_int64,
+                                      c_void_p]),
 ]
 
 EXPORTED_SYMBOLS = tuple(s[0] for s in _SIGNATURES)

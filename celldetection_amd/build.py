@@ -23,6 +23,7 @@ SOURCES = {
     'conv_f32.hip': [],
     # decode/NMS must reproduce the reference's fp32 operation order bit-for-bit: no FMA contraction
     'decode_nms.hip': ['-ffp-contract=off'],
+    'nms_binned.hip': ['-ffp-contract=off'],
     'cpn_abi.hip': [],
 }
 HEADERS = ['cpn_kernels.h', 'cpn_error.h', 'conv_igemm.hip', os.path.join('..', '..', 'include', 'cpn_hip.h')]

@@ -81,12 +81,12 @@ class _Engine:
         self._ws = None
 
     def __del__(self):
-        try:
-            if getattr(self, 'handle', None):
-                _lib.load().cpn_plan_destroy(self.handle)
-                self.handle = None
-        except Exception:
-            pass
+        handle, self.handle = getattr(self, 'handle', None), None
+        if handle:
+            try:
+                _lib.load().cpn_plan_destroy(handle)
+            except (RuntimeError, OSError, AttributeError, TypeError):  # interpreter shutdown: library already unloaded
+                pass
 
     def workspace(self, n, h, w):
         need = int(_lib.load().cpn_plan_workspace_bytes(self.handle, n, h, w))
@@ -96,6 +96,13 @@ class _Engine:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws, need
+
+    def output_size(self, h, w, out_index):
+        """(h, w) of the external output ``out_index`` (``_lib.OUT_*``) for an ``h`` x ``w`` input."""
+        from ctypes import c_int32
+        oh, ow = c_int32(0), c_int32(0)
+        _lib.check(_lib.load().cpn_plan_output_dims(self.handle, h, w, out_index, oh, ow), 'plan_output_dims')
+        return int(oh.value), int(ow.value)
 
     def executed_flops(self, n, h, w):
         return float(_lib.load().cpn_plan_executed_flops(self.handle, n, h, w))
@@ -124,8 +131,6 @@ class _Engine:
         """x: [N,C,H,W] float32 in [0,1] (or uint8) on self.device -> (scores, locations, refinement, fourier, flag)."""
         lib = _lib.load()
         n, c, h, w = x.shape
-        if h % 32 or w % 32:
-            raise ValueError(f'Input height and width must be multiples of 32 on the HIP path, got {(h, w)}.')
         if x.dtype == torch.uint8:
             dt = 1
         else:
@@ -133,18 +138,22 @@ class _Engine:
             if x.dtype != torch.float32:
                 x = x.float()
         x = x.contiguous()
-        d = self.plan.meta['head_down']
         f32 = dict(dtype=torch.float32, device=self.device)
         meta = self.plan.meta
-        scores = torch.empty((n, meta.get('score_channels', 1), h // d, w // d), **f32)
-        locations = torch.empty((n, 2, h // d, w // d), **f32)
-        fourier = torch.empty((n, 4 * order_total, h // d, w // d), **f32)
+        hh, ww = self.output_size(h, w, _lib.OUT_SCORES)  # head grid: any H x W (sizes propagated by the executor)
+        scores = torch.empty((n, meta.get('score_channels', 1), hh, ww), **f32)
+        locations = torch.empty((n, 2, hh, ww), **f32)
+        fourier = torch.empty((n, 4 * order_total, hh, ww), **f32)
         ref = torch.empty((n, 2 * meta.get('refinement_buckets', 1), h, w), **f32) if refinement else None
-        self.last_uncertainty = torch.empty((n, 4, h // d, w // d), **f32) if meta.get('uncertainty_head') else None
+        if refinement and self.output_size(h, w, _lib.OUT_REFINEMENT) != (h, w):
+            raise RuntimeError('refinement head output does not have the input size')  # cpn.py:279 would resize it
+        self.last_uncertainty = torch.empty((n, 4, hh, ww), **f32) if meta.get('uncertainty_head') else None
         flag = torch.zeros(1, dtype=torch.int32, device=self.device)
         # the kernels address activation tensors with 32-bit element offsets: split the batch when a tensor of the
         # graph would reach 2^31 elements (e.g. 8 x 256 ch x 1024^2 in front of an FPN refinement head)
-        per_image = max((h // t.down) * (w // t.down) * t.channels for t in self.tens)
+        per_image = int(lib.cpn_plan_max_tensor_elements(self.handle, h, w))
+        if per_image <= 0:
+            _lib.check(per_image or _lib.E_INVALID, 'plan_max_tensor_elements')
         nb = max(1, min(n, (2 ** 31 - 1) // per_image))
         if _timed is not None and nb < n:
             raise ValueError('per-op profiling needs a batch whose tensors stay below 2^31 elements')
@@ -169,9 +178,16 @@ class _Engine:
 
 
 def _equal_size(x, reference):
-    """celldetection/models/cpn.py:109-115."""
+    """celldetection/models/cpn.py:109-115: bilinear resize (align_corners=False) of an fp32 NCHW map to the spatial
+    size of ``reference`` (own HIP kernel with torch CPU's arithmetic: the thresholded result must not depend on which
+    backend resized the mask)."""
     if reference.shape[2:] != x.shape[2:]:
-        x = F.interpolate(x, reference.shape[2:], mode='bilinear', align_corners=False)
+        x = x.contiguous().float()
+        out = torch.empty(x.shape[:2] + tuple(reference.shape[2:]), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().cpn_resize_bilinear_f32(_lib.ptr(x), _lib.ptr(out), x.shape[0] * x.shape[1], x.shape[2],
+                                                       x.shape[3], out.shape[2], out.shape[3], _lib.stream_ptr()),
+                   'resize_bilinear_f32')
+        x = out
     return x
 
 
@@ -245,8 +261,9 @@ class CPN(nn.Module):
         return super().load_state_dict(state_dict, strict=strict, **kw)
 
     def repack(self):
-        """Call after modifying parameters in place."""
+        """Call after modifying parameters in place (the fp8 activation scales are stale then, too)."""
         self._engine = None
+        self._fp8_scales = None
 
     def _apply(self, fn, *a, **k):
         self._engine = None
@@ -269,6 +286,10 @@ class CPN(nn.Module):
                 if self._fp8_scales is None:
                     if calibration_input is None:
                         raise RuntimeError("precision 'fp8' needs activation scales: call calibrate_fp8(batch) first")
+                    import warnings
+                    warnings.warn("precision 'fp8': calibrating the static activation scales on the first forwarded "
+                                  'batch; activations of later batches that exceed its range saturate at 448 * scale. '
+                                  'Call calibrate_fp8() on representative tiles instead.', RuntimeWarning, stacklevel=3)
                     self.calibrate_fp8(calibration_input)
                 self._engine = _Engine(self._plan, self.state_dict(), device, 'fp8', act_scales=self._fp8_scales)
             else:
@@ -336,9 +357,13 @@ class CPN(nn.Module):
                 done = torch.cuda.Event()
                 done.record(s_post)
             caller.wait_event(done)  # the caller's stream may consume the outputs
-            for v in out.values():
-                for t in (v or ()):
+            if isinstance(out, tuple):  # flat_output: (dict of flat tensors, per-image counts)
+                for t in out[0].values():
                     t.record_stream(caller)
+            else:
+                for v in out.values():
+                    for t in (v or ()):
+                        t.record_stream(caller)
             return out
 
         for item in batches:
@@ -379,10 +404,12 @@ class CPN(nn.Module):
 
     @torch.no_grad()
     def postprocess(self, scores, locations, refinement, fourier, original_size, nms=True, flag=None,
-                    uncertainty=None, **kwargs):
+                    uncertainty=None, flat_output=False, **kwargs):
         """CPN.forward after the core (cpn.py:575-734) on given head maps: ``scores`` [N,1,h,w] probabilities (sigmoid
         already applied; binary CPNs) or [N,classes,h,w] raw logits (multi-class, cpn.py:583-585); locations [N,2,h,w];
-        refinement [N,2*buckets,H,W] or None; fourier [N,4*O,h,w]; uncertainty [N,4,h,w] or None (cpn.py:209-221)."""
+        refinement [N,2*buckets,H,W] or None; fourier [N,4*O,h,w]; uncertainty [N,4,h,w] or None (cpn.py:209-221).
+        ``flat_output``: return ``(dict of flat [K, ...] tensors incl. 'b' = image index int32 [K], per-image counts)``
+        instead of per-image lists (the slide loop filters all tiles of a batch at once)."""
         n = scores.shape[0]
         lb, ub = kwargs.get('scores_lower_bound'), kwargs.get('scores_upper_bound')
         ub = None if ub is None else _equal_size(ub.to(scores), scores)  # cpn.py:118-123
@@ -427,11 +454,13 @@ class CPN(nn.Module):
             # one segmented NMS over all images + ONE gather per output key (instead of N x 7 small index kernels)
             keep, kc = ops._nms_segments(flat['boxes'], nms_weights, offs, self.nms_thresh)
             sel = torch.cat([keep[offs[i]:offs[i] + kc[i]] for i in range(n)])
-            flat = {k: flat[k].index_select(0, sel) for k in keys}  # cpn.py:53-60
+            flat = {k: flat[k].index_select(0, sel) for k in keys + ['b']}  # cpn.py:53-60
             offs = [0]
             for c in kc:
                 offs.append(offs[-1] + c)
             nms = False
+        if flat_output and not nms:
+            return {k: flat[k] for k in keys + ['b']}, [offs[i + 1] - offs[i] for i in range(n)]
         outputs = OrderedDict((k, [flat[k][offs[i]:offs[i + 1]] for i in range(n)]) for k in keys)  # cpn.py:42-50
         if 'box_uncertainties' not in outputs:
             outputs['box_uncertainties'] = None
@@ -440,6 +469,12 @@ class CPN(nn.Module):
             keep = ops.batched_box_nmsi(outputs['boxes'], weights, self.nms_thresh)
             for k in keys:
                 outputs[k] = [v[kp] for v, kp in zip(outputs[k], keep)]
+        if flat_output:
+            cnt = [int(v.shape[0]) for v in outputs['scores']]
+            out = {k: torch.cat(outputs[k]) for k in keys}
+            out['b'] = torch.repeat_interleave(torch.arange(n, dtype=torch.int32, device=scores.device),
+                                               torch.tensor(cnt, device=scores.device))
+            return out, cnt
         return outputs
 
 

@@ -3,7 +3,7 @@
 // the north-star tolerance (contour coordinates within 1e-4, threshold / NMS index sets equal) -- the bf16 MFMA path
 // cannot be bit-compatible end-to-end because `scores > thresh` and round-half-even are discontinuous.
 // Throughput is not a goal here (a few TFLOP/s on the vector ALUs); every fused feature of the bf16 kernel is
-// supported with identical semantics (virtual concat, nearest x2 upsample, upsampled residual, bundles, activations,
+// supported with identical semantics (virtual concat, nearest-resized sources, resized residual, bundles, activations,
 // fp32 NCHW head outputs).  Weights: [bundle][kh*kw][cin_b][cout_b] fp32.
 #include "cpn_kernels.h"
 
@@ -23,8 +23,7 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvArgs a) {
     t /= a.Wout;
     const int oy = (int) (t % a.Hout);
     const int n = (int) (t / a.Hout);
-    const int Hs0 = a.up0 ? (a.Hin >> 1) : a.Hin, Ws0 = a.up0 ? (a.Win >> 1) : a.Win;
-    const int Hs1 = a.up1 ? (a.Hin >> 1) : a.Hin, Ws1 = a.up1 ? (a.Win >> 1) : a.Win;
+    const int Hs0 = a.Hs0, Ws0 = a.Ws0, Hs1 = a.Hs1, Ws1 = a.Ws1;
     const float *src0 = (const float *) a.src0, *src1 = (const float *) a.src1;
     const float *W = (const float *) a.weights + (size_t) g * a.KH * a.KW * a.cin_b * a.cout_b + cq * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -34,8 +33,10 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvArgs a) {
         for (int kx = 0; kx < a.KW; ++kx) {
             const int ix = ox * a.stride - a.pad + kx;
             if (ix < 0 || ix >= a.Win) continue;
-            const size_t p0 = ((size_t) (n * Hs0 + (a.up0 ? iy >> 1 : iy)) * Ws0 + (a.up0 ? ix >> 1 : ix)) * a.c0_stride;
-            const size_t p1 = ((size_t) (n * Hs1 + (a.up1 ? iy >> 1 : iy)) * Ws1 + (a.up1 ? ix >> 1 : ix)) * a.c1_stride;
+            const int y0 = a.up0 ? nearest_src(iy, a.sy0, Hs0) : iy, x0 = a.up0 ? nearest_src(ix, a.sx0, Ws0) : ix;
+            const int y1 = a.up1 ? nearest_src(iy, a.sy1, Hs1) : iy, x1 = a.up1 ? nearest_src(ix, a.sx1, Ws1) : ix;
+            const size_t p0 = ((size_t) (n * Hs0 + y0) * Ws0 + x0) * a.c0_stride;
+            const size_t p1 = ((size_t) (n * Hs1 + y1) * Ws1 + x1) * a.c1_stride;
             const float *wt = W + (size_t) (ky * a.KW + kx) * a.cin_b * a.cout_b;
             for (int c = 0; c < a.cin_b; c += 4) {
                 const int cin = g * a.cin_b + c;
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvArgs a) {
     if (a.out_mode == OUT_BF16_NHWC) {  // (fp32 NHWC in this precision)
         if (a.res) {
             size_t rpix = pix;
-            if (a.res_up) rpix = ((size_t) n * (a.Hout >> 1) + (oy >> 1)) * (a.Wout >> 1) + (ox >> 1);
+            if (a.res_up) rpix = ((size_t) n * a.Hr + nearest_src(oy, a.ry, a.Hr)) * a.Wr + nearest_src(ox, a.rx, a.Wr);
             const float4 r = *(const float4 *) ((const float *) a.res + rpix * a.res_stride + co);
             v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
         }

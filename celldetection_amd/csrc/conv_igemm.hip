@@ -29,6 +29,7 @@
 //   * grouped convs (ResNeXt cardinality 32) run as independent dense "bundles" (grid.z) of >=32 channels with
 //     block-diagonal packed weights.
 #include <algorithm>
+#include <atomic>
 
 #include "cpn_kernels.h"
 
@@ -152,6 +153,7 @@ struct Cfg {
 
 struct HaloGeo {
     int n, iy0, ix0, sub, Hin, Win, Hs0, Ws0, Hs1, Ws1, up0, up1, c0_stride, c1_stride, HH, HWreal;
+    float sy0, sx0, sy1, sx1;
 };
 
 // source element offsets (src0 / src1 variants; -1 = zero padding) of this lane's 16 B of halo DMA instruction q:
@@ -167,8 +169,8 @@ __device__ __forceinline__ void halo_src_offsets(const HaloGeo &G, int q, int la
     o0 = -1;
     o1 = -1;
     if (valid) {
-        const int y0 = G.up0 ? (iy >> 1) : iy, x0 = G.up0 ? (ix >> 1) : ix;
-        const int y1 = G.up1 ? (iy >> 1) : iy, x1 = G.up1 ? (ix >> 1) : ix;
+        const int y0 = G.up0 ? nearest_src(iy, G.sy0, G.Hs0) : iy, x0 = G.up0 ? nearest_src(ix, G.sx0, G.Ws0) : ix;
+        const int y1 = G.up1 ? nearest_src(iy, G.sy1, G.Hs1) : iy, x1 = G.up1 ? nearest_src(ix, G.sx1, G.Ws1) : ix;
         o0 = ((G.n * G.Hs0 + y0) * G.Ws0 + x0) * G.c0_stride + part * EPP;
         o1 = ((G.n * G.Hs1 + y1) * G.Ws1 + x1) * G.c1_stride + part * EPP;
     }
@@ -185,8 +187,10 @@ __device__ __forceinline__ void ds_read16(frag_t &d, unsigned addr) {
 }
 template <int N, int WN, int WM>
 __device__ __forceinline__ void wait_frags(frag_t (&w)[WN], frag_t (&p)[WM]) {
-    static_assert((WN == 2 && (WM == 4 || WM == 2 || WM == 1)) || (WN == 1 && (WM == 2 || WM == 1)), "frag shape");
-    if constexpr (WN == 2 && WM == 4)
+    static_assert((WN == 4 && WM == 4) || (WN == 2 && (WM == 4 || WM == 2 || WM == 1)) || (WN == 1 && (WM == 2 || WM == 1)), "frag shape");
+    if constexpr (WN == 4 && WM == 4)
+        asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]) : "n"(N));
+    else if constexpr (WN == 2 && WM == 4)
         asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(w[0]), "+v"(w[1]), "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]) : "n"(N));
     else if constexpr (WN == 2 && WM == 2)
         asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(w[0]), "+v"(w[1]), "+v"(p[0]), "+v"(p[1]) : "n"(N));
@@ -200,7 +204,9 @@ __device__ __forceinline__ void wait_frags(frag_t (&w)[WN], frag_t (&p)[WM]) {
 // step boundary: all my DMA landed + all my LDS reads returned (fragment set named "+v" as above)
 template <int WN, int WM>
 __device__ __forceinline__ void wait_all(frag_t (&w)[WN], frag_t (&p)[WM]) {
-    if constexpr (WN == 2 && WM == 4)
+    if constexpr (WN == 4 && WM == 4)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]) :: "memory");
+    else if constexpr (WN == 2 && WM == 4)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]) :: "memory");
     else if constexpr (WN == 2 && WM == 2)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(p[0]), "+v"(p[1]) :: "memory");
@@ -215,6 +221,10 @@ template <int WN, int WM, int FRAG_STRIDE>
 __device__ __forceinline__ void load_frags(frag_t (&w)[WN], frag_t (&p)[WM], unsigned paddr, unsigned waddr) {
     ds_read16<0>(w[0], waddr);
     if constexpr (WN > 1) ds_read16<32 * REC>(w[1], waddr);
+    if constexpr (WN > 2) {
+        ds_read16<64 * REC>(w[2], waddr);
+        ds_read16<96 * REC>(w[3], waddr);
+    }
     ds_read16<0>(p[0], paddr);
     if constexpr (WM > 1) ds_read16<FRAG_STRIDE>(p[1], paddr);
     if constexpr (WM > 2) {
@@ -278,13 +288,9 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     const int nhb = pw ? 4 : (nchunks > 1 ? 2 : 1);   // halo ring size (chunk c lives in buffer c & (nhb-1))
     const int nhb_mask = nhb - 1;
     const int nreal = nchunks * ntaps;                // flattened K items; a pipeline step covers two of them
-#if CPN_FP8
     const int nitems = nreal + (nreal & 1);           // + one all-zero weight slab: every step holds two items
-#else
-    const int nitems = nreal;
-#endif
-    const int nsteps = (nitems + 1) >> 1;             // (only the very last step may hold a single item; the fp8
-                                                      // weight blob pads an odd item count with one all-zero slab)
+    const int nsteps = nitems >> 1;                   // (the packer pads an odd item count with an all-zero slab, so
+                                                      // the K loop has no conditional tail)
     const int cout_b = a.cout_b;
     const int cin0 = g * a.cin_b;
     const int c0_used = a.c0_used;
@@ -297,8 +303,8 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     G.n = n; G.iy0 = oy0 * (PW ? a.stride : S) - a.pad; G.ix0 = ox0 * (PW ? a.stride : S) - a.pad;
     G.Hin = a.Hin; G.Win = a.Win;
     G.up0 = a.up0; G.up1 = a.up1;
-    G.Hs0 = a.up0 ? (a.Hin >> 1) : a.Hin; G.Ws0 = a.up0 ? (a.Win >> 1) : a.Win;
-    G.Hs1 = a.up1 ? (a.Hin >> 1) : a.Hin; G.Ws1 = a.up1 ? (a.Win >> 1) : a.Win;
+    G.Hs0 = a.Hs0; G.Ws0 = a.Ws0; G.Hs1 = a.Hs1; G.Ws1 = a.Ws1;
+    G.sy0 = a.sy0; G.sx0 = a.sx0; G.sy1 = a.sy1; G.sx1 = a.sx1;
     G.c0_stride = a.c0_stride; G.c1_stride = a.c1_stride; G.HH = HH; G.HWreal = (TW - 1) * S + KW;
 
     // halo DMA instruction q (0..hinstr) is issued by wave q % NWAVES; the source offsets are recomputed per issue
@@ -367,12 +373,12 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
             if (a_ok[it]) dma16(base_ + a_voff[it], dstb_ + ((wave + it * C::NWAVES) << 10));                  \
     }
 
-    // stages the weights of the next step in order (TWO: it has a second item) into weight buffer BUF
-#define W_DMA(TWO, BUF)                                                                                        \
+    // stages the (two) weight slabs of the next step in order into weight buffer BUF
+#define W_DMA(BUF)                                                                                             \
     {                                                                                                          \
         const unsigned char *s0_ = wptr, *s1_ = wptr + item_bytes;                                             \
         _Pragma("unroll") for (int it = 0; it < C::W_INSTR_WAVE; ++it)                                         \
-            if (!w_k[it] || (TWO)) dma16((w_k[it] ? s1_ : s0_) + w_voff[it], smem + w_m0[it] + (BUF) * WBUF);  \
+            dma16((w_k[it] ? s1_ : s0_) + w_voff[it], smem + w_m0[it] + (BUF) * WBUF);                         \
         wptr += 2 * item_bytes;                                                                                \
     }
 
@@ -438,7 +444,6 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     {                                                                                                          \
         const int idx2_ = 2 * (ST1) + 2; /* first item of step ST1+1 */                                        \
         if (idx2_ < nitems) {                                                                                  \
-            const bool two_nn_ = idx2_ + 1 < nitems;                                                           \
             if (pw_fast) {                                                                                     \
                 if (idx2_ < nreal) CPN_EXP_H(PW_HALO_DMA(idx2_));                                              \
                 if (idx2_ + 1 < nreal) CPN_EXP_H(PW_HALO_DMA(idx2_ + 1));                                      \
@@ -446,7 +451,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
                 if (idx2_ < nreal) CPN_EXP_H(HALO_DMA(idx2_));                                                 \
                 if (idx2_ + 1 < nreal) CPN_EXP_H(HALO_DMA(idx2_ + 1));                                         \
             }                                                                                                  \
-            CPN_EXP_W(W_DMA(two_nn_, ((ST1) + 1) & 1));                                                        \
+            CPN_EXP_W(W_DMA(((ST1) + 1) & 1));                                                                 \
         }                                                                                                      \
         /* KxK: every chunk before IA.c is completely consumed -> its ring buffer can take chunk IA.c+1 */     \
         if (!pw && (CHUNK_CHANGED) && (IA).c + 1 < nchunks) CPN_EXP_H(HALO_DMA((IA).c + 1));                   \
@@ -458,7 +463,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     // ---- prologue: stage step 0, open it, stage step 1, first fragment reads
     HALO_DMA(0);
     if (pw && nchunks > 1) HALO_DMA(1);
-    W_DMA(nitems > 1, 0);
+    W_DMA(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     ISSUE_AT_TRANSITION(i0, 0, true);
@@ -544,17 +549,15 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
         i0 = n0i;
         i1 = next_item(n0i, KH, KW);
     }
-    // last step: two items unless the item count is odd
+    // last step (two items: an odd item count was padded with a zero slab)
     LOAD_GROUP(wB, pB, pa ^ 32u, wa ^ 32u);
     MMA_GROUP(wA, pA, NF);
-    if (!(nitems & 1)) {
-        pa = ITEM_PADDR(i1.c, i1.ky, i1.kx);
-        wa += WITEM;
-        LOAD_GROUP(wA, pA, pa, wa);
-        MMA_GROUP(wB, pB, NF);
-        LOAD_GROUP(wB, pB, pa ^ 32u, wa ^ 32u);
-        MMA_GROUP(wA, pA, NF);
-    }
+    pa = ITEM_PADDR(i1.c, i1.ky, i1.kx);
+    wa += WITEM;
+    LOAD_GROUP(wA, pA, pa, wa);
+    MMA_GROUP(wB, pB, NF);
+    LOAD_GROUP(wB, pB, pa ^ 32u, wa ^ 32u);
+    MMA_GROUP(wA, pA, NF);
     MMA_GROUP(wB, pB, 0);
 #endif
 #undef HALO_DMA
@@ -688,7 +691,8 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
                 const size_t pix = ((size_t) n * a.Hout + oy) * a.Wout + ox;
                 if (a.res) {
                     size_t rpix = pix;
-                    if (a.res_up) rpix = ((size_t) n * (a.Hout >> 1) + (oy >> 1)) * (a.Wout >> 1) + (ox >> 1);
+                    if (a.res_up)
+                        rpix = ((size_t) n * a.Hr + nearest_src(oy, a.ry, a.Hr)) * a.Wr + nearest_src(ox, a.rx, a.Wr);
                     add_res8(v, *(const store8_t *) ((const elem_t *) a.res + rpix * a.res_stride + co), a.res_scale);
                 }
                 if (a.act == ACT_RELU) {
@@ -817,18 +821,23 @@ static size_t lds_bytes(const ConvArgs &a, int TH, int BN) {
 static size_t staging_bytes(int nwaves, int WN) { return (size_t) nwaves * 32 * (WN * 32 * 4 + 16); }
 
 constexpr size_t LDS_MAX = 160 * 1024;
+constexpr int MAX_DEVICES = 64;
 
 template <int TH, int BN, int WM, int WN, int MODE>
 static int launch_mode(const ConvArgs &a, hipStream_t stream) {
     using C = Cfg<TH, BN, WM, WN>;
     size_t lds = std::max(lds_bytes(a, TH, BN), staging_bytes(C::NWAVES, WN));
     if (a.out_mode == OUT_FUSED_HEAD) lds = std::max(lds, (size_t) TH * 32 * BN * 2);
-    static bool attr_set = false;
+    // the dynamic-LDS limit is a per-device function attribute: remember it per device ordinal (atomic flags: plans of
+    // different devices / host threads may launch the same instantiation concurrently)
+    static std::atomic<bool> attr_set[MAX_DEVICES];
     auto kern = conv_igemm_kernel<TH, BN, WM, WN, MODE>;
-    if (!attr_set) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return (int) hipErrorInvalidDevice;
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) LDS_MAX);
         if (e != hipSuccess) return (int) e;
-        attr_set = true;
+        attr_set[dev].store(true, std::memory_order_release);
     }
     const int tiles_x = (a.Wout + TW - 1) / TW, tiles_y = (a.Hout + TH - 1) / TH;
     dim3 grid((unsigned) (tiles_x * tiles_y * a.N), (unsigned) ((a.cout_b + BN - 1) / BN), (unsigned) a.bundles);
@@ -878,7 +887,11 @@ int launch_conv(const ConvArgs &a, hipStream_t stream) {
     if (c.TH == 16) return launch_cfg<16, 64, 2, 2>(a, stream);
     if (c.TH == 8) {
         switch (c.BN) {
+#ifdef CPN_EXP_W44
+            case 256: return launch_cfg<8, 256, 4, 4>(a, stream);
+#else
             case 256: return launch_cfg<8, 256, 4, 2>(a, stream);
+#endif
             case 128: return launch_cfg<8, 128, 2, 2>(a, stream);
             case 64: return launch_cfg<8, 64, 2, 2>(a, stream);
             default: return launch_cfg<8, 32, 2, 1>(a, stream);

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -31,8 +32,13 @@ int check_hip(hipError_t e, const char *where) {
 }
 
 struct ShapePlan {
-    std::vector<int64_t> offsets;  // per tensor
+    std::vector<int64_t> offsets;  // per tensor (arena byte offsets)
+    std::vector<int> th, tw;       // per tensor spatial size for this input size (propagated op by op: any H x W)
+    int out_h[CPN_NUM_OUTPUTS], out_w[CPN_NUM_OUTPUTS];  // sizes of the external fp32 outputs (0 = absent)
     int64_t total = 0;
+    int64_t max_elems = 0;         // largest tensor of the graph, elements per image
+    int error = 0;                 // CPN_E_* when the graph cannot run at this input size
+    std::string message;
 };
 
 }  // namespace cpn
@@ -45,44 +51,100 @@ struct cpn_plan {
     const float *bias = nullptr;
     size_t bias_count = 0;
     int precision = 0;  // CPN_PRECISION_BF16 / CPN_PRECISION_F32 / CPN_PRECISION_FP8
-    std::map<std::tuple<int, int, int>, cpn::ShapePlan> shape_plans;
+    std::map<std::tuple<int, int, int>, cpn::ShapePlan> shape_plans;  // guarded by shape_mutex (std::map nodes are
+    std::mutex shape_mutex;                                            // stable: returned references stay valid)
 };
 
 namespace cpn {
 
-static int64_t tensor_bytes(const cpn_tensor_desc &t, int N, int H, int W, int elem = 2) {
-    const int64_t b = (int64_t) N * (H / t.down) * (W / t.down) * t.channels * elem;
+static int64_t tensor_bytes(const cpn_tensor_desc &t, int N, int h, int w, int elem) {
+    const int64_t b = (int64_t) N * h * w * t.channels * elem;
     return (b + 255) / 256 * 256;
 }
 
+// Spatial sizes of every tensor for an H x W input, following the reference's modules: conv / max-pool output
+// size = floor((in + 2p - k) / s) + 1; a nearest-resized source takes the size of the other concat source
+// (F.interpolate(size=lateral.shape), models/unet.py:213-217, torchvision FPN) or, without one, twice its own size
+// (scale_factor=2, bridge levels); CPN_OP_BILINEAR resizes to the INPUT size (_equal_size(features, inputs),
+// models/cpn.py:277-278) and is a no-op alias when the sizes already agree.
+static void propagate_dims(const cpn_plan *p, int H, int W, ShapePlan &sp) {
+    const int nt = (int) p->tensors.size();
+    sp.th.assign(nt, 0);
+    sp.tw.assign(nt, 0);
+    for (int i = 0; i < CPN_NUM_OUTPUTS; ++i) sp.out_h[i] = sp.out_w[i] = 0;
+    auto bad = [&](const char *m) { sp.error = CPN_E_INVALID; sp.message = m; };
+    for (const cpn_op_desc &o : p->ops) {
+        if (sp.error) return;
+        switch (o.op) {
+            case CPN_OP_INPUT: sp.th[o.dst] = H; sp.tw[o.dst] = W; break;
+            case CPN_OP_MAXPOOL:
+                sp.th[o.dst] = (sp.th[o.src0] + 2 * o.pad - o.kh) / o.stride + 1;
+                sp.tw[o.dst] = (sp.tw[o.src0] + 2 * o.pad - o.kw) / o.stride + 1;
+                if (sp.th[o.src0] + 2 * o.pad < o.kh || sp.tw[o.src0] + 2 * o.pad < o.kw) bad("input too small for the max-pool");
+                break;
+            case CPN_OP_BILINEAR: sp.th[o.dst] = H; sp.tw[o.dst] = W; break;
+            case CPN_OP_CONV: {
+                int hv, wv;
+                if (o.up0 && o.up1) { bad("conv: both sources resized"); break; }
+                if (o.up1) { hv = sp.th[o.src0]; wv = sp.tw[o.src0]; }
+                else if (o.up0 && o.src1 >= 0) { hv = sp.th[o.src1]; wv = sp.tw[o.src1]; }
+                else if (o.up0) { hv = 2 * sp.th[o.src0]; wv = 2 * sp.tw[o.src0]; }
+                else {
+                    hv = sp.th[o.src0]; wv = sp.tw[o.src0];
+                    if (o.src1 >= 0 && (sp.th[o.src1] != hv || sp.tw[o.src1] != wv)) { bad("conv: concat sources differ in size"); break; }
+                }
+                if (hv + 2 * o.pad < o.kh || wv + 2 * o.pad < o.kw) { bad("input too small for a convolution of the graph"); break; }
+                const int ho = (hv + 2 * o.pad - o.kh) / o.stride + 1, wo = (wv + 2 * o.pad - o.kw) / o.stride + 1;
+                if (o.res >= 0 && !o.res_up && (sp.th[o.res] != ho || sp.tw[o.res] != wo)) { bad("conv: residual size mismatch"); break; }
+                if (o.dst >= 0) { sp.th[o.dst] = ho; sp.tw[o.dst] = wo; }
+                else if (o.out_index >= 0 && o.out_index < CPN_NUM_OUTPUTS) { sp.out_h[o.out_index] = ho; sp.out_w[o.out_index] = wo; }
+                break;
+            }
+            default: bad("unknown op");
+        }
+    }
+    for (int t = 0; t < nt && !sp.error; ++t) {
+        if (sp.th[t] < 0 || sp.tw[t] < 0) bad("negative tensor size");
+        sp.max_elems = std::max(sp.max_elems, (int64_t) sp.th[t] * sp.tw[t] * p->tensors[t].channels);
+    }
+}
+
 static const ShapePlan &get_shape_plan(cpn_plan *p, int N, int H, int W) {
+    std::lock_guard<std::mutex> lock(p->shape_mutex);
     auto key = std::make_tuple(N, H, W);
     auto it = p->shape_plans.find(key);
     if (it != p->shape_plans.end()) return it->second;
+    ShapePlan sp;
+    propagate_dims(p, H, W, sp);
     const int nt = (int) p->tensors.size();
+    sp.offsets.assign(nt, -1);
+    if (sp.error) return p->shape_plans.emplace(key, std::move(sp)).first->second;
+    // a bilinear op whose source already has the input size is an alias (no kernel, shared storage)
+    std::vector<int> root(nt);
+    for (int t = 0; t < nt; ++t) root[t] = t;
+    for (const cpn_op_desc &o : p->ops)
+        if (o.op == CPN_OP_BILINEAR && sp.th[o.src0] == sp.th[o.dst] && sp.tw[o.src0] == sp.tw[o.dst]) root[o.dst] = root[o.src0];
     std::vector<int> def(nt, -1), last(nt, -1);
     for (int i = 0; i < (int) p->ops.size(); ++i) {
         const cpn_op_desc &o = p->ops[i];
-        if (o.dst >= 0 && def[o.dst] < 0) def[o.dst] = i;
-        for (int s : {o.src0, o.src1, o.res})
-            if (s >= 0) last[s] = std::max(last[s], i);
-        if (o.dst >= 0) last[o.dst] = std::max(last[o.dst], i);
+        if (o.dst >= 0 && def[root[o.dst]] < 0) def[root[o.dst]] = i;
+        for (int s_ : {o.src0, o.src1, o.res})
+            if (s_ >= 0) last[root[s_]] = std::max(last[root[s_]], i);
+        if (o.dst >= 0) last[root[o.dst]] = std::max(last[root[o.dst]], i);
     }
-    ShapePlan sp;
-    sp.offsets.assign(nt, -1);
     std::vector<int> order;
     for (int t = 0; t < nt; ++t)
-        if (def[t] >= 0) order.push_back(t);
+        if (root[t] == t && def[t] >= 0) order.push_back(t);
     std::sort(order.begin(), order.end(), [&](int a, int b) { return def[a] < def[b]; });
+    const int elem = p->precision == CPN_PRECISION_F32 ? 4 : (p->precision == CPN_PRECISION_FP8 ? 1 : 2);
     std::vector<int> placed;
     for (int t : order) {
-        const int elem = p->precision == CPN_PRECISION_F32 ? 4 : (p->precision == CPN_PRECISION_FP8 ? 1 : 2);
-        const int64_t sz = tensor_bytes(p->tensors[t], N, H, W, elem);
+        const int64_t sz = tensor_bytes(p->tensors[t], N, sp.th[t], sp.tw[t], elem);
         // candidate offsets: 0 and the end of every conflicting placed tensor; take the lowest that fits
         std::vector<std::pair<int64_t, int64_t>> busy;  // [begin, end) of live-overlapping tensors
         for (int q : placed)
             if (!(last[q] < def[t] || last[t] < def[q]))
-                busy.emplace_back(sp.offsets[q], sp.offsets[q] + tensor_bytes(p->tensors[q], N, H, W, elem));
+                busy.emplace_back(sp.offsets[q], sp.offsets[q] + tensor_bytes(p->tensors[q], N, sp.th[q], sp.tw[q], elem));
         std::sort(busy.begin(), busy.end());
         int64_t off = 0;
         for (auto &b : busy) {
@@ -93,6 +155,8 @@ static const ShapePlan &get_shape_plan(cpn_plan *p, int N, int H, int W) {
         sp.total = std::max(sp.total, off + sz);
         placed.push_back(t);
     }
+    for (int t = 0; t < nt; ++t)
+        if (root[t] != t) sp.offsets[t] = sp.offsets[root[t]];
     return p->shape_plans.emplace(key, std::move(sp)).first->second;
 }
 
@@ -100,15 +164,24 @@ struct Dims {
     int h, w;
 };
 
-static int build_conv_args(const cpn_plan *p, const cpn_op_desc &o, int N, int H, int W, ConvArgs &a, const void *s0,
+// Hin x Win: virtual (post-resize) input size.  src_dims (optional): stored sizes {Hs0, Ws0, Hs1, Ws1, Hr, Wr} of the
+// two sources and the residual; without it a resized source / residual is an exact x2 (the stand-alone cpn_conv2d).
+static int build_conv_args(const cpn_plan *p, const cpn_op_desc &o, int N, ConvArgs &a, const void *s0,
                            int c0s, const void *s1, int c1s, const void *res, int rs, void *dst, int ds, int Hin,
-                           int Win) {
-    (void) H; (void) W;
+                           int Win, const int *src_dims = nullptr) {
     a = ConvArgs{};
     a.src0 = s0; a.src1 = s1; a.c0_stride = c0s; a.c1_stride = c1s;
     a.c0_used = o.c0_used;
     a.up0 = o.up0; a.up1 = o.up1;
     a.N = N; a.Hin = Hin; a.Win = Win;
+    a.Hs0 = src_dims ? src_dims[0] : (o.up0 ? Hin >> 1 : Hin); a.Ws0 = src_dims ? src_dims[1] : (o.up0 ? Win >> 1 : Win);
+    a.Hs1 = src_dims ? src_dims[2] : (o.up1 ? Hin >> 1 : Hin); a.Ws1 = src_dims ? src_dims[3] : (o.up1 ? Win >> 1 : Win);
+    if (!o.up0) { a.Hs0 = Hin; a.Ws0 = Win; }
+    if (!o.up1) { a.Hs1 = Hin; a.Ws1 = Win; }
+    if (Hin <= 0 || Win <= 0 || a.Hs0 <= 0 || a.Ws0 <= 0 || (s1 && (a.Hs1 <= 0 || a.Ws1 <= 0)))
+        return fail(CPN_E_INVALID, "conv: empty input");
+    a.sy0 = (float) a.Hs0 / (float) Hin; a.sx0 = (float) a.Ws0 / (float) Win;
+    a.sy1 = (float) a.Hs1 / (float) Hin; a.sx1 = (float) a.Ws1 / (float) Win;
     a.KH = o.kh; a.KW = o.kw; a.stride = o.stride; a.pad = o.pad;
     a.Hout = (Hin + 2 * o.pad - o.kh) / o.stride + 1;
     a.Wout = (Win + 2 * o.pad - o.kw) / o.stride + 1;
@@ -116,6 +189,10 @@ static int build_conv_args(const cpn_plan *p, const cpn_op_desc &o, int N, int H
     a.weights = p ? p->weights + o.weight_offset : nullptr;
     a.bias = (p && o.bias_offset >= 0) ? p->bias + o.bias_offset : nullptr;
     a.res = res; a.res_stride = rs; a.res_up = o.res_up;
+    a.Hr = (src_dims && o.res_up) ? src_dims[4] : (o.res_up ? a.Hout >> 1 : a.Hout);
+    a.Wr = (src_dims && o.res_up) ? src_dims[5] : (o.res_up ? a.Wout >> 1 : a.Wout);
+    if (res && (a.Hr <= 0 || a.Wr <= 0)) return fail(CPN_E_INVALID, "conv: empty residual");
+    a.ry = (float) a.Hr / (float) a.Hout; a.rx = (float) a.Wr / (float) a.Wout;
     a.act = o.act; a.act_scale = o.act_scale;
     a.out_mode = o.dst >= 0 ? OUT_BF16_NHWC : (o.fuse_cout > 0 ? OUT_FUSED_HEAD : OUT_F32_NCHW);
     if (o.fuse_cout > 0) {
@@ -135,7 +212,8 @@ static int build_conv_args(const cpn_plan *p, const cpn_op_desc &o, int N, int H
     }
     if (o.bundles > 1 && s1) return fail(CPN_E_INVALID, "conv: grouped conv with two sources");
     if (!s1 && o.c0_used < o.bundles * o.cin_b) return fail(CPN_E_INVALID, "conv: c0_used smaller than input channels");
-    if ((int64_t) N * Hin * Win * std::max(c0s, c1s) >= (1ll << 31) || (int64_t) N * a.Hout * a.Wout * std::max(ds, 1) >= (1ll << 31))
+    if ((int64_t) N * a.Hs0 * a.Ws0 * c0s >= (1ll << 31) || (s1 && (int64_t) N * a.Hs1 * a.Ws1 * c1s >= (1ll << 31)) ||
+        (int64_t) N * a.Hout * a.Wout * std::max(ds, 1) >= (1ll << 31))
         return fail(CPN_E_UNSUPPORTED, "conv: tensor exceeds 2^31 elements (32-bit offsets)");
     // plain 1x1 convs are GEMMs over the flattened pixel axis: re-tile as [1, M/32, 32] so that narrow images
     // (16x16 at stride 32) still fill the 32-pixel MFMA column fragments
@@ -143,7 +221,7 @@ static int build_conv_args(const cpn_plan *p, const cpn_op_desc &o, int N, int H
         a.out_mode == OUT_BF16_NHWC) {
         const int64_t M = (int64_t) N * Hin * Win;
         if (M % 32 == 0) {
-            a.N = 1; a.Hin = a.Hout = (int) (M / 32); a.Win = a.Wout = 32;
+            a.N = 1; a.Hin = a.Hout = a.Hs0 = a.Hs1 = a.Hr = (int) (M / 32); a.Win = a.Wout = a.Ws0 = a.Ws1 = a.Wr = 32;
         }
     }
     return 0;
@@ -186,7 +264,11 @@ int cpn_plan_create(cpn_plan **plan, const cpn_tensor_desc *tensors, int32_t n_t
                 return fail(CPN_E_INVALID, "cpn_plan_create: tensor id out of range");
             }
         if (o.op == CPN_OP_CONV) {
-            size_t wbytes = (size_t) o.bundles * o.cin_b * o.kh * o.kw * o.cout_b * (precision == CPN_PRECISION_F32 ? 4 : 2);
+            size_t wbytes = (size_t) o.bundles * o.cin_b * o.kh * o.kw * o.cout_b * 4;  // fp32 verification layout
+            if (precision == CPN_PRECISION_BF16) {  // [bundle][items (+1 zero slab if odd)][cout_b][32] bf16
+                const size_t items = (size_t) (o.cin_b / 32) * o.kh * o.kw;
+                wbytes = (size_t) o.bundles * (items + (items & 1)) * o.cout_b * 64;
+            }
             if (precision == CPN_PRECISION_FP8) {  // [bundle][items (+1 zero slab if odd)][cout_b][64] bytes
                 const size_t items = (size_t) (o.cin_b / 64) * o.kh * o.kw;
                 wbytes = (size_t) o.bundles * (items + (items & 1)) * o.cout_b * 64;
@@ -213,20 +295,42 @@ int cpn_plan_create(cpn_plan **plan, const cpn_tensor_desc *tensors, int32_t n_t
 void cpn_plan_destroy(cpn_plan *plan) { delete plan; }
 
 int64_t cpn_plan_workspace_bytes(cpn_plan *plan, int32_t N, int32_t H, int32_t W) {
-    if (!plan || N <= 0 || H <= 0 || W <= 0 || H % 32 || W % 32) {
-        fail(CPN_E_INVALID, "cpn_plan_workspace_bytes: H and W must be positive multiples of 32");
+    if (!plan || N <= 0 || H <= 0 || W <= 0) {
+        fail(CPN_E_INVALID, "cpn_plan_workspace_bytes: N, H and W must be positive");
         return CPN_E_INVALID;
     }
-    return get_shape_plan(plan, N, H, W).total;
+    const ShapePlan &sp = get_shape_plan(plan, N, H, W);
+    if (sp.error) return fail(sp.error, sp.message.c_str());
+    return sp.total;
+}
+
+int cpn_plan_output_dims(cpn_plan *plan, int32_t H, int32_t W, int32_t out_index, int32_t *h, int32_t *w) {
+    if (!plan || H <= 0 || W <= 0 || out_index < 0 || out_index >= CPN_NUM_OUTPUTS || !h || !w)
+        return fail(CPN_E_INVALID, "cpn_plan_output_dims: bad arguments");
+    const ShapePlan &sp = get_shape_plan(plan, 1, H, W);
+    if (sp.error) return fail(sp.error, sp.message.c_str());
+    *h = sp.out_h[out_index];
+    *w = sp.out_w[out_index];
+    return 0;
+}
+
+int64_t cpn_plan_max_tensor_elements(cpn_plan *plan, int32_t H, int32_t W) {
+    if (!plan || H <= 0 || W <= 0) {
+        fail(CPN_E_INVALID, "cpn_plan_max_tensor_elements: bad arguments");
+        return CPN_E_INVALID;
+    }
+    const ShapePlan &sp = get_shape_plan(plan, 1, H, W);
+    if (sp.error) return fail(sp.error, sp.message.c_str());
+    return sp.max_elems;
 }
 
 static int run_or_count(cpn_plan *plan, const void *input, int32_t in_dtype, int32_t N, int32_t H, int32_t W,
                         void *workspace, int64_t workspace_bytes, float *const *outputs, int32_t *range_flag,
                         hipStream_t st, double *flops, hipEvent_t *events = nullptr, double *op_flops = nullptr,
                         float *absmax = nullptr) {
-    if (!plan || N <= 0 || H <= 0 || W <= 0 || H % 32 || W % 32)
-        return fail(CPN_E_INVALID, "cpn_plan_run: H and W must be positive multiples of 32");
+    if (!plan || N <= 0 || H <= 0 || W <= 0) return fail(CPN_E_INVALID, "cpn_plan_run: N, H and W must be positive");
     const ShapePlan &sp = get_shape_plan(plan, N, H, W);
+    if (sp.error) return fail(sp.error, sp.message.c_str());
     if (!flops && sp.total > workspace_bytes) return fail(CPN_E_WORKSPACE, "cpn_plan_run: workspace too small");
     const bool f32 = plan->precision == CPN_PRECISION_F32, fp8 = plan->precision == CPN_PRECISION_FP8;
     if (absmax && plan->precision != CPN_PRECISION_BF16) return fail(CPN_E_INVALID, "cpn_plan_run_stats: bf16 plans only");
@@ -248,31 +352,37 @@ static int run_or_count(cpn_plan *plan, const void *input, int32_t in_dtype, int
             }
             case CPN_OP_MAXPOOL: {
                 if (flops) break;
-                const int din = plan->tensors[o.src0].down, dout = plan->tensors[o.dst].down;
-                PoolArgs a{tptr(o.src0), tptr(o.dst), N, H / din, W / din, H / dout, W / dout, tch(o.src0), o.kh, o.stride, o.pad};
+                PoolArgs a{tptr(o.src0), tptr(o.dst), N, sp.th[o.src0], sp.tw[o.src0], sp.th[o.dst], sp.tw[o.dst],
+                           tch(o.src0), o.kh, o.stride, o.pad};
                 rc = check_hip((hipError_t) (f32 ? launch_maxpool_f32(a, st) : fp8 ? launch_maxpool_fp8(a, st)
                                                                                   : launch_maxpool(a, st)), "maxpool kernel");
                 break;
             }
             case CPN_OP_BILINEAR: {
                 if (flops) break;
-                const int din = plan->tensors[o.src0].down, dout = plan->tensors[o.dst].down;
-                ResizeArgs a{tptr(o.src0), tptr(o.dst), N, H / din, W / din, H / dout, W / dout, tch(o.src0)};
+                if (sp.offsets[o.src0] == sp.offsets[o.dst]) break;  // same size: the planner aliased dst to src
+                ResizeArgs a{tptr(o.src0), tptr(o.dst), N, sp.th[o.src0], sp.tw[o.src0], sp.th[o.dst], sp.tw[o.dst],
+                             tch(o.src0)};
                 rc = check_hip((hipError_t) (f32 ? launch_bilinear_f32(a, st) : fp8 ? launch_bilinear_fp8(a, st)
                                                                                    : launch_bilinear(a, st)), "bilinear kernel");
                 break;
             }
             case CPN_OP_CONV: {
-                const int din = plan->tensors[o.src0].down;
-                const int Hin = (H / din) * (o.up0 ? 2 : 1), Win = (W / din) * (o.up0 ? 2 : 1);
+                int Hin, Win;  // virtual input size (see propagate_dims)
+                if (o.up1) { Hin = sp.th[o.src0]; Win = sp.tw[o.src0]; }
+                else if (o.up0 && o.src1 >= 0) { Hin = sp.th[o.src1]; Win = sp.tw[o.src1]; }
+                else if (o.up0) { Hin = 2 * sp.th[o.src0]; Win = 2 * sp.tw[o.src0]; }
+                else { Hin = sp.th[o.src0]; Win = sp.tw[o.src0]; }
+                const int sdims[6] = {sp.th[o.src0], sp.tw[o.src0], o.src1 >= 0 ? sp.th[o.src1] : 0,
+                                      o.src1 >= 0 ? sp.tw[o.src1] : 0, o.res >= 0 ? sp.th[o.res] : 0,
+                                      o.res >= 0 ? sp.tw[o.res] : 0};
                 void *dst = o.dst >= 0 ? tptr(o.dst) : (outputs ? (void *) outputs[o.out_index] : nullptr);
                 ConvArgs a;
-                rc = build_conv_args(plan, o, N, H, W, a, tptr(o.src0), tch(o.src0), tptr(o.src1), tch(o.src1),
-                                     tptr(o.res), tch(o.res), dst, o.dst >= 0 ? tch(o.dst) : 0, Hin, Win);
+                rc = build_conv_args(plan, o, N, a, tptr(o.src0), tch(o.src0), tptr(o.src1), tch(o.src1),
+                                     tptr(o.res), tch(o.res), dst, o.dst >= 0 ? tch(o.dst) : 0, Hin, Win, sdims);
                 if (rc) return rc;
                 if (o.dst >= 0) {
-                    const int dout = plan->tensors[o.dst].down;
-                    const int64_t M = (int64_t) N * (H / dout) * (W / dout);
+                    const int64_t M = (int64_t) N * sp.th[o.dst] * sp.tw[o.dst];
                     if ((int64_t) a.N * a.Hout * a.Wout != M) return fail(CPN_E_INVALID, "cpn_plan_run: conv output size mismatch");
                 }
                 if (op_flops) op_flops[i] = conv_executed_flops(a);
@@ -287,7 +397,7 @@ static int run_or_count(cpn_plan *plan, const void *input, int32_t in_dtype, int
         if (rc) return rc;
         if (absmax && o.dst >= 0) {  // calibration: max |x| of the tensor this op produced
             const cpn_tensor_desc &t = plan->tensors[o.dst];
-            const long count = (long) N * (H / t.down) * (W / t.down) * t.channels;
+            const long count = (long) N * sp.th[o.dst] * sp.tw[o.dst] * t.channels;
             rc = check_hip((hipError_t) launch_absmax_bf16(tptr(o.dst), count, absmax + o.dst, st), "absmax kernel");
             if (rc) return rc;
         }
@@ -340,7 +450,7 @@ int cpn_conv2d(const cpn_op_desc *op, const void *src0, int32_t c0_stride, const
                const void *weights, const float *bias, void *stream) {
     if (!op || !src0 || !dst || !weights) return fail(CPN_E_INVALID, "cpn_conv2d: null pointer");
     ConvArgs a;
-    int rc = build_conv_args(nullptr, *op, N, 0, 0, a, src0, c0_stride, src1, c1_stride, res, res_stride, dst,
+    int rc = build_conv_args(nullptr, *op, N, a, src0, c0_stride, src1, c1_stride, res, res_stride, dst,
                              dst_stride, Hin, Win);
     if (rc) return rc;
     a.weights = (const unsigned char *) weights + op->weight_offset;
@@ -360,7 +470,7 @@ int cpn_conv2d_fp8(const cpn_op_desc *op, const void *src0, int32_t c0_stride, c
     if (op->cin_b % 64 || op->c0_used % 64 || c0_stride % 64 || (src1 && c1_stride % 64))
         return fail(CPN_E_INVALID, "cpn_conv2d_fp8: input channel counts / strides must be multiples of 64");
     ConvArgs a;
-    int rc = build_conv_args(nullptr, *op, N, 0, 0, a, src0, c0_stride, src1, c1_stride, res, res_stride, dst,
+    int rc = build_conv_args(nullptr, *op, N, a, src0, c0_stride, src1, c1_stride, res, res_stride, dst,
                              dst_stride, Hin, Win);
     if (rc) return rc;
     a.weights = (const unsigned char *) weights + op->weight_offset;

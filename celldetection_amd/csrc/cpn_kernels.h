@@ -14,21 +14,26 @@ enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_TANH_SCALED = 
 
 struct ConvArgs {
     // sources (NHWC bf16).  The conv input is the virtual channel concat [src0 | src1]; a source flagged "up"
-    // is stored at half resolution and read through a nearest x2 upsample (index >> 1).
+    // is stored at its own resolution Hs x Ws and read through a nearest-neighbour resize to Hin x Win with
+    // PyTorch's 'nearest' index rule: src = min(floor(dst * (float(Hs) / Hin)), Hs - 1)  (== dst >> 1 for an exact x2)
     const void *src0, *src1;
     int c0_stride, c1_stride;   // channel stride (= padded channel count) of the source buffers
     int c0_used;                // channels of the virtual concat that come from src0 (multiple of 32)
     int up0, up1;
-    int N, Hin, Win;            // virtual (post-upsample) input size
+    int Hs0, Ws0, Hs1, Ws1;     // stored sizes of the sources (== Hin, Win when not resized)
+    float sy0, sx0, sy1, sx1;   // float(Hs) / Hin, float(Ws) / Win of the resized sources
+    int N, Hin, Win;            // virtual (post-resize) input size
     int Hout, Wout;
     int KH, KW, stride, pad;
     int bundles;                // grid.z: independent channel bundles (grouped conv); 1 for dense
     int cin_b, cout_b;          // channels per bundle (cin_b multiple of 32; cout_b multiple of 32)
-    const void *weights;        // [bundle][cin_b/32][KH*KW][cout_b][32] bf16
+    const void *weights;        // [bundle][cin_b/32 x KH*KW items (+1 zero item if odd)][cout_b][32] bf16
     const float *bias;          // [bundles*cout_b] fp32 (BN folded) or nullptr
     // epilogue
     const void *res;            // residual NHWC bf16 (added before activation) or nullptr
-    int res_stride, res_up;
+    int res_stride, res_up;     // res_up: stored at Hr x Wr, nearest-resized to Hout x Wout (FPN top-down path)
+    int Hr, Wr;
+    float ry, rx;               // float(Hr) / Hout, float(Wr) / Wout
     int act;
     float act_scale;
     int out_mode;
@@ -47,6 +52,12 @@ struct ConvArgs {
     const float *mult;
     float res_scale, out_inv_scale;
 };
+
+// PyTorch 'nearest' source index (upsample_nearest2d, legacy 'nearest' mode, size= given)
+__host__ __device__ inline int nearest_src(int dst, float scale, int in_size) {
+    const int s = (int) floorf((float) dst * scale);
+    return s < in_size - 1 ? s : in_size - 1;
+}
 
 // picks a tile configuration and launches; returns hipError_t as int
 int launch_conv(const ConvArgs &a, hipStream_t stream);

@@ -159,7 +159,7 @@ struct DecodeArgs {
     const float *scores, *locations, *fourier, *refinement;
     int32_t N, h, w, H, W, order_total, order, samples, iterations;
     const float *cos_t, *sin_t;
-    const int64_t *offsets;
+    const float *offsets;  // [N][2] xy; the reference adds int64 offsets to fp32 tensors = fp32 add of (float) offset
     float *contours, *proposals, *boxes, *out_scores, *out_locations, *out_fourier;
     int32_t *batch_index;
     Buckets bk;
@@ -191,8 +191,8 @@ __global__ __launch_bounds__(DWAVES *WAVE) void decode_kernel(const DecodeArgs a
     const float sx = (float) a.W / (float) a.w, sy = (float) a.H / (float) a.h;  // get_scale, ops/cpn.py:98-103
     float offx = 0.f, offy = 0.f;
     if (a.offsets) {
-        offx = (float) a.offsets[b * 2 + 0];
-        offy = (float) a.offsets[b * 2 + 1];
+        offx = a.offsets[b * 2 + 0];
+        offy = a.offsets[b * 2 + 1];
     }
     const bool do_refine = a.refinement != nullptr && a.iterations > 0;
     const float *ref_b = do_refine ? a.refinement + (size_t) b * 2 * (a.bk.n < 1 ? 1 : a.bk.n) * a.H * a.W : nullptr;
@@ -210,10 +210,18 @@ __global__ __launch_bounds__(DWAVES *WAVE) void decode_kernel(const DecodeArgs a
         mnx = fminf(mnx, cx); mny = fminf(mny, cy);
         mxx = fmaxf(mxx, cx); mxy = fmaxf(mxy, cy);
         const size_t o = ((size_t) p * a.samples + s) * 2;
-        a.contours[o] = __fadd_rn(cx, offx);
-        a.contours[o + 1] = __fadd_rn(cy, offy);
-        a.proposals[o] = __fadd_rn(px, offx);
-        a.proposals[o + 1] = __fadd_rn(py, offy);
+        float ox = __fadd_rn(cx, offx), oy = __fadd_rn(cy, offy);
+        float qx = __fadd_rn(px, offx), qy = __fadd_rn(py, offy);
+        if (!do_refine && a.offsets) {
+            // without refinement `selected_contours` IS `selected_contour_proposals` in the reference (cpn.py:655-656):
+            // the two in-place `+= offsets` (cpn.py:697-699) hit the one tensor twice; boxes/locations get it once
+            ox = __fadd_rn(ox, offx); oy = __fadd_rn(oy, offy);
+            qx = ox; qy = oy;
+        }
+        a.contours[o] = ox;
+        a.contours[o + 1] = oy;
+        a.proposals[o] = qx;
+        a.proposals[o + 1] = qy;
     }
     mnx = wave_min(mnx); mny = wave_min(mny);
     mxx = wave_max(mxx); mxy = wave_max(mxy);
@@ -280,6 +288,68 @@ __global__ __launch_bounds__(256) void border_kernel(const float *__restrict__ c
     }
     const bool all_ok = __all(ok);
     if (lane == 0) keep[p] = all_ok ? 1 : 0;
+}
+
+// all detections of a forwarded batch at once: contour p belongs to image img[p]; per-image tile parameters
+// (neighbour-side bit mask, xy offsets that are ADDED to the coordinates) come from device tables, so the slide loop
+// needs one launch per batch instead of one launch + boolean indexing per tile
+__global__ __launch_bounds__(256) void border_batched_kernel(const float *__restrict__ contours, long P, int samples,
+                                                            const int32_t *__restrict__ img,
+                                                            const int32_t *__restrict__ sides_tab,
+                                                            const float *__restrict__ off_tab, float h, float w,
+                                                            float pad, uint8_t *__restrict__ keep) {
+    const int lane = threadIdx.x & 63;
+    const long p = blockIdx.x * 4l + (threadIdx.x >> 6);
+    if (p >= P) return;
+    const int b = img[p];
+    const int sides = sides_tab[b];
+    const float offx = off_tab[2 * b], offy = off_tab[2 * b + 1];
+    bool ok = true;
+    for (int s = lane; s < samples; s += 64) {
+        const float x = __fadd_rn(contours[(p * samples + s) * 2], offx);
+        const float y = __fadd_rn(contours[(p * samples + s) * 2 + 1], offy);
+        if (sides & 1) ok = ok && (y > pad);
+        if (sides & 2) ok = ok && (x < __fsub_rn(w, pad));
+        if (sides & 4) ok = ok && (y < __fsub_rn(h, pad));
+        if (sides & 8) ok = ok && (x > pad);
+    }
+    const bool all_ok = __all(ok);
+    if (lane == 0) keep[p] = all_ok ? 1 : 0;
+}
+
+// fp32 NCHW bilinear resize, align_corners=False, of score-bound masks / head maps (`_equal_size`,
+// models/cpn.py:109-123,279): torch CPU's separable form out = (v00*wx0 + v01*wx1)*wy0 + (v10*wx0 + v11*wx1)*wy1 with
+// src = max(scale*(dst+0.5)-0.5, 0), scale = in/out, w1 = src - floor(src), w0 = 1 - w1; every product/sum rounded
+__global__ __launch_bounds__(256) void resize_f32_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                        long planes, int Hin, int Win, int Hout, int Wout) {
+    const long i = blockIdx.x * 256l + threadIdx.x;
+    const long total = planes * Hout * Wout;
+    if (i >= total) return;
+    const int ox = (int) (i % Wout);
+    const long t = i / Wout;
+    const int oy = (int) (t % Hout);
+    const long pl = t / Hout;
+    const float sy = (float) Hin / (float) Hout, sx = (float) Win / (float) Wout;
+    const float *p = src + pl * Hin * Win;
+    int y0 = oy, y1 = oy, x0 = ox, x1 = ox;
+    float wy0 = 1.f, wy1 = 0.f, wx0 = 1.f, wx1 = 0.f;
+    if (Hin != Hout) {
+        const float fy = fmaxf(__fsub_rn(__fmul_rn(sy, __fadd_rn((float) oy, 0.5f)), 0.5f), 0.f);
+        y0 = min((int) fy, Hin - 1);
+        y1 = y0 + (y0 < Hin - 1 ? 1 : 0);
+        wy1 = fminf(fmaxf(__fsub_rn(fy, (float) y0), 0.f), 1.f);
+        wy0 = __fsub_rn(1.f, wy1);
+    }
+    if (Win != Wout) {
+        const float fx = fmaxf(__fsub_rn(__fmul_rn(sx, __fadd_rn((float) ox, 0.5f)), 0.5f), 0.f);
+        x0 = min((int) fx, Win - 1);
+        x1 = x0 + (x0 < Win - 1 ? 1 : 0);
+        wx1 = fminf(fmaxf(__fsub_rn(fx, (float) x0), 0.f), 1.f);
+        wx0 = __fsub_rn(1.f, wx1);
+    }
+    const float ra = __fadd_rn(__fmul_rn(p[(long) y0 * Win + x0], wx0), __fmul_rn(p[(long) y0 * Win + x1], wx1));
+    const float rb = __fadd_rn(__fmul_rn(p[(long) y1 * Win + x0], wx0), __fmul_rn(p[(long) y1 * Win + x1], wx1));
+    dst[i] = __fadd_rn(__fmul_rn(ra, wy0), __fmul_rn(rb, wy1));
 }
 
 // =========================================================================================================
@@ -532,6 +602,8 @@ int64_t cpn_compact_workspace_bytes(int32_t N, int32_t h, int32_t w) {
 int cpn_compact(const float *scores, int32_t N, int32_t h, int32_t w, float thresh, int32_t *indices, int32_t *counts,
                 void *workspace, void *stream) {
     if (N <= 0 || h <= 0 || w <= 0) return cpn::fail(CPN_E_INVALID, "cpn_compact: bad shape");
+    if ((int64_t) N * h * w >= (1ll << 31))
+        return cpn::fail(CPN_E_UNSUPPORTED, "cpn_compact: N*h*w must stay below 2^31 (int32 proposal indices)");
     hipStream_t st = (hipStream_t) stream;
     const int hw = h * w;
     const int bpi = (hw + CBLK - 1) / CBLK;
@@ -548,13 +620,15 @@ int cpn_compact(const float *scores, int32_t N, int32_t h, int32_t w, float thre
 int cpn_decode(const int32_t *indices, int32_t P, const float *scores, const float *locations, const float *fourier,
                const float *refinement, int32_t N, int32_t h, int32_t w, int32_t H, int32_t W, int32_t order_total,
                int32_t order, int32_t samples, int32_t iterations, const float *cos_table, const float *sin_table,
-               const int64_t *offsets, float *contours, float *proposals, float *boxes, float *out_scores,
+               const float *offsets, float *contours, float *proposals, float *boxes, float *out_scores,
                float *out_locations, float *out_fourier, int32_t *batch_index, int32_t buckets,
                const int32_t *bucket_index, const float *bucket_weight, void *stream) {
     if (P < 0 || order < 1 || order > order_total || order * 4 > MAX_COEF || samples < 1)
         return cpn::fail(CPN_E_INVALID, "cpn_decode: bad arguments (need 1 <= order <= min(order_total, 64))");
     if (buckets > 1 && refinement && iterations > 0 && (!bucket_index || !bucket_weight))
         return cpn::fail(CPN_E_INVALID, "cpn_decode: refinement_buckets > 1 needs the bucket tables");
+    if (N <= 0 || h <= 0 || w <= 0 || (int64_t) N * h * w >= (1ll << 31))
+        return cpn::fail(CPN_E_UNSUPPORTED, "cpn_decode: N*h*w must be positive and below 2^31 (int32 proposal indices)");
     if (P == 0) return 0;
     DecodeArgs a{indices, P, scores, locations, fourier, refinement, N, h, w, H, W, order_total, order, samples,
                  iterations, cos_table, sin_table, offsets, contours, proposals, boxes, out_scores, out_locations,
@@ -634,6 +708,29 @@ int cpn_border_keep(const float *contours, int64_t P, int32_t samples, float off
     hipLaunchKernelGGL(border_kernel, dim3((unsigned) ((P + 3) / 4)), dim3(256), 0, (hipStream_t) stream, contours,
                        (long) P, samples, off_x, off_y, h, w, pad, sides, keep);
     return cpn::check_hip(hipGetLastError(), "cpn_border_keep");
+}
+
+int cpn_resize_bilinear_f32(const float *src, float *dst, int64_t planes, int32_t Hin, int32_t Win, int32_t Hout,
+                            int32_t Wout, void *stream) {
+    if (planes < 0 || Hin < 1 || Win < 1 || Hout < 1 || Wout < 1 || !src || !dst)
+        return cpn::fail(CPN_E_INVALID, "cpn_resize_bilinear_f32: bad arguments");
+    const long total = (long) planes * Hout * Wout;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(resize_f32_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, (hipStream_t) stream,
+                       src, dst, (long) planes, Hin, Win, Hout, Wout);
+    return cpn::check_hip(hipGetLastError(), "cpn_resize_bilinear_f32");
+}
+
+int cpn_border_keep_batched(const float *contours, int64_t P, int32_t samples, const int32_t *image_index,
+                            const int32_t *sides, const float *offsets, int32_t n_images, float h, float w, float pad,
+                            uint8_t *keep, void *stream) {
+    if (P < 0 || samples < 1 || n_images < 1) return cpn::fail(CPN_E_INVALID, "cpn_border_keep_batched: bad arguments");
+    if (P == 0) return 0;
+    if (!contours || !image_index || !sides || !offsets || !keep)
+        return cpn::fail(CPN_E_INVALID, "cpn_border_keep_batched: null pointer");
+    hipLaunchKernelGGL(border_batched_kernel, dim3((unsigned) ((P + 3) / 4)), dim3(256), 0, (hipStream_t) stream,
+                       contours, (long) P, samples, image_index, sides, offsets, h, w, pad, keep);
+    return cpn::check_hip(hipGetLastError(), "cpn_border_keep_batched");
 }
 
 int64_t cpn_nms_workspace_bytes(int64_t P, int64_t max_segment, int32_t nseg) {

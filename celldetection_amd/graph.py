@@ -78,10 +78,10 @@ class Plan:
         self.ops.append(dict(op='maxpool', src0=src, dst=dst, k=k, stride=stride, pad=pad))
         return dst
 
-    def bilinear_up2(self, src):
-        t = self.tensors[src]
-        assert t['down'] % 2 == 0
-        dst = self.tensor(t['c'], t['down'] // 2)
+    def bilinear_to_input(self, src):
+        """``_equal_size(features, inputs)`` (models/cpn.py:109-115,277-278): bilinear resize (align_corners=False) to
+        the input size; the executor aliases source and destination when the sizes already agree."""
+        dst = self.tensor(self.tensors[src]['c'], 1)
         self.ops.append(dict(op='bilinear', src0=src, dst=dst))
         return dst
 
@@ -101,8 +101,38 @@ def _two_conv_norm_relu(P, x, cout, prefix, bias=True, src1=None, up0=False, up1
     return P.conv(x, cout, 3, w=prefix + '3.', bn=prefix + '4.', bias=bias, act='relu')
 
 
+# constructor options of the reference backbones that the HIP graph does not model: accepted only with the listed
+# (default) values -- anything else must fail loudly instead of silently building a different network than the one the
+# checkpoint was trained with (e.g. inputs_mean / inputs_std: Normalize has no parameters, so a state dict cannot tell)
+_DEFAULT_ONLY = dict(pretrained=(False, None), inputs_mean=(0., None), inputs_std=(1., None), fused_initial=(False,),
+                     interpolate=('nearest',), nd=(2,), block_cls=(None,), secondary_block=(None,), pool=(True,),
+                     block=(None,), block_kwargs=(None, {}), bridge_strides=(True,), bridge_block_cls=(None,),
+                     bridge_block_kwargs=(None, {}), block_interpolate=(False,), bridge_block_interpolate=(False,),
+                     extra_blocks=(None,), norm_layer=(None, 'BatchNorm2d', 'batchnorm2d'), activation=('relu', 'ReLU'),
+                     cat_order=(0,), final_activation=(None,), final_interpolate=('nearest',), anchor=(None,),
+                     anchor_kwargs=(None, {}), kernel_size=(3,), padding=(1,), stride=(1,), out_layer=(False, None),
+                     keep_features=(False,), groups=(None,), width_per_group=(None,), replace_stride_with_dilation=(None,),
+                     layers=(None,), final_layer=(None,), final_pool=(None,))
+
+
+def _check_kwargs(kw: dict, allowed: tuple, where: str):
+    for k, v in kw.items():
+        if k in allowed:
+            continue
+        ok = _DEFAULT_ONLY.get(k)
+        if ok is not None and any((v is o) or (type(v) is type(o) and v == o) or
+                                  (isinstance(v, (int, float)) and isinstance(o, (int, float)) and
+                                   not isinstance(v, bool) and not isinstance(o, bool) and v == o)
+                                  or (isinstance(v, (tuple, list)) and isinstance(o, (int, float)) and
+                                      all(float(i) == float(o) for i in v)) for o in ok):
+            continue
+        raise NotImplementedError(f'{where}: option {k}={v!r} is not supported by the HIP engine '
+                                  f'(supported: {sorted(allowed)}; default-valued reference options are accepted)')
+
+
 def _unet_encoder(P, x, in_channels, prefix, depth=5, base_channels=64, factor=2, **unused):
     """UNetEncoder (unet.py:29-58) with pool=True, TwoConvNormRelu blocks."""
+    _check_kwargs(unused, (), 'UNetEncoder')
     feats, channels = [], []
     for i in range(depth):
         out_c = base_channels * (factor ** i)
@@ -130,6 +160,7 @@ _RESNETS = {
 def _resnet(P, x, in_channels, prefix, kind, base_channel=64, **unused):
     """ResNet(fused_initial=False) (resnet.py:265-297): body.0 = conv7x7 s2 + BN + ReLU (feature '0'),
     body.1 = Sequential(MaxPool(3,2,1), layer1), body.2..4 = layer2..4; blocks per torchvision forward."""
+    _check_kwargs(unused, (), kind)
     block, layers, groups, base_width = _RESNETS[kind]
     bc = base_channel
     x = P.conv(x, bc, 7, w=prefix + '0.0.', bn=prefix + '0.1.', stride=2, pad=3, act='relu')
@@ -292,6 +323,7 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
     ks = dict(kernel_sizes or {})
     family, enc = BACKBONES[backbone]
     bkw = dict(backbone_kwargs or {})
+    _check_kwargs(bkw, ('backbone_kwargs',) + (('fpn_channels',) if family == 'fpn' else ()), backbone)
     P = Plan()
     if order_weights:
         P.entries.append(('order_weights', (order, 1), 'buffer'))
@@ -328,8 +360,11 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
                  k=ks.get('uncertainty', 7), fuse=fuse_readout)
     if refinement:
         r = f0
-        while P.tensors[r]['down'] > 1:  # cpn.py:277-278: bilinear resize of the features to the input size
-            r = P.bilinear_up2(r)
+        # cpn.py:277-278: bilinear resize of the features to the input size.  FPN: always (f0 lives at stride 2);
+        # ResNet + UNet: the bridge level is 2 * ceil(H / 2) pixels high, i.e. H + 1 for odd H (no-op alias otherwise);
+        # U22: level 0 has the input size by construction (3x3 convs, padding 1)
+        if family == 'fpn' or enc != 'U22':
+            r = P.bilinear_to_input(r)
         _readout(P, r, cm0, 2 * refinement_buckets, 'core.refinement_head.', 'tanh_scaled', float(refinement_margin),
                  _lib.OUT_REFINEMENT, k=ks.get('refinement', 7), fuse=fuse_readout)
     P.meta = dict(backbone=backbone, order=order, head_down=scale, refinement=refinement, in_channels=in_channels,
@@ -381,7 +416,7 @@ def _pad64(c):
 def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=None, effective_weights: list = None):
     """-> (tensor_descs, op_descs, weight_blob[bf16 | f32, device], bias_blob[f32, device]).
 
-    bf16: weights [bundle][cin_b/32][k*k][cout_b][32]; fp32 (verification path): [bundle][k*k][cin_b][cout_b].
+    bf16: weights [bundle][cin_b/32][k*k (+1 zero slab if the item count is odd)][cout_b][32]; fp32 (verification path): [bundle][k*k][cin_b][cout_b].
     fp8 (e4m3, groundwork for BASELINE configs[4]): ``act_scales[tensor id]`` = value per activation code; channels
     are padded to 64; weights [bundle][cin_b/64][k*k (+1 zero slab if odd)][cout_b][64] as e4m3 codes of
     ``w * input_scale / weight_scale[cout]``; returns additionally (mult_blob[f32] = weight_scale per output channel,
@@ -492,7 +527,12 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=Non
                     weff = torch.stack([dq[:, g_ * cig_:(g_ + 1) * cig_, g_ * cig_:(g_ + 1) * cig_] for g_ in range(gpb)], 1)
                     weff = weff.reshape(cout, cig_, k, k) / act_scales[op['src0']]
                 effective_weights.append(dict(w=weff, b=b.clone()))
-        else:
+        elif f32:
+            wparts.append(packed.contiguous().reshape(-1).to(wdt))
+        else:  # bf16: [bundle][item][cout][32]; the kernel's pipeline step holds two items -> pad an odd item count
+            packed = packed.contiguous().reshape(bundles, -1, cout_b, KC)
+            if packed.shape[1] % 2:
+                packed = torch.cat((packed, torch.zeros_like(packed[:, :1])), 1)
             wparts.append(packed.contiguous().reshape(-1).to(wdt))
         bparts.append(bias.to(torch.float32))
         d.op = _lib.OP_CONV

@@ -23,6 +23,7 @@ import torch
 from .util import get_tiling_slices
 
 __all__ = ['shard_tiles', 'pack_detections', 'unpack_detections', 'gather_detections', 'tiled_inference',
+           'stitch_rule_batched',
            'ensemble_inference', 'forward_tiled', 'KEYS']
 
 KEYS = ('contours', 'boxes', 'scores', 'classes', 'locations', 'fourier', 'contour_proposals')
@@ -79,7 +80,30 @@ def gather_detections(buf: torch.Tensor, group=None) -> torch.Tensor:
 
 def _default_ops():
     from . import ops
-    return ops.remove_border_contours, ops.filter_contours_by_stitching_rule, ops.nms
+    return ops.remove_border_contours_batched, stitch_rule_batched, ops.nms
+
+
+def stitch_rule_batched(contours: torch.Tensor, image_index: torch.Tensor, stops: torch.Tensor,
+                        offsets: torch.Tensor) -> torch.Tensor:
+    """``filter_contours_by_stitching_rule(rule='ex_br')`` (celldetection/ops/cpn.py:293-325) for all detections of a
+    batch: contour p (of tile ``image_index[p]``) is dropped iff every point has x >= stops[tile, 0] or
+    y >= stops[tile, 1] after adding ``offsets[tile]`` (stops = (tile_size - overlap_with_next_tile) in xy order)."""
+    b = image_index.long()
+    c = contours + offsets[b][:, None].to(contours.dtype)
+    return ~((c >= stops[b][:, None].to(contours.dtype)).any(-1).all(-1))
+
+
+def _lists_to_flat(y, device):
+    """Per-image lists (``CPN.forward`` contract) -> (flat dict incl. 'b', counts)."""
+    counts = [int(t.shape[0]) for t in y['scores']]
+    flat = {k: torch.cat(list(y[k])) for k in KEYS}
+    flat['b'] = torch.repeat_interleave(torch.arange(len(counts), dtype=torch.int32), torch.tensor(counts)).to(device)
+    return flat, counts
+
+
+def _sync(dev):
+    if dev.type == 'cuda':
+        torch.cuda.synchronize(dev)
 
 
 @torch.no_grad()
@@ -87,38 +111,49 @@ def tiled_inference(model, img: torch.Tensor, crop_size=(1024, 1024), strides=(7
                     border_removal: int = 4, stitching_rule: str = 'nms', rank: Optional[int] = None,
                     world_size: Optional[int] = None, group=None, nms_thresh: Optional[float] = None,
                     forward_fn: Optional[Callable] = None, ops_fns=None, mask: Optional[torch.Tensor] = None,
-                    point_mask: Optional[torch.Tensor] = None, point_mask_exclusive: bool = False):
+                    point_mask: Optional[torch.Tensor] = None, point_mask_exclusive: bool = False,
+                    timings: Optional[dict] = None):
     """Slide-level CPN inference.
 
     Args:
         model: ``celldetection_amd.models.CPN`` (on the GPU of this rank).
-        img: slide as Tensor[C, H, W] or [1, C, H, W], uint8 or float in [0, 1], ideally already on the device.
+        img: slide as Tensor[C, H, W] or [1, C, H, W], uint8 or float in [0, 1], ideally already on the device.  Any
+            size: a slide smaller than the crop is one tile of the slide's own size.
         crop_size, strides: tiling (celldetection_scripts/cpn_inference.py:451-452 defaults 1024 / 768).
         batch_size: tiles per forward.
         border_removal: contours touching the outer ``border_removal`` px of a tile side that has a neighbouring
             tile are dropped (cpn_inference.py:370-380).
         stitching_rule: 'nms' (global NMS) and/or 'ex_br' (cpn_inference.py:382-388,405-408).
         rank, world_size, group: tile sharding; default = torch.distributed state (single process if uninitialised).
-        forward_fn / ops_fns: injection points used by the CPU (gloo) tests of the sharding/gather logic.
+        forward_fn / ops_fns: injection points used by the CPU (gloo) tests of the sharding/gather logic:
+            ``forward_fn(tiles, offsets, **kw)`` -> per-image lists; ``ops_fns`` = (border_keep_batched(contours,
+            image_index, sides, offsets, size, pad) -> mask, stitch_rule_batched, nms).
         mask: optional [H, W] (or [1, H, W]) foreground mask: tiles whose mask crop is empty are skipped and the crop
             is passed as ``scores_upper_bound`` (TileLoader semantics, cpn_inference.py:94-100).
         point_mask: optional [H, W] map of seed points: tiles without seeds are skipped, ``clip(crop, 0, 1)`` is passed
             as ``scores_lower_bound`` and, with ``point_mask_exclusive``, also as ``scores_upper_bound``
             (cpn_inference.py:102-113).
+        timings: optional dict that receives wall-clock seconds of the phases ('tiles', 'gather', 'nms'; the device
+            is synchronised at the phase boundaries when given) and the detection counts.
 
     Returns:
         OrderedDict of flat tensors (contours [K,S,2], boxes [K,4], scores [K], classes [K], locations [K,2],
         fourier [K,O,4], contour_proposals [K,S,2]) in global slide coordinates, identical on every rank.
+
+    Host work is O(batches): every forwarded batch is filtered by ONE border-rule launch over all its detections; the
+    kept rows of all batches are gathered once at the end (one host synchronisation for the whole filter).
     """
+    import time
     import torch.distributed as dist
     if world_size is None:
         world_size = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
     if rank is None:
         rank = dist.get_rank(group) if (dist.is_available() and dist.is_initialized()) else 0
-    remove_border, stitch_filter, nms_fn = ops_fns if ops_fns is not None else _default_ops()
+    border_fn, stitch_fn, nms_fn = ops_fns if ops_fns is not None else _default_ops()
     if img.ndim == 4:
         assert img.shape[0] == 1, 'one slide at a time'
         img = img[0]
+    dev = img.device
     H, W = img.shape[-2:]
     crop_size = (crop_size,) * 2 if np.isscalar(crop_size) else tuple(crop_size)
     strides = (strides,) * 2 if np.isscalar(strides) else tuple(strides)
@@ -135,9 +170,9 @@ def tiled_inference(model, img: torch.Tensor, crop_size=(1024, 1024), strides=(7
     mine = [tile_ids[j] for j in shard_tiles(len(tile_ids), rank, world_size)]
     nms_thresh = model.nms_thresh if nms_thresh is None else nms_thresh
     rules = stitching_rule.split(',')
-    coll: Dict[str, List[torch.Tensor]] = {k: [] for k in KEYS}
     samples = order = None
     meta = []  # FIFO of (tile ids, offsets, tile size) of the batches handed to the model
+    t_start = time.perf_counter()
 
     def batches():
         for b0 in range(0, len(mine), batch_size):
@@ -158,35 +193,60 @@ def tiled_inference(model, img: torch.Tensor, crop_size=(1024, 1024), strides=(7
             yield tiles, kw
 
     if forward_fn is None:  # conv graph of batch i+1 overlaps the post-processing / border filtering of batch i
-        results = model.forward_pipelined(batches())
+        results = model.forward_pipelined(batches(), flat_output=True)
     else:
-        results = (forward_fn(t, kw.pop('offsets'), **kw) for t, kw in batches())
-    for y in results:
+        results = (_lists_to_flat(forward_fn(t, kw.pop('offsets'), **kw), dev) for t, kw in batches())
+    pending = []  # (flat tensors of a batch, keep mask): rows are selected once, after the loop
+    for flat, counts in results:
         idxs, offs, size = meta.pop(0)
-        for n, i in enumerate(idxs):
+        samples, order = flat['contours'].shape[1], flat['fourier'].shape[1]
+        if flat['scores'].shape[0] == 0:
+            continue
+        sides = []
+        for i in idxs:  # sides that have a neighbouring tile (cpn_inference.py:372-380)
             h_i, w_i = np.unravel_index(i, shape)
-            con = y['contours'][n]
-            keep = remove_border(con, size, border_removal, top=h_i > 0, right=w_i < (w_tiles - 1),
-                                 bottom=h_i < (h_tiles - 1), left=w_i > 0, offsets=-offs[n])
-            if 'ex_br' in rules:
-                keep = stitch_filter(con, size, torch.as_tensor(overlaps[i]), rule='ex_br',
-                                     offsets=-offs[n].to(con.device)) & keep
-            for k in KEYS:
-                coll[k].append(y[k][n][keep])
-            samples, order = con.shape[1], y['fourier'][n].shape[1]
+            sides.append((1 if h_i > 0 else 0) | (2 if w_i < (w_tiles - 1) else 0) |
+                         (4 if h_i < (h_tiles - 1) else 0) | (8 if w_i > 0 else 0))
+        sides_t = torch.tensor(sides, dtype=torch.int32).to(dev, non_blocking=True)
+        neg = (-offs).to(torch.float32).to(dev, non_blocking=True)
+        keep = border_fn(flat['contours'], flat['b'], sides_t, neg, size, border_removal).bool()
+        if 'ex_br' in rules:
+            ov = torch.tensor([[overlaps[i][1][1], overlaps[i][0][1]] for i in idxs], dtype=torch.float32)
+            stops = (torch.tensor([size[1], size[0]], dtype=torch.float32) - ov).to(dev, non_blocking=True)
+            keep = keep & stitch_fn(flat['contours'], flat['b'], stops, neg)
+        pending.append((flat, keep))
     if samples is None:  # this rank had no tiles: shapes from the model
         samples, order = model.samples, min(model.order, model.core.order)
-    dev = img.device
     local = OrderedDict()
     shapes = dict(contours=(0, samples, 2), boxes=(0, 4), scores=(0,), classes=(0,), locations=(0, 2),
                   fourier=(0, order, 4), contour_proposals=(0, samples, 2))
-    for k in KEYS:
-        local[k] = torch.cat(coll[k]) if coll[k] else torch.zeros(shapes[k], device=dev)
+    if pending:
+        sel = torch.cat([k for _, k in pending]).nonzero().squeeze(1)  # the one host sync of the filter
+        for k in KEYS:
+            local[k] = torch.cat([f[k] for f, _ in pending]).index_select(0, sel)
+    else:
+        for k in KEYS:
+            local[k] = torch.zeros(shapes[k], device=dev)
+    if timings is not None:
+        _sync(dev)
+        timings['tiles'] = time.perf_counter() - t_start
+        timings['tiles_local'] = len(mine)
+        timings['detections_local'] = int(local['scores'].shape[0])
+        t_start = time.perf_counter()
     buf = gather_detections(pack_detections(local), group=group)
     res = unpack_detections(buf, samples, order)
+    if timings is not None:
+        _sync(dev)
+        timings['gather'] = time.perf_counter() - t_start
+        timings['detections_gathered'] = int(res['scores'].shape[0])
+        t_start = time.perf_counter()
     if 'nms' in rules and res['scores'].shape[0]:
         keep = nms_fn(res['boxes'], res['scores'], nms_thresh)
         res = OrderedDict((k, v[keep]) for k, v in res.items())
+    if timings is not None:
+        _sync(dev)
+        timings['nms'] = time.perf_counter() - t_start
+        timings['detections_final'] = int(res['scores'].shape[0])
     return res
 
 

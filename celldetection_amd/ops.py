@@ -4,7 +4,7 @@ Same names, argument meaning and return conventions as the reference (celldetect
 tensors must live on the GPU -- there is no CPU fallback in the product path (the CPU restatement lives in
 ``oracle/`` and is test infrastructure only).
 """
-from ctypes import c_int64
+from ctypes import c_int32, c_int64
 from typing import List
 
 import numpy as np
@@ -14,12 +14,16 @@ from torch import Tensor
 from . import _lib
 from ._lib import check, ptr, stream_ptr
 
-__all__ = ['fouriers2contours', 'local_refinement', 'nms', 'batched_box_nmsi', 'remove_border_contours',
+__all__ = ['fouriers2contours', 'local_refinement', 'nms', 'nms_binned', 'batched_box_nmsi', 'remove_border_contours',
+           'remove_border_contours_batched',
            'filter_contours_by_stitching_rule', 'compact_scores', 'decode_proposals', 'sampling_tables',
            'bucket_tables', 'class_scores', 'certainty_mask', 'gather_channels', 'filter_by_box_voting',
            'NMS_BATCH_SIZE']
 
 NMS_BATCH_SIZE = 50000  # celldetection/ops/cpn.py:12
+# single-segment NMS calls with more boxes than this use the spatially binned formulation (identical keep list,
+# O(P + E) memory instead of the dense P x P/64 bit mask: 32768 boxes = 134 MB of mask)
+NMS_BINNED_MIN = 32768
 
 _table_cache = {}
 
@@ -123,13 +127,48 @@ def _nms_segments(boxes: Tensor, scores: Tensor, seg_offsets: List[int], thresh:
 def nms(boxes: Tensor, scores: Tensor, iou_threshold: float) -> Tensor:
     """torch.ops.torchvision.nms semantics (greedy, stable descending score order, NaN IoU never suppresses);
     returns kept indices (int64) in descending-score order.  Replaces celldetection/ops/cpn.py:211 and
-    celldetection_scripts/cpn_inference.py:407."""
+    celldetection_scripts/cpn_inference.py:407.  Large sets (slide-level NMS) run through ``nms_binned`` -- the same
+    keep list without the dense P x P/64 mask."""
     _need_cuda(boxes, scores)
     P = int(boxes.shape[0])
     if P == 0:
         return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    if P >= NMS_BINNED_MIN and iou_threshold >= 0:
+        return nms_binned(boxes, scores, iou_threshold)
     keep, counts = _nms_segments(boxes, scores, [0, P], iou_threshold)
     return keep[:counts[0]]
+
+
+def nms_binned(boxes: Tensor, scores: Tensor, iou_threshold: float, return_stats: bool = False):
+    """Spatially binned greedy NMS (csrc/nms_binned.hip): identical result to ``nms`` for ``iou_threshold >= 0``
+    with O(P + E) workspace (E = overlapping higher-ranked pairs).  Synchronises the stream (edge count, convergence,
+    keep count are read back).  ``return_stats``: also returns dict(edges, sweeps, workspace_bytes)."""
+    _need_cuda(boxes, scores)
+    lib = _lib.load()
+    P = int(boxes.shape[0])
+    dev = boxes.device
+    if P == 0:
+        empty = torch.empty((0,), dtype=torch.int64, device=dev)
+        return (empty, dict(edges=0, sweeps=0, workspace_bytes=0)) if return_stats else empty
+    bx = boxes.contiguous().float()
+    sc = scores.contiguous().float()
+    keep = torch.empty(P, dtype=torch.int64, device=dev)
+    cnt, need, sweeps = c_int64(0), c_int64(0), c_int32(0)
+    max_edges = max(32 * P, 1 << 16)
+    for attempt in range(2):
+        ws_bytes = int(lib.cpn_nms_binned_workspace_bytes(P, max_edges))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        rc = lib.cpn_nms_binned(ptr(bx), ptr(sc), P, float(iou_threshold), max_edges, ptr(keep), None, cnt, need,
+                                sweeps, ptr(ws), ws_bytes, stream_ptr())
+        if rc == _lib.E_WORKSPACE and attempt == 0 and need.value > max_edges:
+            max_edges = int(need.value)  # exact size reported by the count pass
+            continue
+        check(rc, 'nms_binned')
+        break
+    out = keep[:cnt.value]
+    if return_stats:
+        return out, dict(edges=int(need.value), sweeps=int(sweeps.value), workspace_bytes=ws_bytes)
+    return out
 
 
 def batched_box_nmsi(boxes: List[Tensor], scores: List[Tensor], iou_threshold: float, batch_size: int = None
@@ -186,6 +225,27 @@ def remove_border_contours(contours: Tensor, size, padding=1, top=True, right=Tr
     check(_lib.load().cpn_border_keep(ptr(c), P, S, ox, oy, float(h), float(w), float(padding), sides, ptr(keep),
                                       stream_ptr()), 'remove_border_contours')
     return keep.bool()
+
+
+def remove_border_contours_batched(contours: Tensor, image_index: Tensor, sides: Tensor, offsets: Tensor, size,
+                                   padding=1) -> Tensor:
+    """``remove_border_contours`` for all detections of a forwarded batch in ONE launch (the per-tile loop of
+    celldetection_scripts/cpn_inference.py:370-380): contours [P,S,2]; image_index int32 [P] (tile of each contour);
+    sides int32 [N] bit masks (1 top, 2 right, 4 bottom, 8 left = sides that have a neighbouring tile); offsets float
+    [N,2] (xy) ADDED to the coordinates (the reference passes ``-tile_offset``).  -> uint8 keep mask [P] (device)."""
+    _need_cuda(contours, image_index, sides, offsets)
+    P, S = int(contours.shape[0]), int(contours.shape[1])
+    keep = torch.empty(P, dtype=torch.uint8, device=contours.device)
+    if P == 0:
+        return keep
+    h, w = size[:2]
+    c = contours.contiguous().float()
+    check(_lib.load().cpn_border_keep_batched(ptr(c), P, S, ptr(image_index.to(torch.int32).contiguous()),
+                                              ptr(sides.to(torch.int32).contiguous()),
+                                              ptr(offsets.to(torch.float32).contiguous()), int(sides.shape[0]),
+                                              float(h), float(w), float(padding), ptr(keep), stream_ptr()),
+          'remove_border_contours_batched')
+    return keep
 
 
 def filter_contours_by_stitching_rule(contours: Tensor, tile_size, overlaps, rule='ex_br', offsets=None,
@@ -303,8 +363,8 @@ def decode_proposals(indices: Tensor, scores: Tensor, locations: Tensor, fourier
         return out
     cos_t, sin_t = sampling_tables(order, samples, dev)
     offs = None
-    if offsets is not None:
-        offs = torch.as_tensor(offsets).to(device=dev, dtype=torch.int64).contiguous()
+    if offsets is not None:  # the reference adds the (int64) offsets to fp32 tensors: fp32 add of the converted value
+        offs = torch.as_tensor(offsets).to(device=dev, dtype=torch.float32).contiguous()
         assert offs.shape == (N, 2), 'offsets must be Tensor[N, 2] (xy)'
     ref = None if refinement is None else refinement.contiguous().float()
     bidx, bw = bucket_tables(samples, num_buckets, dev) if (num_buckets > 1 and ref is not None) else (None, None)

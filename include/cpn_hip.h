@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CPN_ABI_VERSION 5
+#define CPN_ABI_VERSION 6
 
 #define CPN_E_INVALID (-1)
 #define CPN_E_UNSUPPORTED (-2)
@@ -43,7 +43,7 @@ int cpn_abi_version(void);
 /* activation tensors of the graph (NHWC bf16, channel count padded to a multiple of 32) */
 typedef struct {
     int32_t channels;  /* padded channel count (multiple of 32; 64 for CPN_PRECISION_FP8 plans)   */
-    int32_t down;      /* spatial size = input size / down (down in 1,2,4,...,32)                 */
+    int32_t down;      /* nominal down-sampling factor (1,2,4,...,32); actual sizes are propagated per input size */
     float scale;       /* CPN_PRECISION_FP8: value of one e4m3 code unit of this tensor; else unused */
 } cpn_tensor_desc;
 
@@ -56,11 +56,13 @@ typedef struct {
     int32_t op;               /* CPN_OP_*                                                                   */
     int32_t src0, src1, res;  /* tensor ids (-1 = none). src1: second source of a virtual channel concat      */
     int32_t dst;              /* tensor id, or -1 when the op writes an external fp32 NCHW output             */
-    int32_t up0, up1, res_up; /* source is stored at half resolution, read through nearest x2 upsampling      */
+    int32_t up0, up1, res_up; /* source / residual is nearest-resized (PyTorch 'nearest': floor(dst*in/out)) to the
+                               * size of the other concat source / of the output; a lone up0 source: exact x2       */
     int32_t c0_used;          /* channels of the concat taken from src0 (multiple of 32)                      */
     int32_t kh, kw, stride, pad;
     int32_t bundles, cin_b, cout_b; /* grouped convs run as `bundles` dense convs of cin_b -> cout_b channels  */
-    int64_t weight_offset;    /* byte offset into the packed weight blob: [bundle][cin_b/32][kh*kw][cout_b][32] bf16 */
+    int64_t weight_offset;    /* byte offset into the packed weight blob: [bundle][(cin_b/32)*kh*kw items, + one
+                               * all-zero item when that count is odd][cout_b][32] bf16 (chunk-major, tap-minor)  */
     int64_t bias_offset;      /* float offset into the bias blob, -1 = no bias                                 */
     int32_t act;              /* CPN_ACT_*                                                                    */
     float act_scale;
@@ -97,8 +99,15 @@ int cpn_plan_create(cpn_plan **plan, const cpn_tensor_desc *tensors, int32_t n_t
                     int32_t n_ops, const void *weights, size_t weight_bytes, const float *bias, size_t bias_count,
                     int32_t precision);
 void cpn_plan_destroy(cpn_plan *plan);
-/* Workspace (activation arena, liveness-planned) needed for a batch of N inputs of H x W (H, W multiples of 32). */
+/* Workspace (activation arena, liveness-planned) needed for a batch of N inputs of H x W.  Any H, W the graph can
+ * digest: tensor sizes are propagated op by op with the reference modules' rules (conv / max-pool floor((in+2p-k)/s)+1;
+ * top-down maps nearest-resized to the lateral's size, models/unet.py:213-217 and torchvision FPN; features
+ * bilinear-resized to the input size, models/cpn.py:277-278); too small an input returns CPN_E_INVALID. */
 int64_t cpn_plan_workspace_bytes(cpn_plan *plan, int32_t N, int32_t H, int32_t W);
+/* Spatial size (h, w) of the external output CPN_OUT_* for an H x W input (0 x 0: the plan has no such output), and
+ * the element count per image of the largest activation tensor (callers split batches at 2^31 elements). */
+int cpn_plan_output_dims(cpn_plan *plan, int32_t H, int32_t W, int32_t out_index, int32_t *h, int32_t *w);
+int64_t cpn_plan_max_tensor_elements(cpn_plan *plan, int32_t H, int32_t W);
 /* 2*MAC FLOPs executed by the MFMA loops for that shape (includes channel/tile padding). */
 double cpn_plan_executed_flops(cpn_plan *plan, int32_t N, int32_t H, int32_t W);
 
@@ -166,7 +175,9 @@ int cpn_compact(const float *scores, int32_t N, int32_t h, int32_t w, float thre
  *   scores [N,1,h,w], locations [N,2,h,w], fourier [N,4*order_total,h,w], refinement [N,2,H,W] or NULL (fp32 NCHW)
  *   order <= order_total (cpn.py:597-598 "changed order"), samples = S, iterations = refinement iterations
  *   cos_table/sin_table [order][samples] fp32 device (built by the host exactly like ops/cpn.py:69-78)
- *   offsets: int64 [N,2] (xy) device or NULL
+ *   offsets: float [N,2] (xy) device or NULL (the reference adds int64 offsets to fp32 tensors = fp32 add of the
+ *   converted value); when no refinement runs, contours and contour_proposals are ONE tensor in the reference and
+ *   receive the offset twice (cpn.py:655-656,697-699) -- reproduced
  *   buckets = refinement_buckets (cpn.py:72-82): 1 = plain map; > 1: refinement is [N,2*buckets,H,W] and
  *   bucket_index / bucket_weight are [3][samples] device tables (bucket number and blend weight of the three
  *   neighbouring buckets of every sample, built by the host like resolve_refinement_buckets, ops/cpn.py:238-255)
@@ -175,7 +186,7 @@ int cpn_compact(const float *scores, int32_t N, int32_t h, int32_t w, float thre
 int cpn_decode(const int32_t *indices, int32_t P, const float *scores, const float *locations, const float *fourier,
                const float *refinement, int32_t N, int32_t h, int32_t w, int32_t H, int32_t W, int32_t order_total,
                int32_t order, int32_t samples, int32_t iterations, const float *cos_table, const float *sin_table,
-               const int64_t *offsets, float *contours, float *proposals, float *boxes, float *out_scores,
+               const float *offsets, float *contours, float *proposals, float *boxes, float *out_scores,
                float *out_locations, float *out_fourier, int32_t *batch_index, int32_t buckets,
                const int32_t *bucket_index, const float *bucket_weight, void *stream);
 
@@ -227,6 +238,33 @@ int cpn_box_votes(const float *boxes, int64_t P, float thresh, float *votes, voi
  * sides: bit0 top, bit1 right, bit2 bottom, bit3 left. */
 int cpn_border_keep(const float *contours, int64_t P, int32_t samples, float off_x, float off_y, float h, float w,
                     float pad, int32_t sides, uint8_t *keep, void *stream);
+
+/* F.interpolate(x, size, mode='bilinear', align_corners=False) on fp32 NCHW planes: `_equal_size` of the score-bound
+ * masks and head maps (celldetection/models/cpn.py:109-123,279).  src [planes, Hin, Win] -> dst [planes, Hout, Wout]. */
+int cpn_resize_bilinear_f32(const float *src, float *dst, int64_t planes, int32_t Hin, int32_t Win, int32_t Hout,
+                            int32_t Wout, void *stream);
+
+/* The same rule for ALL detections of a forwarded batch of tiles in one launch (the per-tile loop of
+ * celldetection_scripts/cpn_inference.py:370-380): contour p belongs to image image_index[p] (int32, device);
+ * sides[n] (int32, device) is the bit mask above of tile n, offsets[n] = (x, y) floats ADDED to the coordinates
+ * (the reference passes -tile_offset); h, w, pad as above. */
+int cpn_border_keep_batched(const float *contours, int64_t P, int32_t samples, const int32_t *image_index,
+                            const int32_t *sides, const float *offsets, int32_t n_images, float h, float w, float pad,
+                            uint8_t *keep, void *stream);
+
+/* Slide-scale NMS: same semantics and the SAME keep list as cpn_nms with one segment (torchvision nms: greedy, stable
+ * descending-score order), computed with a spatial grid + sparse suppressor lists + a monotone fixed point instead of
+ * the dense P x P/64 bit mask -- O(P + E) memory, E = number of (box, higher-ranked box with IoU > thresh) pairs.
+ * Replaces the global NMS over all detections of a slide (celldetection_scripts/cpn_inference.py:405-408,426).
+ * Needs thresh >= 0.  max_edges: capacity of the caller's edge buffer; when E exceeds it the call returns
+ * CPN_E_WORKSPACE with *edges_needed = E (retry with a larger workspace).  keep: int64 [P] device (first
+ * *keep_count_host entries valid); keep_count_dev (optional) receives the count on the device as well.
+ * sweeps (optional, host): number of fixed-point sweeps executed.  This call SYNCHRONISES the stream (it reads E, the
+ * convergence counter and the keep count back). */
+int64_t cpn_nms_binned_workspace_bytes(int64_t P, int64_t max_edges);
+int cpn_nms_binned(const float *boxes, const float *scores, int64_t P, float thresh, int64_t max_edges, int64_t *keep,
+                   int64_t *keep_count_dev, int64_t *keep_count_host, int64_t *edges_needed, int32_t *sweeps,
+                   void *workspace, int64_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

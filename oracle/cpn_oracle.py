@@ -433,7 +433,8 @@ def cpn_postprocess(scores_raw, locations, refinement, fourier, *, input_size, o
         contours = proposals.copy()
     contours[..., 0] = np.clip(contours[..., 0], 0, W - 1)  # cpn.py:661-663 (also clamps the proposals when
     contours[..., 1] = np.clip(contours[..., 1], 0, H - 1)  # no refinement is applied: same tensor object)
-    if refinement is None or refinement_iterations <= 0:
+    aliased = refinement is None or refinement_iterations <= 0  # cpn.py:655-656: ONE tensor object
+    if aliased:
         proposals = contours
     if len(contours):
         boxes = np.concatenate((contours.min(1), contours.max(1)), 1)
@@ -441,11 +442,12 @@ def cpn_postprocess(scores_raw, locations, refinement, fourier, *, input_size, o
         boxes = np.zeros((0, 4), np.float32)
     if offsets is not None:  # cpn.py:695-702
         offs = to_np(offsets)[b]
-        contours = contours + offs[:, None].astype(np.float32)
-        if proposals is not contours:
-            proposals = proposals + offs[:, None].astype(np.float32)
-        else:
+        if aliased:  # the two in-place `+=` of cpn.py:697-699 both hit the one tensor: offset added twice
+            contours = (contours + offs[:, None].astype(np.float32)) + offs[:, None].astype(np.float32)
             proposals = contours
+        else:
+            contours = contours + offs[:, None].astype(np.float32)
+            proposals = proposals + offs[:, None].astype(np.float32)
         boxes = boxes + np.tile(offs, (1, 2)).astype(np.float32)
         sel_loc = sel_loc + offs.astype(np.float32)
     flat = OrderedDict(contours=contours.astype(np.float32), boxes=boxes.astype(np.float32), scores=sel_scores,

@@ -70,7 +70,9 @@ def _simulate(plan, state_dict, effective_weights, act_scales, x, T, outs, ei, _
         elif kind == 'bilinear':
             t = T[op['src0']]
             s = act_scales[op['src0']]
-            T[op['dst']] = _q(F.interpolate(t, scale_factor=2, mode='bilinear', align_corners=False), s)
+            if t.shape[2:] != x.shape[2:]:  # _equal_size(features, inputs), models/cpn.py:277-278
+                t = F.interpolate(t, x.shape[2:], mode='bilinear', align_corners=False)
+            T[op['dst']] = _q(t, s)
         else:
             e = effective_weights[ei]
             ei += 1

@@ -10,6 +10,8 @@ Imports the read-only Python reference (celldetection 0.4.9) through ``oracle/re
                    via ``celldetection_amd.synth``; the file holds the 8 calibrated head tensors, the input,
                    the five ``CPNCore`` maps and the full ``CPN.forward`` outputs (nms on/off, offsets, bounds)
 * ``stitch.npz``   G8: multi-tile stitch (TileLoader offsets/overlaps -> border removal -> global NMS)
+* ``stitch_dups.npz`` G8b: the stitching rule on synthetic per-tile detections WITH cross-tile duplicates (the global
+                   NMS removes > 10 % of what survives the border rule)
 
 Run:  python tests/golden/make_golden.py
 """
@@ -67,6 +69,20 @@ MODEL_SPECS = {
                                                     kernel_size_refinement=5, refinement_buckets=3, backbone_kwargs={
                                                         'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}),
                              (1, 3, 64, 64)),
+    # arbitrary input sizes (not multiples of 32; odd): conv / pool floor rules, top-down maps nearest-resized to the
+    # lateral's size (unet.py:213-217, torchvision FPN), features bilinear-resized to the input size (cpn.py:277-279)
+    'CpnResNeXt101UNet_odd': ('CpnResNeXt101UNet',
+                              dict(in_channels=3, backbone_kwargs={'backbone_kwargs': {'base_channel': 8}}),
+                              (1, 3, 75, 101)),
+    'CpnResNeXt101UNet_100x140': ('CpnResNeXt101UNet',
+                                  dict(in_channels=3, backbone_kwargs={'backbone_kwargs': {'base_channel': 8}}),
+                                  (2, 3, 100, 140)),
+    'CpnResNet18FPN_odd': ('CpnResNet18FPN', dict(in_channels=3, backbone_kwargs={
+        'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}), (1, 3, 75, 101)),
+    'CpnU22_odd': ('CpnU22', dict(in_channels=3, backbone_kwargs={'backbone_kwargs': {'base_channels': 8}}),
+                   (1, 3, 75, 101)),
+    'CpnU22_300': ('CpnU22', dict(in_channels=3, backbone_kwargs={'backbone_kwargs': {'base_channels': 8}}),
+                   (1, 3, 300, 300)),
 }
 
 
@@ -223,10 +239,14 @@ def gen_model(name, seed=0):
         out['offsets'] = npy(offsets)
         flat_outputs('offs', model(x, offsets=offsets.clone()), out)
         g = torch.Generator().manual_seed(3)
-        ub = (torch.rand(shape[0], 1, shape[2] // 4, shape[3] // 4, generator=g) > .3).float()
-        lb = (torch.rand(shape[0], 1, shape[2] // 8, shape[3] // 8, generator=g) > .97).float()
+        ub = (torch.rand(shape[0], 1, max(shape[2] // 4, 1), max(shape[3] // 4, 1), generator=g) > .3).float()
+        lb = (torch.rand(shape[0], 1, max(shape[2] // 8, 1), max(shape[3] // 8, 1), generator=g) > .97).float()
         out['scores_upper_bound'], out['scores_lower_bound'] = npy(ub), npy(lb)
         flat_outputs('bounds', model(x, scores_upper_bound=ub, scores_lower_bound=lb), out)
+        if name == 'CpnU22':  # no refinement: contours IS contour_proposals -> both `+= offsets` hit one tensor
+            model.refinement_iterations = 0
+            flat_outputs('noref_offs', model(x, offsets=offsets.clone()), out)
+            model.refinement_iterations = 4
         if name == 'CpnU22':  # run-time attribute changes (config/flags)
             model.samples, model.refinement_iterations, model.score_thresh, model.nms_thresh = 17, 2, .7, .5
             flat_outputs('attr', model(x), out)
@@ -272,6 +292,61 @@ def gen_stitch():
     save('stitch.npz', **out)
 
 
+def gen_stitch_dups():
+    """G8b: the stitching rule itself (border removal per tile -> concat -> ONE global NMS, cpn_inference.py:370-408)
+    with the reference's own functions on synthetic per-tile detection lists that DO contain cross-tile duplicates:
+    objects of a global canvas are 'detected' by every tile that contains their centre (tile-specific sub-pixel jitter
+    and score noise), so the global NMS has real work (the model-level stitch.npz happens to suppress nothing)."""
+    rng = np.random.default_rng(2024)
+    H, W, crop, stride, border, S, O = 400, 520, (128, 128), (96, 96), 4, 16, 3
+    slices, overlaps, shape = cd.get_tiling_slices((H, W), crop, stride, return_overlaps=True)
+    slices, overlaps = list(slices), list(overlaps)
+    h_tiles, w_tiles = shape
+    n_obj = 260
+    ctr = rng.uniform([2, 2], [W - 2, H - 2], (n_obj, 2))
+    rad = rng.uniform(3, 9, n_obj)
+    base_score = rng.uniform(.5, 1., n_obj)
+    ang = np.linspace(0, 2 * np.pi, S, endpoint=False)
+    out = dict(size=np.array((H, W)), crop=np.array(crop), stride=np.array(stride), border=np.array(border),
+               n_tiles=np.array(len(slices)), nms_thresh=np.array(.2, np.float32))
+    coll = {}
+    pre = 0
+    for idx, sl in enumerate(slices):
+        h0, w0 = sl[0].start, sl[1].start
+        inside = (ctr[:, 0] >= w0) & (ctr[:, 0] < w0 + crop[1]) & (ctr[:, 1] >= h0) & (ctr[:, 1] < h0 + crop[0])
+        ids = np.nonzero(inside)[0]
+        k = len(ids)
+        jit = rng.uniform(-.3, .3, (k, 1, 2))
+        con = ctr[ids, None] + rad[ids, None, None] * np.stack((np.cos(ang), np.sin(ang)), -1)[None] * \
+            rng.uniform(.85, 1.15, (k, S, 1)) + jit
+        con = np.clip(con, [w0, h0], [w0 + crop[1] - 1, h0 + crop[0] - 1]).astype(np.float32)  # tile-local clamp + offset
+        sco = (base_score[ids] + rng.uniform(-.02, .02, k)).astype(np.float32)
+        d = dict(contours=con, boxes=np.concatenate((con.min(1), con.max(1)), 1).astype(np.float32), scores=sco,
+                 classes=np.ones(k, np.int64), locations=(ctr[ids] + jit[:, 0]).astype(np.float32),
+                 fourier=rng.standard_normal((k, O, 4)).astype(np.float32), contour_proposals=(con + .25).astype(np.float32))
+        for kk, v in d.items():
+            out[f'tile{idx}.{kk}'] = v
+        h_i, w_i = np.unravel_index(idx, shape)
+        offs = torch.tensor([w0, h0])
+        keep = rops.remove_border_contours(torch.as_tensor(con), crop, border, top=h_i > 0, right=w_i < w_tiles - 1,
+                                           bottom=h_i < h_tiles - 1, left=w_i > 0, offsets=-offs)
+        keep_br = keep & rops.filter_contours_by_stitching_rule(torch.as_tensor(con), crop, torch.as_tensor(overlaps[idx]),
+                                                                rule='ex_br', offsets=-offs)
+        out[f'tile{idx}.keep_border'] = npy(keep)
+        out[f'tile{idx}.keep_border_exbr'] = npy(keep_br)
+        pre += int(keep.sum())
+        for kk, v in d.items():
+            vv = torch.as_tensor(v)[keep]
+            coll[kk] = torch.cat((coll[kk], vv)) if kk in coll else vv
+    keep = torch.ops.torchvision.nms(coll['boxes'], coll['scores'], .2)
+    out['pre_nms_count'] = np.array(pre)
+    for kk, v in coll.items():
+        out[f'final.{kk}'] = npy(v[keep])
+    print('stitch_dups: tiles', shape, 'pre-nms', pre, 'final', len(keep))
+    assert len(keep) <= 0.9 * pre
+    save('stitch_dups.npz', **out)
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['ops', 'tiling', 'models', 'stitch']
     if 'ops' in which:
@@ -286,3 +361,5 @@ if __name__ == '__main__':
             gen_model(name_)
     if 'stitch' in which:
         gen_stitch()
+    if 'stitch' in which or 'stitch_dups' in which:
+        gen_stitch_dups()

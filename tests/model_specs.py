@@ -44,7 +44,18 @@ VARIANT_SPECS = {
         backbone_kwargs={'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}),
         cpn_kwargs=dict(_DEF, refinement_buckets=3)),
 }
-ALL_SPECS = dict(MODEL_SPECS, **VARIANT_SPECS)
+_R8 = {'backbone_kwargs': {'base_channel': 8}}
+# arbitrary input sizes (not multiples of 32 / odd): same constructors, fixtures generated at 75x101, 100x140, 300x300
+SIZE_SPECS = {
+    'CpnResNeXt101UNet_odd': dict(cls='CpnResNeXt101UNet', kwargs=dict(in_channels=3, backbone_kwargs=_R8), cpn_kwargs=dict(_DEF)),
+    'CpnResNeXt101UNet_100x140': dict(cls='CpnResNeXt101UNet', kwargs=dict(in_channels=3, backbone_kwargs=_R8),
+                                      cpn_kwargs=dict(_DEF)),
+    'CpnResNet18FPN_odd': dict(cls='CpnResNet18FPN', kwargs=dict(in_channels=3, backbone_kwargs={
+        'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}), cpn_kwargs=dict(_DEF)),
+    'CpnU22_odd': dict(cls='CpnU22', kwargs=dict(in_channels=3, backbone_kwargs=_U8), cpn_kwargs=dict(_DEF)),
+    'CpnU22_300': dict(cls='CpnU22', kwargs=dict(in_channels=3, backbone_kwargs=_U8), cpn_kwargs=dict(_DEF)),
+}
+ALL_SPECS = dict(MODEL_SPECS, **VARIANT_SPECS, **SIZE_SPECS)
 
 
 def ref_template_state_dict(name, fixture=None):

@@ -1,0 +1,40 @@
+"""bench.py launch contract (CPU, gloo): `--gpus N` outside torchrun starts N ranks itself, a launcher/flag mismatch
+fails loudly, and the sharding + packed all-gather plumbing of the multi-GPU path runs end to end (``--dry-run``: no
+GPU, no kernels, not a measurement)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env=None, timeout=240):
+    e = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, capture_output=True, text=True,
+                          env=e, timeout=timeout, cwd=ROOT)
+
+
+def _json_line(out):
+    lines = [l for l in out.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def test_self_launch_two_ranks_gloo():
+    r = _run(['--gpus', '2', '--backend', 'gloo', '--dry-run'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d['dry_run'] is True and d['n_gpus'] == 2 and d['world_size_seen'] == 2
+    assert d['gathered_detections'] == 3 * d['tiles'] + 1  # 3 per tile + rank (0 + 1): ragged per-rank counts
+
+
+def test_single_rank_dry_run():
+    d = _json_line(_run(['--gpus', '1', '--dry-run']).stdout)
+    assert d['n_gpus'] == 1
+
+
+def test_world_size_mismatch_fails():
+    r = _run(['--gpus', '2', '--dry-run'], env=dict(WORLD_SIZE='1', RANK='0', LOCAL_RANK='0'))
+    assert r.returncode != 0 and 'WORLD_SIZE=1' in (r.stderr + r.stdout)

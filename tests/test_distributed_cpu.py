@@ -37,12 +37,40 @@ def fake_forward(tiles, offsets):
 
 
 def cpu_ops():
-    rb = lambda con, size, pad, **kw: torch.as_tensor(orc.remove_border_contours(
-        con.numpy(), size, pad, offsets=kw.pop('offsets').numpy().astype(np.float32), **kw))
-    sf = lambda con, size, ov, rule, offsets: torch.as_tensor(orc.filter_contours_by_stitching_rule(
-        con.numpy(), size, ov.numpy(), offsets=offsets.numpy().astype(np.float32)))
+    """CPU stand-ins with the batched signatures of the product ops, built from the oracle's per-tile functions."""
+    def border(contours, image_index, sides, offsets, size, pad):
+        con, b = contours.numpy(), image_index.numpy()
+        keep = np.zeros(len(con), bool)
+        for n in np.unique(b):
+            m = b == n
+            sd = int(sides[n])
+            keep[m] = orc.remove_border_contours(con[m], size, pad, top=bool(sd & 1), right=bool(sd & 2),
+                                                 bottom=bool(sd & 4), left=bool(sd & 8),
+                                                 offsets=offsets[n].numpy().astype(np.float32))
+        return torch.as_tensor(keep)
+
     nms = lambda b, s, t: torch.as_tensor(orc.nms(b.numpy(), s.numpy(), t))
-    return rb, sf, nms
+    return border, inference.stitch_rule_batched, nms
+
+
+def reference_loop(img, crop, strides, border, thr):
+    """The reference's per-tile loop (cpn_inference.py:357-408) restated with the oracle's per-tile functions."""
+    slices, overlaps, shape = orc.get_tiling_slices(tuple(img.shape[-2:]), crop, strides)
+    coll = {}
+    for idx, ((h0, h1), (w0, w1)) in enumerate(slices):
+        offs = torch.tensor([[w0, h0]])
+        y = fake_forward(img[..., h0:h1, w0:w1], offs)
+        h_i, w_i = np.unravel_index(idx, shape)
+        con = y['contours'][0].numpy()
+        neg = -offs[0].numpy().astype(np.float32)
+        keep = orc.remove_border_contours(con, crop, border, top=h_i > 0, right=w_i < shape[1] - 1,
+                                          bottom=h_i < shape[0] - 1, left=w_i > 0, offsets=neg)
+        keep &= orc.filter_contours_by_stitching_rule(con, crop, np.array(overlaps[idx]), offsets=neg)
+        for k in inference.KEYS:
+            v = y[k][0].numpy()[keep]
+            coll[k] = np.concatenate((coll[k], v)) if k in coll else v
+    keep = orc.nms(coll['boxes'], coll['scores'], thr)
+    return {k: v[keep] for k, v in coll.items()}
 
 
 class _Model:
@@ -77,6 +105,9 @@ def test_two_rank_gloo_matches_single_process():
                                        forward_fn=fake_forward, ops_fns=cpu_ops(), stitching_rule='nms,ex_br',
                                        rank=0, world_size=1)
     assert single['scores'].shape[0] > 10
+    ref = reference_loop(img, (64, 96), (48, 64), 4, _Model.nms_thresh)  # batched filtering == the per-tile loop
+    for k, v in single.items():
+        np.testing.assert_array_equal(v.numpy(), ref[k], err_msg=k)
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
@@ -106,3 +137,25 @@ def test_pack_unpack_roundtrip():
     back = inference.unpack_detections(inference.pack_detections(d), S, O)
     for k in inference.KEYS:
         assert torch.equal(back[k], d[k]) and back[k].dtype == d[k].dtype
+
+
+def test_slide_loop_reproduces_reference_stitching_with_duplicates():
+    """Host logic of the slide loop (tiling, sharding x3, batched border rule, packing, global NMS) on the fixture with
+    cross-tile duplicates: the result equals what the reference's functions produced (CPU stand-ins for the kernels)."""
+    import stitch_fixture as sf
+    g = sf.load()
+    H, W = (int(i) for i in g['size'])
+    img = torch.zeros(1, 3, H, W)
+    kw = dict(crop_size=tuple(int(i) for i in g['crop']), strides=tuple(int(i) for i in g['stride']), batch_size=5,
+              border_removal=int(g['border']), forward_fn=sf.forward_fn(g, 'cpu'), ops_fns=cpu_ops())
+    res = inference.tiled_inference(sf.StubModel(), img, rank=0, world_size=1, **kw)
+    assert res['scores'].shape[0] <= 0.9 * int(g['pre_nms_count'])
+    for k in inference.KEYS:
+        np.testing.assert_array_equal(res[k].numpy(), g[f'final.{k}'], err_msg=k)
+    # sharded: the union of the three ranks' local results, gathered by hand, gives the same final set
+    parts = [inference.tiled_inference(sf.StubModel(), img, rank=r, world_size=3, stitching_rule='', **kw) for r in range(3)]
+    boxes = torch.cat([p['boxes'] for p in parts])
+    scores = torch.cat([p['scores'] for p in parts])
+    assert scores.shape[0] == int(g['pre_nms_count'])
+    keep = orc.nms(boxes.numpy(), scores.numpy(), float(g['nms_thresh']))
+    np.testing.assert_array_equal(boxes.numpy()[keep], g['final.boxes'])

@@ -494,3 +494,86 @@ def test_bucketed_local_refinement_vs_reference_golden(dev, nb):
     got = ops.local_refinement(torch.as_tensor(g['refine_in']).to(dev), torch.as_tensor(g[f'refine_bucket_map_{nb}']).to(dev),
                                3, torch.as_tensor(g['refine_b']).to(dev), num_buckets=nb)
     np.testing.assert_array_equal(got.cpu().numpy(), g[f'refine_bucket_out_{nb}'])
+
+
+@pytest.mark.parametrize('P,extent', [(1, 50), (700, 100), (5000, 200), (40000, 800), (40000, 120)])
+def test_nms_binned_equals_dense_and_oracle(dev, P, extent):
+    """Spatially binned NMS (slide-level path) = dense bit-mask NMS = CPU oracle: identical keep lists incl. ties,
+    zero-area boxes (NaN IoU), duplicates and dense clusters (extent 120: ~thousands of overlaps per box)."""
+    import cpn_oracle as orc
+    from celldetection_amd import ops
+    rng = np.random.default_rng(P + extent)
+    xy = rng.uniform(0, extent, (P, 2)).astype(np.float32)
+    wh = rng.uniform(0, 20, (P, 2)).astype(np.float32)
+    boxes = np.concatenate((xy, xy + wh), 1)
+    boxes[::17, 2:] = boxes[::17, :2]  # zero-area
+    if P > 100:
+        boxes[5] = boxes[4]
+        boxes[50, :] = np.nan
+    scores = rng.random(P).astype(np.float32)
+    scores[::5] = scores[0]  # ties
+    b, s = torch.as_tensor(boxes).to(dev), torch.as_tensor(scores).to(dev)
+    for thr in (.2, 0.):
+        got, st = ops.nms_binned(b, s, thr, return_stats=True)
+        dense, cnt = ops._nms_segments(b, s, [0, P], thr)
+        np.testing.assert_array_equal(got.cpu().numpy(), dense[:cnt[0]].cpu().numpy())
+        if P <= 40000 and thr == .2:
+            np.testing.assert_array_equal(got.cpu().numpy(), orc.nms(boxes, scores, thr))
+        print(f'nms_binned P={P} extent={extent} thr={thr}: kept {got.numel()}, edges {st["edges"]}, sweeps {st["sweeps"]}, '
+              f'workspace {st["workspace_bytes"] / 1e6:.1f} MB')
+
+
+def test_nms_binned_slide_scale(dev):
+    """10^6 detections spread like cells on a slide: < 1 GB of workspace (the dense mask would need 125 GB), the keep
+    list is sorted by score, idempotent, and agrees with the dense path on a 60 000-box crop of the same set."""
+    from celldetection_amd import ops
+    P = 1_000_000
+    g = torch.Generator().manual_seed(5)
+    ctr = torch.rand(P, 2, generator=g) * 16384
+    wh = torch.rand(P, 2, generator=g) * 24 + 4
+    boxes = torch.cat((ctr - wh / 2, ctr + wh / 2), 1).to(dev)
+    scores = torch.rand(P, generator=g).to(dev)
+    keep, st = ops.nms_binned(boxes, scores, .2, return_stats=True)
+    print(f'slide-scale NMS: kept {keep.numel()} of {P}, edges {st["edges"]}, sweeps {st["sweeps"]}, '
+          f'workspace {st["workspace_bytes"] / 1e6:.0f} MB')
+    assert st['workspace_bytes'] < 1e9
+    ks = scores[keep]
+    assert bool((ks[:-1] >= ks[1:]).all()) and 0 < keep.numel() < P
+    again = ops.nms_binned(boxes[keep], ks, .2)
+    assert torch.equal(again, torch.arange(keep.numel(), device=dev))
+    sub = (ctr[:, 0] < 4000) & (ctr[:, 1] < 4000)
+    idx = sub.nonzero().squeeze(1)[:60000].to(dev)
+    a = ops.nms_binned(boxes[idx], scores[idx], .2)
+    d, c = ops._nms_segments(boxes[idx], scores[idx], [0, idx.numel()], .2)
+    assert torch.equal(a, d[:c[0]])
+
+
+def test_border_batched_equals_per_tile(dev, gops):
+    from celldetection_amd import ops
+    con = torch.as_tensor(gops['border_in']).to(dev)  # [40, 12, 2]
+    P = con.shape[0]
+    img = torch.arange(P, dtype=torch.int32, device=dev) % 3
+    sides = torch.tensor([15, 10, 5], dtype=torch.int32, device=dev)  # all / right+left / top+bottom
+    offs = torch.tensor([[-3., 5.], [0., 0.], [2., -1.]], device=dev)
+    got = ops.remove_border_contours_batched(con, img, sides, offs, (48, 64), 4).bool()
+    for n, (top, right, bottom, left) in enumerate([(True, True, True, True), (False, True, False, True),
+                                                    (True, False, True, False)]):
+        m = img == n
+        exp = ops.remove_border_contours(con[m], (48, 64), 4, top=top, right=right, bottom=bottom, left=left, offsets=offs[n])
+        assert torch.equal(got[m], exp)
+    np.testing.assert_array_equal(got[img == 0].cpu().numpy(), gops['border_keep_0'][(np.arange(P) % 3) == 0])
+
+
+@pytest.mark.parametrize('shape,size', [((2, 1, 16, 24), (64, 96)), ((1, 3, 19, 26), (75, 101)), ((2, 2, 76, 102), (75, 101)),
+                                        ((1, 1, 9, 9), (9, 31))])
+def test_resize_bilinear_f32_vs_torch_cpu(dev, shape, size):
+    """fp32 NCHW bilinear resize (score-bound masks, `_equal_size`) vs torch CPU's F.interpolate."""
+    from celldetection_amd.cpn import _equal_size
+    x = torch.rand(*shape, generator=torch.Generator().manual_seed(1))
+    ref = F.interpolate(x, size, mode='bilinear', align_corners=False)
+    got = _equal_size(x.to(dev), torch.empty(1, 1, *size)).cpu()
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=2e-7)
+    m = (x > .5).float()  # 0/1 masks: what the slide loop passes as score bounds
+    np.testing.assert_array_equal(_equal_size(m.to(dev), torch.empty(1, 1, *size)).cpu().numpy() > .9,
+                                  F.interpolate(m, size, mode='bilinear', align_corners=False).numpy() > .9)

@@ -92,8 +92,13 @@ def _emulate_packed_conv(op_desc, wblob, bblob, x0, x1):
     k, s, pad = op_desc.kh, op_desc.stride, op_desc.pad
     B, cin_b, cout_b = op_desc.bundles, op_desc.cin_b, op_desc.cout_b
     xin = x0 if x1 is None else torch.cat((x0, x1), 1)
-    w = wblob[op_desc.weight_offset // 2: op_desc.weight_offset // 2 + B * cin_b * k * k * cout_b].float()
-    w = w.reshape(B, cin_b // 32, k * k, cout_b, 32).permute(0, 3, 1, 4, 2).reshape(B * cout_b, cin_b, k, k)
+    items = (cin_b // 32) * k * k
+    slabs = items + items % 2  # an odd item count is padded with one all-zero slab (two items per pipeline step)
+    w = wblob[op_desc.weight_offset // 2: op_desc.weight_offset // 2 + B * slabs * cout_b * 32].float()
+    w = w.reshape(B, slabs, cout_b, 32)
+    if slabs != items:
+        assert float(w[:, -1].abs().max()) == 0.
+    w = w[:, :items].reshape(B, cin_b // 32, k * k, cout_b, 32).permute(0, 3, 1, 4, 2).reshape(B * cout_b, cin_b, k, k)
     b = bblob[op_desc.bias_offset: op_desc.bias_offset + B * cout_b]
     return F.conv2d(xin[:, :B * cin_b], w, b, s, pad, 1, B)
 
