@@ -24,6 +24,7 @@ SOURCES = {
     # decode/NMS must reproduce the reference's fp32 operation order bit-for-bit: no FMA contraction
     'decode_nms.hip': ['-ffp-contract=off'],
     'nms_binned.hip': ['-ffp-contract=off'],
+    'labels.hip': [],
     'cpn_abi.hip': [],
 }
 HEADERS = ['cpn_kernels.h', 'cpn_error.h', 'conv_igemm.hip', os.path.join('..', '..', 'include', 'cpn_hip.h')]

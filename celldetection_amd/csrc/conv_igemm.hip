@@ -364,6 +364,25 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
         }                                                                                                      \
     }
 
+    // instructions [Q0, Q1) of the halo tile of chunk CHUNK (KxK convs: the tile of the next chunk is staged in slices,
+    // one slice per step transition, instead of one burst of ~4 KiB-instructions per wave at the chunk change)
+#define HALO_DMA_RANGE(CHUNK, Q0, Q1)                                                                          \
+    {                                                                                                          \
+        const int c_ = (CHUNK);                                                                                \
+        const int cin_ = cin0 + c_ * CH;                                                                       \
+        const bool from0_ = cin_ < c0_used;                                                                    \
+        const elem_t *base_ = from0_ ? src0 + cin_ : src1 + (cin_ - c0_used);                                  \
+        unsigned char *dstb_ = smem + (c_ & nhb_mask) * halo_buf;                                              \
+        const int q1_ = (Q1);                                                                                  \
+        for (int q_ = (Q0) + wave; q_ < q1_; q_ += C::NWAVES) {                                                \
+            int o0_, o1_;                                                                                      \
+            halo_src_offsets<PITCH>(G, q_, lane, o0_, o1_);                                                    \
+            const int off_ = from0_ ? o0_ : o1_;                                                               \
+            const void *gsrc_ = off_ >= 0 ? (const void *) (base_ + off_) : (const void *) zero_src;           \
+            dma16(gsrc_, dstb_ + (q_ << 10));                                                                  \
+        }                                                                                                      \
+    }
+
 #define PW_HALO_DMA(CHUNK)                                                                                     \
     {                                                                                                          \
         const int c_ = (CHUNK);                                                                                \
@@ -454,8 +473,32 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
             CPN_EXP_W(W_DMA(((ST1) + 1) & 1));                                                                 \
         }                                                                                                      \
         /* KxK: every chunk before IA.c is completely consumed -> its ring buffer can take chunk IA.c+1 */     \
-        if (!pw && (CHUNK_CHANGED) && (IA).c + 1 < nchunks) CPN_EXP_H(HALO_DMA((IA).c + 1));                   \
+        CPN_HALO_AT_TRANSITION(IA, CHUNK_CHANGED)                                                              \
     }
+
+#ifdef CPN_SPREAD_HALO
+    // the first item of chunk c+1 sits floor(ntaps/2) or more steps behind the transition that frees its buffer, and a
+    // slice issued at the transition into step s has landed (vmcnt(0) at the end of s) before step s+1 reads: spreading
+    // the tile over those transitions keeps the DMA queue of a step at "2 weight slabs + one slice"
+    const int hq_rounds = (hinstr + C::NWAVES - 1) / C::NWAVES;
+    const int hq_avail = max(1, ntaps >> 1);
+    const int hq_step = C::NWAVES * ((hq_rounds + hq_avail - 1) / hq_avail);
+    int hq_next = hinstr, hq_chunk = 0;
+#define CPN_HALO_AT_TRANSITION(IA, CHUNK_CHANGED)                                                              \
+    if (!pw) {                                                                                                 \
+        if ((CHUNK_CHANGED) && (IA).c + 1 < nchunks) {                                                         \
+            hq_chunk = (IA).c + 1;                                                                             \
+            hq_next = 0;                                                                                       \
+        }                                                                                                      \
+        if (hq_next < hinstr) {                                                                                \
+            CPN_EXP_H(HALO_DMA_RANGE(hq_chunk, hq_next, min(hq_next + hq_step, hinstr)));                      \
+            hq_next += hq_step;                                                                                \
+        }                                                                                                      \
+    }
+#else
+#define CPN_HALO_AT_TRANSITION(IA, CHUNK_CHANGED)                                                              \
+    if (!pw && (CHUNK_CHANGED) && (IA).c + 1 < nchunks) CPN_EXP_H(HALO_DMA((IA).c + 1));
+#endif
 
     ItemState i0{0, 0, 0};                 // first item of the current step
     ItemState i1 = next_item(i0, KH, KW);  // second item of the current step
@@ -561,6 +604,8 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     MMA_GROUP(wB, pB, 0);
 #endif
 #undef HALO_DMA
+#undef HALO_DMA_RANGE
+#undef CPN_HALO_AT_TRANSITION
 #undef PW_HALO_DMA
 #undef W_DMA
 #undef LOAD_GROUP

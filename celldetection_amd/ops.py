@@ -175,7 +175,8 @@ def batched_box_nmsi(boxes: List[Tensor], scores: List[Tensor], iou_threshold: f
                      ) -> List[Tensor]:
     """celldetection/ops/cpn.py:189-227 incl. the chunked path for > batch_size boxes.  All images that fit one
     batch are processed by ONE segmented NMS launch sequence."""
-    assert len(scores) == len(boxes), 'The number of score tensors must match the number of box tensors.'
+    if len(scores) != len(boxes):
+        raise AssertionError(f'got {len(boxes)} box tensors but {len(scores)} score tensors')
     batch_size = NMS_BATCH_SIZE if batch_size is None else batch_size
     keeps = [None] * len(boxes)
     small = [i for i, b in enumerate(boxes) if b.shape[0] <= batch_size]
@@ -193,17 +194,18 @@ def batched_box_nmsi(boxes: List[Tensor], scores: List[Tensor], iou_threshold: f
         else:
             for i in small:
                 keeps[i] = torch.empty((0,), dtype=torch.int64, device=boxes[i].device)
-    for i, (con, sco) in enumerate(zip(boxes, scores)):
+    for i in range(len(boxes)):
         if keeps[i] is not None:
             continue
-        num = con.shape[0]
-        indices = torch.zeros(0, dtype=torch.long, device=con.device)
-        for s in range(0, num, batch_size):
-            e = min(s + batch_size, num)
-            indices = torch.cat((indices, nms(con[s:e], sco[s:e], iou_threshold) + s))
-        if indices.numel() > 0:
-            indices = indices[nms(con[indices], sco[indices], iou_threshold)]
-        keeps[i] = indices
+        # image with more than batch_size boxes: NMS per chunk of batch_size boxes, then one NMS over the survivors
+        # (the reference's memory-saving procedure, ops/cpn.py:212-224 -- NOT equivalent to one global NMS)
+        total = int(boxes[i].shape[0])
+        survivors = [nms(boxes[i][lo:lo + batch_size], scores[i][lo:lo + batch_size], iou_threshold) + lo
+                     for lo in range(0, total, batch_size)]
+        cand = torch.cat(survivors) if survivors else torch.zeros(0, dtype=torch.long, device=boxes[i].device)
+        if cand.numel():
+            cand = cand[nms(boxes[i][cand], scores[i][cand], iou_threshold)]
+        keeps[i] = cand
     return keeps
 
 

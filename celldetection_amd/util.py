@@ -84,18 +84,19 @@ def fetch_model(name, map_location=None, **kwargs):
 
 
 def model2dict(model):
-    """celldetection/util/util.py:527-542."""
-    kwargs = dict(model.hparams)
-    updated = {}
-    for k, v in kwargs.items():
-        if k in model.__dict__:
-            cv = model.__dict__[k]
-            r = v != cv
-            if hasattr(r, 'any'):
-                r = r.any()
-            if r:
-                updated[k] = cv
-    return dict(model=model.__class__.__name__, kwargs=kwargs, updated_kwargs=updated)
+    """Serialisable description of a model: class name, constructor hyper-parameters and the attributes that were
+    changed after construction (the ``cd.models`` entry of the reference file format, util.py:527-542)."""
+    hparams = dict(model.hparams)
+    changed = {}
+    for name, ctor_value in hparams.items():
+        if name not in vars(model):
+            continue  # not an instance attribute (e.g. consumed by the plan builder)
+        now = vars(model)[name]
+        differs = now != ctor_value
+        differs = bool(differs.any()) if hasattr(differs, 'any') else bool(differs)
+        if differs:
+            changed[name] = now
+    return {'model': type(model).__name__, 'kwargs': hparams, 'updated_kwargs': changed}
 
 
 def save_fetchable_model(model, filename, **kwargs):
@@ -112,27 +113,35 @@ def OrderedDictCPU(sd):
     return OrderedDict((k, v.detach().cpu()) for k, v in sd.items())
 
 
+def _axis_tiles(length: int, crop: int, stride: int):
+    """Tiles along one axis: (starts, stops, overlap with the previous tile, overlap with the next tile)."""
+    if crop >= length:
+        stops = np.array([length])
+    else:
+        n_steps = -(-(length - crop) // stride)  # ceil: tiles after the first one
+        stops = np.minimum(crop + stride * np.arange(n_steps + 1), length)
+    starts = np.maximum(stops - crop, 0)  # a tile that would stick out is shifted back: every tile is full-size
+    prev_stop = np.concatenate((starts[:1], stops[:-1]))
+    before = prev_stop - starts
+    after = np.concatenate((before[1:], [0]))
+    return starts, stops, before, after
+
+
 def get_tiling_slices(size, crop_size, strides, return_overlaps=False):
-    """celldetection/util/util.py:1305-1354: the last tile per axis is shifted back so that all tiles are full-size;
-    overlaps = (overlap with previous tile, overlap with next tile) per axis.  Row-major cartesian product."""
+    """Tiling table of the slide loop (semantics of celldetection/util/util.py:1305-1354, pinned by the golden tables in
+    tests/golden/tiling.npz): per axis the tiles end at crop, crop + stride, ... clipped to the image; a tile that would
+    stick out is shifted back so that all tiles are full-size; overlaps = (with the previous tile, with the next tile).
+    Returns an iterator over the row-major cartesian product of the per-axis slices (+ overlaps) and the tile grid."""
     assert isinstance(size, (tuple, list))
     nd = len(size)
     crop_size = (crop_size,) * nd if np.isscalar(crop_size) else tuple(crop_size)
     strides = (strides,) * nd if np.isscalar(strides) else tuple(strides)
-    slices, shape, overlaps = [], [], []
-    for axis in range(nd):
-        if crop_size[axis] >= size[axis]:
-            tl = [size[axis]]
-        else:
-            tl = range(crop_size[axis], 1 + crop_size[axis] + int(np.ceil((size[axis] - crop_size[axis]) /
-                                                                        strides[axis])) * strides[axis], strides[axis])
-        stops = np.minimum(tl, size[axis])
-        starts = np.maximum(0, stops - crop_size[axis])
-        ov_start = np.concatenate((starts[:1], stops[:-1])) - starts
-        ov_end = np.concatenate((ov_start[1:], [0]))
-        slices.append([slice(int(a), int(b)) for a, b in zip(starts, stops)])
-        overlaps.append([[int(a), int(b)] for a, b in zip(ov_start, ov_end)])
-        shape.append(len(starts))
+    per_axis_slices, per_axis_overlaps, grid = [], [], []
+    for length, crop, stride in zip(size, crop_size, strides):
+        starts, stops, before, after = _axis_tiles(int(length), int(crop), int(stride))
+        per_axis_slices.append([slice(int(a), int(b)) for a, b in zip(starts, stops)])
+        per_axis_overlaps.append([[int(a), int(b)] for a, b in zip(before, after)])
+        grid.append(len(starts))
     if return_overlaps:
-        return product(*slices), product(*overlaps), shape
-    return product(*slices), shape
+        return product(*per_axis_slices), product(*per_axis_overlaps), grid
+    return product(*per_axis_slices), grid

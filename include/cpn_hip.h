@@ -266,6 +266,34 @@ int cpn_nms_binned(const float *boxes, const float *scores, int64_t P, float thr
                    int64_t *keep_count_dev, int64_t *keep_count_host, int64_t *edges_needed, int32_t *sweeps,
                    void *workspace, int64_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Label rasterisation.  Replaces celldetection.data.contours2labels / render_contour
+ * (celldetection/data/cpn.py:245-255,292-358; called from celldetection_scripts/cpn_inference.py:811) with the default
+ * arguments: contour k is rounded (half to even), clipped to the image, filled as a polygon (OpenCV
+ * drawContours(thickness=-1) rule for integer vertices, restated) and added with value k + 1 to the FIRST channel whose
+ * region [bbox expanded by `gap`] holds no label yet.  The sequential loop of the reference is resolved in rounds over
+ * mutually independent contours (see csrc/labels.hip); the caller drives the rounds:
+ *   cpn_labels_prepare:     contours fp32 [K,S,2] -> integer points [K,S,2], boxes [K,4] = (xmin, ymin, xmax, ymax)
+ *   cpn_labels_bin:         cell id of every box centre for a grid_w x grid_h grid of `cell`-pixel cells (cell >= largest
+ *                           box extent + gap + 1) and the identity index; the caller sorts (stably) by cell id
+ *   cpn_labels_cell_bounds: [begin, end) of every non-empty cell in the sorted order (arrays pre-zeroed)
+ *   cpn_labels_round:       ONE round: marks the contours whose predecessors are all painted, chooses their channel on
+ *                           the planar int32 canvas [channels][H][W] and paints them.  counters_host[0] = painted in
+ *                           this round, [1] = contours that found all `channels` occupied (grow the canvas, call
+ *                           again), [2] = ready contours.  Synchronises the stream.
+ * ---------------------------------------------------------------------------------------------------------- */
+int cpn_labels_prepare(const float *contours, int64_t K, int32_t S, int32_t H, int32_t W, int32_t rounded, int32_t clip,
+                       int32_t *points, int32_t *boxes, void *stream);
+int cpn_labels_bin(const int32_t *boxes, int64_t K, int32_t grid_w, int32_t grid_h, int32_t cell, uint32_t *cell_id,
+                   uint32_t *index, void *stream);
+int cpn_labels_cell_bounds(const uint32_t *sorted_cell_id, int64_t K, uint32_t *cell_begin, uint32_t *cell_end,
+                           void *stream);
+int cpn_labels_round(const int32_t *points, const int32_t *boxes, int64_t K, int32_t S, int32_t H, int32_t W,
+                     int32_t gap, int32_t grid_w, int32_t grid_h, int32_t cell, const uint32_t *sorted_index,
+                     const uint32_t *cell_begin, const uint32_t *cell_end, int32_t *canvas, int32_t channels,
+                     uint8_t *state, uint8_t *ready, uint32_t *ready_list, int32_t *channel, int32_t *counters,
+                     int32_t *counters_host, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -134,9 +134,10 @@ def test_end_to_end_match_rate(dev, name):
     for i in range(x.shape[0]):
         rates.append(_iou_match_rate(y['boxes'][i].cpu().numpy(), g[f'nonms.boxes.{i}']))
         n_ref, n_got = len(g[f'nonms.scores.{i}']), len(y['scores'][i])
-        assert abs(n_ref - n_got) <= max(3, 0.25 * n_ref), f'{name}[{i}]: proposals {n_got} vs reference {n_ref}'
+        # measured (round 2, six model families): match rates 0.956 .. 1.0, counts within a few per cent
+        assert abs(n_ref - n_got) <= max(3, 0.1 * n_ref), f'{name}[{i}]: proposals {n_got} vs reference {n_ref}'
     print(name, 'proposal IoU>0.5 match rates', rates)
-    assert min(rates) > .7, rates
+    assert min(rates) > .9, rates
     y = model(x)  # with NMS: output contract
     assert list(y.keys()) == ['contours', 'boxes', 'scores', 'classes', 'locations', 'fourier', 'contour_proposals',
                               'box_uncertainties']
@@ -201,7 +202,7 @@ def test_tiled_inference_stitching(dev):
     # (2) vs the reference (bf16 conv stack => matched, not identical)
     rate = _iou_match_rate(res['boxes'].cpu().numpy(), g['final.boxes'])
     print('stitch: detections', len(res['scores']), 'reference', len(g['final.scores']), 'match rate', rate)
-    assert rate > .7
+    assert rate > .85  # measured 0.93
 
 
 @pytest.mark.parametrize('name', list(MODEL_SPECS))
@@ -437,7 +438,7 @@ def test_full_size_properties(dev):
     got8 = model(x[:1], nms=False)
     rate8 = _iou_match_rate(got8['boxes'][0].cpu().numpy(), ref['boxes'][0])
     print('full size tile 0 fp8: proposals', len(got8['scores'][0]), 'IoU>0.5 match rate', rate8)
-    assert abs(n_ref - len(got8['scores'][0])) <= 0.25 * n_ref and rate8 > .75
+    assert abs(n_ref - len(got8['scores'][0])) <= 0.2 * n_ref and rate8 > .8  # measured 0.897
 
 
 @pytest.mark.parametrize('name', ['CpnU22', 'CpnU22_wide', 'CpnResNeXt101UNet', 'CpnResNet18FPN', 'CpnResNet50FPN'])
@@ -463,7 +464,7 @@ def test_fp8_precision_vs_reference_maps(dev, name):
     y = model(x, nms=False)
     rates = [_iou_match_rate(y['boxes'][i].cpu().numpy(), g[f'nonms.boxes.{i}']) for i in range(x.shape[0])]
     print(name, 'fp8 proposal IoU>0.5 match rates', rates)
-    assert min(rates) > .5, rates
+    assert min(rates) > .8, rates  # measured 0.89 .. 0.99
     # the same fp8 algorithm restated on the CPU (oracle/fp8_sim.py: identical codes, scales and weights).  A deep
     # quantised graph is chaotic -- one e4m3 rounding that differs because of the fp32 summation order shifts ~1
     # rounding decision in the next layer, so after 30..120 layers the two noise realisations are decorrelated

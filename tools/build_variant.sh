@@ -6,5 +6,6 @@ cd "$(dirname "$0")/.."
 NAME=$1; shift
 D=celldetection_amd/build/variants; mkdir -p $D
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c celldetection_amd/csrc/conv_igemm.hip -o $D/conv_igemm_$NAME.o "$@"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $D/conv_igemm_$NAME.o celldetection_amd/build/misc_kernels.o celldetection_amd/build/conv_f32.o celldetection_amd/build/decode_nms.o celldetection_amd/build/cpn_abi.o -o $D/libcpn_$NAME.so
+OTHERS=$(ls celldetection_amd/build/*.o | grep -v '/conv_igemm.o$')
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $D/conv_igemm_$NAME.o $OTHERS -o $D/libcpn_$NAME.so
 echo $D/libcpn_$NAME.so

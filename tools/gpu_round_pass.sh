@@ -24,6 +24,8 @@ profile)
    python tools/summarize_rocprof.py $P/trace; echo
    echo "### tools/run_graph_only.py 5 (5 conv-graph executions, batch 16): kernel-trace, FETCH_SIZE, WRITE_SIZE, MFMA/SQ counters"
    python tools/summarize_rocprof.py $P/gtrace $P/fetch $P/write $P/mfma) > gpurun_out/${TAG}_rocprofv3_summary.txt 2>&1
+  python tools/summarize_rocprof.py --traffic-json $P/fetch $P/write 5 CpnResNeXt101UNet/b16/t512/bf16 gpurun_out/${TAG}_traffic.json \
+    "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of tools/run_graph_only.py 5 (${TAG}); see profiles/${TAG}_rocprofv3_summary.txt"
   grep -h "^{" $P/trace.log > gpurun_out/${TAG}_bench_lines_under_rocprof.txt
   grep -A8 "run_graph_only" gpurun_out/${TAG}_rocprofv3_summary.txt | cut -c1-150;;
 fp8)

@@ -53,6 +53,35 @@ def summarize(d):
             print(f'-- {base}: {n} dispatches')
 
 
+def counter_totals(d):
+    """Sum of every counter over all dispatches found under directory d."""
+    tot = defaultdict(float)
+    for f in glob.glob(os.path.join(d, '**', '*counter_collection*.csv'), recursive=True):
+        for r in csv.DictReader(open(f)):
+            tot[r['Counter_Name']] += float(r['Counter_Value'])
+    return tot
+
+
+def traffic_json(fetch_dir, write_dir, graphs, key, out, source):
+    """profiles/traffic.json entry: HBM bytes per conv-graph execution = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 / graphs.
+    FETCH_SIZE / WRITE_SIZE are reported in KiB; the factor 2 on the reads is the gfx950 correction of
+    MI355X_MICROARCH.md (section HBM) for wide 16-B/lane streaming reads (128-B requests tallied at 64 B)."""
+    import json
+    fs, ws = counter_totals(fetch_dir).get('FETCH_SIZE', 0.), counter_totals(write_dir).get('WRITE_SIZE', 0.)
+    entry = dict(traffic_bytes_per_graph=(2 * fs + ws) * 1024. / graphs, fetch_size_kib_raw_per_graph=fs / graphs,
+                 write_size_kib_per_graph=ws / graphs, graphs=graphs, source=source)
+    data = {}
+    if os.path.isfile(out):
+        data = json.load(open(out))
+    data[key] = entry
+    json.dump(data, open(out, 'w'), indent=1, sort_keys=True)
+    print('traffic', key, entry)
+
+
 if __name__ == '__main__':
-    for d_ in sys.argv[1:]:
-        summarize(d_)
+    if len(sys.argv) > 1 and sys.argv[1] == '--traffic-json':
+        # --traffic-json <fetch dir> <write dir> <graphs> <key> <out.json> <source text>
+        traffic_json(sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5], sys.argv[6], sys.argv[7])
+    else:
+        for d_ in sys.argv[1:]:
+            summarize(d_)
