@@ -92,6 +92,8 @@ _SIGNATURES = [
                                                c_void_p]),
     ('cpn_border_keep_batched', ctypes.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
                                                c_float, c_float, c_float, c_void_p, c_void_p]),
+    ('cpn_histogram', ctypes.c_int, [c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
+    ('cpn_rescale_to_uint8', ctypes.c_int, [c_void_p, c_int32, c_int64, c_double, c_double, c_void_p, c_void_p]),
     ('cpn_labels_prepare', ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                           c_void_p, c_void_p]),
     ('cpn_labels_bin', ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),

@@ -506,4 +506,17 @@ int cpn_convert_input(const void *src, int32_t in_dtype, void *dst, int32_t N, i
     return check_hip((hipError_t) launch_input(a, (hipStream_t) stream), "cpn_convert_input");
 }
 
+int cpn_histogram(const void *x, int32_t dtype, int64_t n, uint32_t *hist, void *stream) {
+    if (!x || !hist || n < 0 || (dtype != 1 && dtype != 2)) return fail(CPN_E_INVALID, "cpn_histogram: dtype 1 (u8) or 2 (u16)");
+    if (n == 0) return 0;
+    return check_hip((hipError_t) launch_histogram(x, dtype, (long) n, hist, (hipStream_t) stream), "cpn_histogram");
+}
+
+int cpn_rescale_to_uint8(const void *x, int32_t dtype, int64_t n, double low, double high, uint8_t *out, void *stream) {
+    if (!x || !out || n < 0 || dtype < 0 || dtype > 2) return fail(CPN_E_INVALID, "cpn_rescale_to_uint8: dtype 0 (f32), 1 (u8), 2 (u16)");
+    if (!(high > low)) return fail(CPN_E_INVALID, "cpn_rescale_to_uint8: needs high > low");
+    if (n == 0) return 0;
+    return check_hip((hipError_t) launch_rescale_u8(x, dtype, (long) n, low, high, out, (hipStream_t) stream), "cpn_rescale_to_uint8");
+}
+
 }  // extern "C"

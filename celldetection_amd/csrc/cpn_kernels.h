@@ -93,6 +93,10 @@ int launch_input_f32(const InputArgs &a, hipStream_t stream);
 int launch_maxpool_f32(const PoolArgs &a, hipStream_t stream);
 int launch_bilinear_f32(const ResizeArgs &a, hipStream_t stream);
 
+// slide preprocessing: value histogram (dtype 1 = u8: 256 bins, 2 = u16: 65536 bins) and percentile rescale to uint8
+int launch_histogram(const void *x, int dtype, long n, unsigned int *hist, hipStream_t stream);
+int launch_rescale_u8(const void *x, int dtype, long n, double low, double high, unsigned char *out, hipStream_t stream);
+
 // fp8 (e4m3) helper kernels (csrc/misc_fp8.hip) and the calibration reduction
 int launch_input_fp8(const InputArgs &a, float inv_scale, hipStream_t stream);
 int launch_maxpool_fp8(const PoolArgs &a, hipStream_t stream);

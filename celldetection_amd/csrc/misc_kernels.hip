@@ -159,4 +159,62 @@ int launch_bilinear(const ResizeArgs &a, hipStream_t stream) {
     return (int) hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// percentile normalisation of a whole slide before tiling (celldetection_scripts/cpn_inference.py:196-222 `preprocess`
+// -> cd.data.normalize_percentile, celldetection/data/misc.py:156-161): value histogram of 8/16-bit integer images
+// (exact order statistics without sorting 10^9 values) and the clip/rescale/round-to-uint8 pass
+template <typename T>
+__global__ __launch_bounds__(256) void histogram_kernel(const T *__restrict__ x, long n, unsigned int *__restrict__ hist) {
+    // 8-bit: per-block LDS histogram; 16-bit: 65536 bins do not fit the per-block budget -> global atomics (values of
+    // natural images spread over thousands of bins: little contention)
+    __shared__ unsigned int lh[256];
+    constexpr bool small = sizeof(T) == 1;
+    if (small) {
+        lh[threadIdx.x] = 0;
+        __syncthreads();
+    }
+    for (long i = blockIdx.x * 256l + threadIdx.x; i < n; i += (long) gridDim.x * 256l) {
+        const unsigned int v = (unsigned int) x[i];
+        if (small) atomicAdd(&lh[v], 1u);
+        else atomicAdd(&hist[v], 1u);
+    }
+    if (small) {
+        __syncthreads();
+        if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rescale_u8_kernel(const T *__restrict__ x, long n, double low, double high,
+                                                        unsigned char *__restrict__ out) {
+    // img = (clip(image, low, high) - low) / (high - low)  (float64, data/misc.py:160); img_as_ubyte: rint(img * 255)
+    const double inv = high - low;
+    for (long i = blockIdx.x * 256l + threadIdx.x; i < n; i += (long) gridDim.x * 256l) {
+        double v = (double) x[i];
+        v = fmin(fmax(v, low), high);
+        v = (v - low) / inv;
+        v = rint(v * 255.0);
+        out[i] = (unsigned char) fmin(fmax(v, 0.0), 255.0);
+    }
+}
+
+int launch_histogram(const void *x, int dtype, long n, unsigned int *hist, hipStream_t stream) {
+    int blocks = (int) ((n + 256 * 16 - 1) / (256 * 16));
+    blocks = blocks < 1 ? 1 : (blocks > 256 * 32 ? 256 * 32 : blocks);
+    if (dtype == 1) hipLaunchKernelGGL(histogram_kernel<unsigned char>, dim3(blocks), dim3(256), 0, stream, (const unsigned char *) x, n, hist);
+    else if (dtype == 2) hipLaunchKernelGGL(histogram_kernel<unsigned short>, dim3(blocks), dim3(256), 0, stream, (const unsigned short *) x, n, hist);
+    else return (int) hipErrorInvalidValue;
+    return (int) hipGetLastError();
+}
+
+int launch_rescale_u8(const void *x, int dtype, long n, double low, double high, unsigned char *out, hipStream_t stream) {
+    int blocks = (int) ((n + 256 * 8 - 1) / (256 * 8));
+    blocks = blocks < 1 ? 1 : (blocks > 256 * 64 ? 256 * 64 : blocks);
+    if (dtype == 0) hipLaunchKernelGGL(rescale_u8_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float *) x, n, low, high, out);
+    else if (dtype == 1) hipLaunchKernelGGL(rescale_u8_kernel<unsigned char>, dim3(blocks), dim3(256), 0, stream, (const unsigned char *) x, n, low, high, out);
+    else if (dtype == 2) hipLaunchKernelGGL(rescale_u8_kernel<unsigned short>, dim3(blocks), dim3(256), 0, stream, (const unsigned short *) x, n, low, high, out);
+    else return (int) hipErrorInvalidValue;
+    return (int) hipGetLastError();
+}
+
 }  // namespace cpn

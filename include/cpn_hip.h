@@ -266,6 +266,15 @@ int cpn_nms_binned(const float *boxes, const float *scores, int64_t P, float thr
                    int64_t *keep_count_dev, int64_t *keep_count_host, int64_t *edges_needed, int32_t *sweeps,
                    void *workspace, int64_t workspace_bytes, void *stream);
 
+/* Slide preprocessing before tiling: `preprocess` -> cd.data.normalize_percentile
+ * (celldetection_scripts/cpn_inference.py:196-222, celldetection/data/misc.py:156-161).
+ * cpn_histogram: value histogram of an 8-bit (dtype 1, 256 bins) or 16-bit (dtype 2, 65536 bins) image into the
+ * pre-zeroed uint32 array `hist` (the caller derives np.percentile's interpolated order statistics from it).
+ * cpn_rescale_to_uint8: out = uint8(rint(((clip(x, low, high) - low) / (high - low)) * 255)) in float64
+ * (normalize_percentile + skimage.img_as_ubyte); x: dtype 0 = f32, 1 = u8, 2 = u16. */
+int cpn_histogram(const void *x, int32_t dtype, int64_t n, uint32_t *hist, void *stream);
+int cpn_rescale_to_uint8(const void *x, int32_t dtype, int64_t n, double low, double high, uint8_t *out, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Label rasterisation.  Replaces celldetection.data.contours2labels / render_contour
  * (celldetection/data/cpn.py:245-255,292-358; called from celldetection_scripts/cpn_inference.py:811) with the default
