@@ -149,12 +149,13 @@ class _Engine:
             raise RuntimeError('refinement head output does not have the input size')  # cpn.py:279 would resize it
         self.last_uncertainty = torch.empty((n, 4, hh, ww), **f32) if meta.get('uncertainty_head') else None
         flag = torch.zeros(1, dtype=torch.int32, device=self.device)
-        # the kernels address activation tensors with 32-bit element offsets: split the batch when a tensor of the
-        # graph would reach 2^31 elements (e.g. 8 x 256 ch x 1024^2 in front of an FPN refinement head)
+        # the kernels address activation tensors with 32-bit offsets / 2^31-byte buffer descriptors: split the batch when
+        # a tensor of the graph would exceed that (e.g. 8 x 256 ch x 1024^2 in front of an FPN refinement head)
         per_image = int(lib.cpn_plan_max_tensor_elements(self.handle, h, w))
         if per_image <= 0:
             _lib.check(per_image or _lib.E_INVALID, 'plan_max_tensor_elements')
-        nb = max(1, min(n, (2 ** 31 - 1) // per_image))
+        limit = (2 ** 31 - 1) // (2 if self.precision == 'bf16' else 1)  # sources: 2^31 bytes (fp32 path: elements)
+        nb = max(1, min(n, limit // per_image))
         if _timed is not None and nb < n:
             raise ValueError('per-op profiling needs a batch whose tensors stay below 2^31 elements')
         ws, need = self.workspace(nb, h, w)

@@ -73,7 +73,6 @@ typedef bf16x8 frag_t;  // 8 bf16
 constexpr int REC = 64;  // LDS bytes per 32-channel record (pixel or weight row)
 constexpr int TW = 32;   // output tile width in pixels (= one MFMA column fragment)
 
-__device__ __attribute__((aligned(16))) unsigned int g_zero16[4];  // source of zero padding for the halo DMA
 
 // two fp32 -> packed bf16 pair (lo, hi), round to nearest even: one v_cvt_pk_bf16_f32 on gfx950 (the software
 // sequence cost ~7 VALU per element and made the epilogue of the memory-bound layers VALU-bound)
@@ -125,10 +124,19 @@ __device__ __forceinline__ void add_res8(float (&v)[8], const store8_t r, float)
 }
 #endif
 
-__device__ __forceinline__ void dma16(const void *gsrc, unsigned char *lds_wave_base) {
-    // 64 lanes x 16 B -> LDS [lds_wave_base + lane*16]; the LDS base must be wave-uniform
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) gsrc,
-                                     (__attribute__((address_space(3))) void *) lds_wave_base, 16, 0, 0);
+// LDS-DMA through a raw buffer descriptor (buffer_load_dwordx4 ... offen lds): 64 lanes x 16 B -> LDS
+// [lds_wave_base + lane*16] (wave-uniform base).  Address = descriptor base + per-lane 32-bit byte offset + scalar byte
+// offset: no 64-bit address arithmetic per instruction, and a lane whose offset lies beyond the descriptor's size
+// receives ZEROS (tools/probes/buffer_lds_probe.hip: voffset + soffset + 16 > num_records -> 0) -- that is the conv's
+// zero padding; OOB_LANE is the offset used for such lanes (tensors are limited to 2^31 bytes, see cpn_abi.hip)
+constexpr unsigned OOB_LANE = 0x80000000u;
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *) base, 0, (int) bytes, 0x00020000);
+}
+__device__ __forceinline__ void bdma16(rsrc_t rsrc, unsigned lane_off, unsigned scalar_off, unsigned char *lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *) lds_wave_base, 16,
+                                             (int) lane_off, (int) scalar_off, 0, 0);
 }
 
 enum Mode : int { MODE_PW = 0, MODE_S1 = 1, MODE_S2 = 2 };  // pointwise stride 1 / KxK stride 1 / stride 2
@@ -309,9 +317,8 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
 
     // halo DMA instruction q (0..hinstr) is issued by wave q % NWAVES; the source offsets are recomputed per issue
     // (a few VALU per 1-KiB DMA; keeping them in registers cost 10 VGPRs of a kernel that sits at the 256 limit)
-    const elem_t *const src0 = (const elem_t *) a.src0;
-    const elem_t *const src1 = (const elem_t *) a.src1;
-    const unsigned char *const zero_src = (const unsigned char *) g_zero16;
+    const rsrc_t rs0 = make_rsrc(a.src0, (unsigned) ((size_t) a.N * a.Hs0 * a.Ws0 * a.c0_stride * ES));
+    const rsrc_t rs1 = make_rsrc(a.src1, a.src1 ? (unsigned) ((size_t) a.N * a.Hs1 * a.Ws1 * a.c1_stride * ES) : 0u);
 
     // weight DMA: instruction q = wave + it*NWAVES of a step covers item k = q / W_INSTR_ITEM, rows qi*16..+15 of
     // the BN tile; lane -> (row, swizzled 16-B part).  Everything that does not change from step to step is
@@ -330,12 +337,12 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
         w_voff[it] = (n0 + qi * 16 + (lane >> 2) < cout_b) ? (unsigned) (qi << 10) + w_dma_lane
                                                            : (w_dma_lane & 63u);
     }
-    const size_t item_bytes = (size_t) cout_b * REC;
-    // slab of the first item of the NEXT step to be staged (steps are staged in order, two items each)
-    const unsigned char *wptr = (const unsigned char *) a.weights + ((size_t) g * nitems * cout_b + n0) * REC;
+    const unsigned item_bytes = (unsigned) cout_b * REC;
+    const rsrc_t rsw = make_rsrc(a.weights, (unsigned) ((size_t) a.bundles * nitems * cout_b * REC));
+    // byte offset of the slab of the first item of the NEXT step to be staged (steps are staged in order, two items each)
+    unsigned wsoff = (unsigned) (((size_t) g * nitems * cout_b + n0) * REC);
 
-    // 1x1 fast path of the activation-tile DMA: single full-resolution source -> per-lane offsets are loop constants;
-    // out-of-image lanes are masked off (their LDS bytes stay stale: they only feed output pixels never stored)
+    // 1x1 fast path of the activation-tile DMA: single full-resolution source -> per-lane offsets are loop constants
     constexpr int A_INSTR_WAVE = PW ? (TH * 2 + C::NWAVES - 1) / C::NWAVES : 1;
     const bool pw_fast = PW && a.src1 == nullptr && !a.up0;
     unsigned a_voff[A_INSTR_WAVE];
@@ -344,61 +351,47 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     for (int it = 0; it < A_INSTR_WAVE; ++it) {
         int o0 = -1, o1 = -1;
         if (PW) halo_src_offsets<PITCH>(G, wave + it * C::NWAVES, lane, o0, o1);
-        a_ok[it] = o0 >= 0 && (wave + it * C::NWAVES) < hinstr;
-        a_voff[it] = (unsigned) (o0 < 0 ? 0 : o0) * (unsigned) ES;
+        a_ok[it] = (wave + it * C::NWAVES) < hinstr;  // (wave-uniform) the instruction exists
+        a_voff[it] = o0 < 0 ? OOB_LANE : (unsigned) o0 * (unsigned) ES;  // out-of-image lanes read zeros
     }
 
-#define HALO_DMA(CHUNK)                                                                                        \
-    {                                                                                                          \
-        const int c_ = (CHUNK);                                                                                \
-        const int cin_ = cin0 + c_ * CH;                                                                       \
-        const bool from0_ = cin_ < c0_used;                                                                    \
-        const elem_t *base_ = from0_ ? src0 + cin_ : src1 + (cin_ - c0_used);                                  \
-        unsigned char *dstb_ = smem + (c_ & nhb_mask) * halo_buf;                                              \
-        for (int q_ = wave; q_ < hinstr; q_ += C::NWAVES) {                                                    \
-            int o0_, o1_;                                                                                      \
-            halo_src_offsets<PITCH>(G, q_, lane, o0_, o1_);                                                    \
-            const int off_ = from0_ ? o0_ : o1_;                                                               \
-            const void *gsrc_ = off_ >= 0 ? (const void *) (base_ + off_) : (const void *) zero_src;           \
-            dma16(gsrc_, dstb_ + (q_ << 10));                                                                  \
-        }                                                                                                      \
-    }
+#define HALO_DMA(CHUNK) HALO_DMA_RANGE(CHUNK, 0, hinstr)
 
-    // instructions [Q0, Q1) of the halo tile of chunk CHUNK (KxK convs: the tile of the next chunk is staged in slices,
-    // one slice per step transition, instead of one burst of ~4 KiB-instructions per wave at the chunk change)
+    // instructions [Q0, Q1) of the halo tile of chunk CHUNK
 #define HALO_DMA_RANGE(CHUNK, Q0, Q1)                                                                          \
     {                                                                                                          \
         const int c_ = (CHUNK);                                                                                \
         const int cin_ = cin0 + c_ * CH;                                                                       \
         const bool from0_ = cin_ < c0_used;                                                                    \
-        const elem_t *base_ = from0_ ? src0 + cin_ : src1 + (cin_ - c0_used);                                  \
+        const unsigned soff_ = (unsigned) (from0_ ? cin_ : cin_ - c0_used) * (unsigned) ES;                    \
         unsigned char *dstb_ = smem + (c_ & nhb_mask) * halo_buf;                                              \
         const int q1_ = (Q1);                                                                                  \
         for (int q_ = (Q0) + wave; q_ < q1_; q_ += C::NWAVES) {                                                \
             int o0_, o1_;                                                                                      \
             halo_src_offsets<PITCH>(G, q_, lane, o0_, o1_);                                                    \
             const int off_ = from0_ ? o0_ : o1_;                                                               \
-            const void *gsrc_ = off_ >= 0 ? (const void *) (base_ + off_) : (const void *) zero_src;           \
-            dma16(gsrc_, dstb_ + (q_ << 10));                                                                  \
+            const unsigned voff_ = off_ >= 0 ? (unsigned) off_ * (unsigned) ES : OOB_LANE;                     \
+            if (from0_) bdma16(rs0, voff_, soff_, dstb_ + (q_ << 10));                                         \
+            else bdma16(rs1, voff_, soff_, dstb_ + (q_ << 10));                                                \
         }                                                                                                      \
     }
 
 #define PW_HALO_DMA(CHUNK)                                                                                     \
     {                                                                                                          \
         const int c_ = (CHUNK);                                                                                \
-        const unsigned char *base_ = (const unsigned char *) (src0 + cin0 + c_ * CH);                          \
+        const unsigned soff_ = (unsigned) (cin0 + c_ * CH) * (unsigned) ES;                                    \
         unsigned char *dstb_ = smem + (c_ & nhb_mask) * halo_buf;                                              \
         _Pragma("unroll") for (int it = 0; it < A_INSTR_WAVE; ++it)                                            \
-            if (a_ok[it]) dma16(base_ + a_voff[it], dstb_ + ((wave + it * C::NWAVES) << 10));                  \
+            if (a_ok[it]) bdma16(rs0, a_voff[it], soff_, dstb_ + ((wave + it * C::NWAVES) << 10));             \
     }
 
     // stages the (two) weight slabs of the next step in order into weight buffer BUF
 #define W_DMA(BUF)                                                                                             \
     {                                                                                                          \
-        const unsigned char *s0_ = wptr, *s1_ = wptr + item_bytes;                                             \
+        const unsigned s0_ = wsoff, s1_ = wsoff + item_bytes;                                                  \
         _Pragma("unroll") for (int it = 0; it < C::W_INSTR_WAVE; ++it)                                         \
-            dma16((w_k[it] ? s1_ : s0_) + w_voff[it], smem + w_m0[it] + (BUF) * WBUF);                         \
-        wptr += 2 * item_bytes;                                                                                \
+            bdma16(rsw, w_voff[it], w_k[it] ? s1_ : s0_, smem + w_m0[it] + (BUF) * WBUF);                      \
+        wsoff += 2 * item_bytes;                                                                               \
     }
 
     // ---- accumulators

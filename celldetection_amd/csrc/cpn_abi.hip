@@ -212,9 +212,14 @@ static int build_conv_args(const cpn_plan *p, const cpn_op_desc &o, int N, ConvA
     }
     if (o.bundles > 1 && s1) return fail(CPN_E_INVALID, "conv: grouped conv with two sources");
     if (!s1 && o.c0_used < o.bundles * o.cin_b) return fail(CPN_E_INVALID, "conv: c0_used smaller than input channels");
-    if ((int64_t) N * a.Hs0 * a.Ws0 * c0s >= (1ll << 31) || (s1 && (int64_t) N * a.Hs1 * a.Ws1 * c1s >= (1ll << 31)) ||
+    // sources are read through raw buffer descriptors whose out-of-range sentinel is byte offset 2^31 (conv_igemm.hip):
+    // a source tensor may hold at most 2^31 BYTES (fp32 verification path: 2^31 elements); destinations are addressed
+    // with 32-bit element offsets
+    const int64_t src_limit = (p && p->precision == CPN_PRECISION_F32) ? (1ll << 31) : (1ll << 31) / (kc == 64 ? 1 : 2);
+    if ((int64_t) N * a.Hs0 * a.Ws0 * c0s >= src_limit || (s1 && (int64_t) N * a.Hs1 * a.Ws1 * c1s >= src_limit) ||
         (int64_t) N * a.Hout * a.Wout * std::max(ds, 1) >= (1ll << 31))
-        return fail(CPN_E_UNSUPPORTED, "conv: tensor exceeds 2^31 elements (32-bit offsets)");
+        return fail(CPN_E_UNSUPPORTED, "conv: tensor too large for one launch (sources: 2^31 bytes, destination: 2^31 "
+                                       "elements); split the batch");
     // plain 1x1 convs are GEMMs over the flattened pixel axis: re-tile as [1, M/32, 32] so that narrow images
     // (16x16 at stride 32) still fill the 32-pixel MFMA column fragments
     if (o.kh == 1 && o.kw == 1 && o.stride == 1 && o.pad == 0 && !o.up0 && !o.up1 && !o.res_up &&
