@@ -238,7 +238,8 @@ class CPN(nn.Module):
         # that was not called, from the first batch that is forwarded)
         self.precision = 'bf16'
         self._fp8_scales = None
-        self._plan = graph.build_plan(**self._plan_kwargs)
+        self._plan = graph.build_plan(**self._plan_kwargs)  # bf16: fused ReadOut tails + fused bilinear head source
+        self._alt_plans = {}
         for key, shape, kind in self._plan.entries:
             _register(self, key, shape, kind)
         self.core.order = order
@@ -275,6 +276,17 @@ class CPN(nn.Module):
             raise NotImplementedError('celldetection_amd.CPN is an inference engine; training is out of scope.')
         return super().train(False)
 
+    def plan_for(self, precision: str) -> graph.Plan:
+        """Layer plan per precision: bf16 fuses the ReadOut tails and the bilinear resize in front of the refinement head;
+        fp8 keeps that resize as its own op (on e4m3 codes; also the plan its bf16 calibration run uses, so that the
+        tensor ids of the activation scales match); fp32 (verification) fuses nothing."""
+        if precision == 'bf16':
+            return self._plan
+        if precision not in self._alt_plans:
+            extra = dict(fuse_bilinear=False) if precision == 'fp8' else dict(fuse_readout=False, fuse_bilinear=False)
+            self._alt_plans[precision] = graph.build_plan(**self._plan_kwargs, **extra)
+        return self._alt_plans[precision]
+
     def engine(self, device=None, calibration_input=None) -> _Engine:
         device = torch.device(device) if device is not None else self.order_weights_device()
         if device.type != 'cuda':
@@ -292,21 +304,20 @@ class CPN(nn.Module):
                                   'batch; activations of later batches that exceed its range saturate at 448 * scale. '
                                   'Call calibrate_fp8() on representative tiles instead.', RuntimeWarning, stacklevel=3)
                     self.calibrate_fp8(calibration_input)
-                self._engine = _Engine(self._plan, self.state_dict(), device, 'fp8', act_scales=self._fp8_scales)
+                self._engine = _Engine(self.plan_for('fp8'), self.state_dict(), device, 'fp8', act_scales=self._fp8_scales)
             else:
-                plan = self._plan if self.precision == 'bf16' else graph.build_plan(**self._plan_kwargs,
-                                                                                   fuse_readout=False)
-                self._engine = _Engine(plan, self.state_dict(), device, self.precision)
+                self._engine = _Engine(self.plan_for(self.precision), self.state_dict(), device, self.precision)
         return self._engine
 
     @torch.no_grad()
     def calibrate_fp8(self, inputs: torch.Tensor):
         """Static e4m3 activation scales (one per tensor of the conv graph) from ONE bf16 run on ``inputs``:
         scale = max|x| / 448.  Weight scales are per output channel and need no data."""
-        eng = _Engine(self._plan, self.state_dict(), inputs.device, 'bf16')
+        plan = self.plan_for('fp8')
+        eng = _Engine(plan, self.state_dict(), inputs.device, 'bf16')
         absmax = eng.activation_absmax(inputs, self.core.order, self.refinement)
         self._fp8_scales = [max(float(v), 1e-12) / 448. for v in absmax.tolist()]
-        for op in self._plan.ops:  # max-pool / bilinear kernels work on the codes: output scale == input scale
+        for op in plan.ops:  # max-pool / bilinear kernels work on the codes: output scale == input scale
             if op['op'] in ('maxpool', 'bilinear'):
                 self._fp8_scales[op['dst']] = self._fp8_scales[op['src0']]
         if self._engine is not None and self._engine.precision == 'fp8':

@@ -139,12 +139,13 @@ __device__ __forceinline__ void bdma16(rsrc_t rsrc, unsigned lane_off, unsigned 
                                              (int) lane_off, (int) scalar_off, 0, 0);
 }
 
-enum Mode : int { MODE_PW = 0, MODE_S1 = 1, MODE_S2 = 2 };  // pointwise stride 1 / KxK stride 1 / stride 2
+// pointwise stride 1 / KxK stride 1 / KxK stride 2 / KxK stride 1 whose source is read through a bilinear resize
+enum Mode : int { MODE_PW = 0, MODE_S1 = 1, MODE_S2 = 2, MODE_BL = 3 };
 
 template <int MODE>
 struct ModeCfg {
     static constexpr int S = MODE == MODE_S2 ? 2 : 1;                              // conv stride
-    static constexpr int PITCH = MODE == MODE_PW ? 32 : (MODE == MODE_S1 ? 48 : 80);  // halo row pitch (pixels)
+    static constexpr int PITCH = MODE == MODE_PW ? 32 : (MODE == MODE_S2 ? 80 : 48);  // halo row pitch (pixels)
 };
 
 template <int TH, int BN, int WM, int WN>
@@ -182,6 +183,75 @@ __device__ __forceinline__ void halo_src_offsets(const HaloGeo &G, int q, int la
         o0 = ((G.n * G.Hs0 + y0) * G.Ws0 + x0) * G.c0_stride + part * EPP;
         o1 = ((G.n * G.Hs1 + y1) * G.Ws1 + x1) * G.c1_stride + part * EPP;
     }
+}
+
+// MODE_BL: the conv reads src0 through F.interpolate(mode='bilinear', align_corners=False) to Hin x Win (the FPN
+// refinement head, celldetection/models/cpn.py:277-278: 256 channels at full resolution are never materialised).
+// This lane's 16 B of halo instruction q = EPP channels of one halo pixel: four source pixels are loaded, blended in fp32
+// with the arithmetic of bilinear_kernel (csrc/misc_kernels.hip) / bilinear_fp8_kernel, rounded to the activation type
+// and written to the lane-linear LDS slot the DMA would have filled (same swizzled part order).
+template <int PITCH>
+__device__ __forceinline__ void halo_bilinear_store(const HaloGeo &G, int q, int lane, const unsigned char *src_chunk,
+                                                    unsigned char *dst_instr) {
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;  // explicit LDS address space: through a generic
+    typedef __attribute__((address_space(3))) u32x4 lds_u32x4;       // pointer hipcc emitted FLAT stores for the e4m3
+    typedef __attribute__((address_space(3))) unsigned int lds_u32;  // instantiation (8 M VMEM writes per launch)
+    lds_u8 *const dst = (lds_u8 *) dst_instr + lane * 16;
+    const int idx = (q << 6) + lane;
+    const int pix = idx >> 2;
+    const int part = (idx & 3) ^ ((pix >> 2) & 3);
+    const int hy_ = pix / PITCH, hx_ = pix - hy_ * PITCH;
+    const int iy = G.iy0 + hy_, ix = G.ix0 + hx_;
+    if (!(hy_ < G.HH && hx_ < G.HWreal && iy >= 0 && iy < G.Hin && ix >= 0 && ix < G.Win)) {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        *(lds_u32x4 *) dst = z;
+        return;
+    }
+    const float fy = fmaxf(G.sy0 * ((float) iy + 0.5f) - 0.5f, 0.f);
+    const float fx = fmaxf(G.sx0 * ((float) ix + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int) fy, x0 = (int) fx;
+    const int y1 = y0 + (y0 < G.Hs0 - 1 ? 1 : 0), x1 = x0 + (x0 < G.Ws0 - 1 ? 1 : 0);
+    const float ly = fy - (float) y0, lx = fx - (float) x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const unsigned char *b = src_chunk + ((size_t) G.n * G.Hs0 * G.Ws0 * G.c0_stride + (size_t) part * EPP) * ES;
+    const unsigned ps = (unsigned) G.c0_stride * ES;
+    const unsigned char *p00 = b + (size_t) (y0 * G.Ws0 + x0) * ps, *p01 = b + (size_t) (y0 * G.Ws0 + x1) * ps;
+    const unsigned char *p10 = b + (size_t) (y1 * G.Ws0 + x0) * ps, *p11 = b + (size_t) (y1 * G.Ws0 + x1) * ps;
+#if CPN_FP8
+    // one dword (4 e4m3 codes) at a time: the e4m3 kernel has ~10 free VGPRs next to its 128 accumulators and four
+    // fragment sets -- the 16-channel version of the bf16 code below spilled 138..257 of them
+    _Pragma("nounroll") for (int w = 0; w < 4; ++w) {
+        const unsigned a00 = ((const unsigned *) p00)[w], a01 = ((const unsigned *) p01)[w];
+        const unsigned a10 = ((const unsigned *) p10)[w], a11 = ((const unsigned *) p11)[w];
+        float r[4];
+#define CPN_BL_E(E)                                                                                                \
+    r[E] = __builtin_amdgcn_fmed3f(hy * (hx * __builtin_amdgcn_cvt_f32_fp8((int) a00, E) +                        \
+                                         lx * __builtin_amdgcn_cvt_f32_fp8((int) a01, E)) +                       \
+                                   ly * (hx * __builtin_amdgcn_cvt_f32_fp8((int) a10, E) +                        \
+                                         lx * __builtin_amdgcn_cvt_f32_fp8((int) a11, E)), -448.f, 448.f)
+        CPN_BL_E(0); CPN_BL_E(1); CPN_BL_E(2); CPN_BL_E(3);
+#undef CPN_BL_E
+        int c = 0;
+        c = __builtin_amdgcn_cvt_pk_fp8_f32(r[0], r[1], c, false);
+        c = __builtin_amdgcn_cvt_pk_fp8_f32(r[2], r[3], c, true);
+        ((lds_u32 *) dst)[w] = (unsigned) c;  // the tensor scale is unchanged by the resize
+    }
+#else
+    const u32x4 v00 = *(const u32x4 *) p00, v01 = *(const u32x4 *) p01, v10 = *(const u32x4 *) p10, v11 = *(const u32x4 *) p11;
+    const unsigned a00[4] = {v00.x, v00.y, v00.z, v00.w}, a01[4] = {v01.x, v01.y, v01.z, v01.w};
+    const unsigned a10[4] = {v10.x, v10.y, v10.z, v10.w}, a11[4] = {v11.x, v11.y, v11.z, v11.w};
+    unsigned o[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float lo = hy * (hx * bf16_bits_to_f32(a00[w] & 0xffffu) + lx * bf16_bits_to_f32(a01[w] & 0xffffu)) +
+                         ly * (hx * bf16_bits_to_f32(a10[w] & 0xffffu) + lx * bf16_bits_to_f32(a11[w] & 0xffffu));
+        const float hi = hy * (hx * bf16_bits_to_f32(a00[w] >> 16) + lx * bf16_bits_to_f32(a01[w] >> 16)) +
+                         ly * (hx * bf16_bits_to_f32(a10[w] >> 16) + lx * bf16_bits_to_f32(a11[w] >> 16));
+        o[w] = pack_bf16x2(lo, hi);
+    }
+    const u32x4 out = {o[0], o[1], o[2], o[3]};
+    *(lds_u32x4 *) dst = out;
+#endif
 }
 
 // ---- hand-counted LDS fragment reads ----------------------------------------------------------------------------
@@ -265,6 +335,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     constexpr int S = ModeCfg<MODE>::S;
     constexpr int PITCH = ModeCfg<MODE>::PITCH;
     constexpr bool PW = MODE == MODE_PW;
+    constexpr bool BL = MODE == MODE_BL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -366,13 +437,17 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
         const unsigned soff_ = (unsigned) (from0_ ? cin_ : cin_ - c0_used) * (unsigned) ES;                    \
         unsigned char *dstb_ = smem + (c_ & nhb_mask) * halo_buf;                                              \
         const int q1_ = (Q1);                                                                                  \
-        for (int q_ = (Q0) + wave; q_ < q1_; q_ += C::NWAVES) {                                                \
-            int o0_, o1_;                                                                                      \
-            halo_src_offsets<PITCH>(G, q_, lane, o0_, o1_);                                                    \
-            const int off_ = from0_ ? o0_ : o1_;                                                               \
-            const unsigned voff_ = off_ >= 0 ? (unsigned) off_ * (unsigned) ES : OOB_LANE;                     \
-            if (from0_) bdma16(rs0, voff_, soff_, dstb_ + (q_ << 10));                                         \
-            else bdma16(rs1, voff_, soff_, dstb_ + (q_ << 10));                                                \
+        _Pragma("nounroll") for (int q_ = (Q0) + wave; q_ < q1_; q_ += C::NWAVES) {                            \
+            if constexpr (BL) {                                                                                \
+                halo_bilinear_store<PITCH>(G, q_, lane, (const unsigned char *) a.src0 + soff_, dstb_ + (q_ << 10)); \
+            } else {                                                                                           \
+                int o0_, o1_;                                                                                  \
+                halo_src_offsets<PITCH>(G, q_, lane, o0_, o1_);                                                \
+                const int off_ = from0_ ? o0_ : o1_;                                                           \
+                const unsigned voff_ = off_ >= 0 ? (unsigned) off_ * (unsigned) ES : OOB_LANE;                 \
+                if (from0_) bdma16(rs0, voff_, soff_, dstb_ + (q_ << 10));                                     \
+                else bdma16(rs1, voff_, soff_, dstb_ + (q_ << 10));                                            \
+            }                                                                                                  \
         }                                                                                                      \
     }
 
@@ -476,7 +551,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     const int hq_rounds = (hinstr + C::NWAVES - 1) / C::NWAVES;
     const int hq_avail = max(1, ntaps >> 1);
     const int hq_step = C::NWAVES * ((hq_rounds + hq_avail - 1) / hq_avail);
-    int hq_next = hinstr, hq_chunk = 0;
+    int hq_next = hinstr, hq_chunk = 0, bl_pending = -1;
 #define CPN_HALO_AT_TRANSITION(IA, CHUNK_CHANGED)                                                              \
     if (!pw) {                                                                                                 \
         if ((CHUNK_CHANGED) && (IA).c + 1 < nchunks) {                                                         \
@@ -489,9 +564,24 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
         }                                                                                                      \
     }
 #else
+    // MODE_BL: the next chunk's tile is blended in registers (global loads + VALU + ds_write), which needs ~50 VGPRs:
+    // it is deferred to the END of the loop iteration, where only one fragment set is live (done at the transition,
+    // between the loads and the MFMAs of the last group, the e4m3 instantiation spilled 138 VGPRs).  Any point of the
+    // step that follows the chunk change is early enough: the tile is first read >= floor(ntaps / 2) steps later
+    int bl_pending = -1;
 #define CPN_HALO_AT_TRANSITION(IA, CHUNK_CHANGED)                                                              \
-    if (!pw && (CHUNK_CHANGED) && (IA).c + 1 < nchunks) CPN_EXP_H(HALO_DMA((IA).c + 1));
+    if (!pw && (CHUNK_CHANGED) && (IA).c + 1 < nchunks) {                                                      \
+        if constexpr (BL) bl_pending = (IA).c + 1;                                                             \
+        else CPN_EXP_H(HALO_DMA((IA).c + 1));                                                                  \
+    }
 #endif
+#define CPN_BL_FLUSH()                                                                                         \
+    if constexpr (BL) {                                                                                        \
+        if (bl_pending >= 0) {                                                                                 \
+            HALO_DMA(bl_pending);                                                                              \
+            bl_pending = -1;                                                                                   \
+        }                                                                                                      \
+    }
 
     ItemState i0{0, 0, 0};                 // first item of the current step
     ItemState i1 = next_item(i0, KH, KW);  // second item of the current step
@@ -500,9 +590,10 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     HALO_DMA(0);
     if (pw && nchunks > 1) HALO_DMA(1);
     W_DMA(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (lgkmcnt: the MODE_BL halo is written with ds_write)
     __builtin_amdgcn_s_barrier();
     ISSUE_AT_TRANSITION(i0, 0, true);
+    CPN_BL_FLUSH();
 
 #if CPN_FP8
     // fp8: an item = 64 channels x 1 tap.  A lane's operand is the 32 contiguous bytes of its record half = two
@@ -540,6 +631,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
         LOAD_GROUP(wX0, pX0, pa, wa);                 // first part of step st+1
         MMA8(wX1, wY1, pX1, pY1, NF);                 // item 1 (operands already in registers)
         wait_frags<0, WN, WM>(wX0, pX0);
+        CPN_BL_FLUSH();
         i0 = n0i;
         i1 = next_item(n0i, KH, KW);
     }
@@ -582,6 +674,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
         LOAD_GROUP(wA, pA, pa, wa);                   // first group of step st+1
         MMA_GROUP(wB, pB, NF);                        // last group of step st (operands already in registers)
         wait_frags<0, WN, WM>(wA, pA);                // nothing is in flight across the loop back-edge
+        CPN_BL_FLUSH();
         i0 = n0i;
         i1 = next_item(n0i, KH, KW);
     }
@@ -599,6 +692,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
 #undef HALO_DMA
 #undef HALO_DMA_RANGE
 #undef CPN_HALO_AT_TRANSITION
+#undef CPN_BL_FLUSH
 #undef PW_HALO_DMA
 #undef W_DMA
 #undef LOAD_GROUP
@@ -841,13 +935,14 @@ struct TileChoice {
 
 static int conv_mode(const ConvArgs &a) {
     if (a.KH == 1 && a.KW == 1 && a.pad == 0) return MODE_PW;  // incl. strided 1x1: the tile gathers only its outputs
+    if (a.up0 == 2) return MODE_BL;
     return a.stride == 2 ? MODE_S2 : MODE_S1;
 }
 
 static size_t lds_bytes(const ConvArgs &a, int TH, int BN) {
     const int mode = conv_mode(a);
     const int S = mode == MODE_S2 ? 2 : 1;
-    const int pitch = mode == MODE_PW ? 32 : (mode == MODE_S1 ? 48 : 80);
+    const int pitch = mode == MODE_PW ? 32 : (mode == MODE_S2 ? 80 : 48);
     const int HH = (TH - 1) * S + a.KH;
     const int nchunks = a.cin_b / 32;
     const size_t halo_buf = (size_t) ((HH * pitch * 4 + 63) / 64) * 1024;
@@ -888,6 +983,10 @@ static int launch_cfg(const ConvArgs &a, hipStream_t stream) {
     switch (conv_mode(a)) {
         case MODE_PW: return launch_mode<TH, BN, WM, WN, MODE_PW>(a, stream);
         case MODE_S1: return launch_mode<TH, BN, WM, WN, MODE_S1>(a, stream);
+#if !CPN_FP8  // bf16 only: the e4m3 kernel has no registers to spare for the in-register blend (it spilled, and ran at
+              // 0.16 of its plain rate); fp8 plans keep the separate resize op, which moves half the bytes of a bf16 one
+        case MODE_BL: return launch_mode<TH, BN, WM, WN, MODE_BL>(a, stream);
+#endif
         default: return launch_mode<TH, BN, WM, WN, MODE_S2>(a, stream);
     }
 }
@@ -913,6 +1012,8 @@ static TileChoice choose_tile(const ConvArgs &a) {
 int launch_conv(const ConvArgs &a, hipStream_t stream) {
     if (a.cin_b % CH || a.cout_b % 32 || a.c0_used % CH) return (int) hipErrorInvalidValue;
     if (a.stride != 1 && a.stride != 2) return (int) hipErrorInvalidValue;
+    if (a.up0 == 2 && (CPN_FP8 || a.stride != 1 || a.src1 || a.up1 || (a.KH == 1 && a.KW == 1)))
+        return (int) hipErrorInvalidValue;  // bilinear source: single-source KxK stride-1 convs of the bf16 path only
     if ((a.stride == 1 && a.KW > 17) || (a.stride == 2 && a.KW > 18)) return (int) hipErrorInvalidValue;
     TileChoice c = choose_tile(a);
     if (a.out_mode == OUT_FUSED_HEAD) {  // the block must own all output channels; TH multiple of the wave count

@@ -86,7 +86,8 @@ static void propagate_dims(const cpn_plan *p, int H, int W, ShapePlan &sp) {
             case CPN_OP_CONV: {
                 int hv, wv;
                 if (o.up0 && o.up1) { bad("conv: both sources resized"); break; }
-                if (o.up1) { hv = sp.th[o.src0]; wv = sp.tw[o.src0]; }
+                if (o.up0 == 2) { hv = H; wv = W; }  // bilinear resize of the source to the INPUT size (cpn.py:277-278)
+                else if (o.up1) { hv = sp.th[o.src0]; wv = sp.tw[o.src0]; }
                 else if (o.up0 && o.src1 >= 0) { hv = sp.th[o.src1]; wv = sp.tw[o.src1]; }
                 else if (o.up0) { hv = 2 * sp.th[o.src0]; wv = 2 * sp.tw[o.src0]; }
                 else {
@@ -178,6 +179,8 @@ static int build_conv_args(const cpn_plan *p, const cpn_op_desc &o, int N, ConvA
     a.Hs1 = src_dims ? src_dims[2] : (o.up1 ? Hin >> 1 : Hin); a.Ws1 = src_dims ? src_dims[3] : (o.up1 ? Win >> 1 : Win);
     if (!o.up0) { a.Hs0 = Hin; a.Ws0 = Win; }
     if (!o.up1) { a.Hs1 = Hin; a.Ws1 = Win; }
+    if (a.Hs0 == Hin && a.Ws0 == Win) a.up0 = 0;  // same size: the resize (nearest or bilinear) is the identity
+    if (a.Hs1 == Hin && a.Ws1 == Win) a.up1 = 0;
     if (Hin <= 0 || Win <= 0 || a.Hs0 <= 0 || a.Ws0 <= 0 || (s1 && (a.Hs1 <= 0 || a.Ws1 <= 0)))
         return fail(CPN_E_INVALID, "conv: empty input");
     a.sy0 = (float) a.Hs0 / (float) Hin; a.sx0 = (float) a.Ws0 / (float) Win;
@@ -374,7 +377,8 @@ static int run_or_count(cpn_plan *plan, const void *input, int32_t in_dtype, int
             }
             case CPN_OP_CONV: {
                 int Hin, Win;  // virtual input size (see propagate_dims)
-                if (o.up1) { Hin = sp.th[o.src0]; Win = sp.tw[o.src0]; }
+                if (o.up0 == 2) { Hin = H; Win = W; }
+                else if (o.up1) { Hin = sp.th[o.src0]; Win = sp.tw[o.src0]; }
                 else if (o.up0 && o.src1 >= 0) { Hin = sp.th[o.src1]; Win = sp.tw[o.src1]; }
                 else if (o.up0) { Hin = 2 * sp.th[o.src0]; Win = 2 * sp.tw[o.src0]; }
                 else { Hin = sp.th[o.src0]; Win = sp.tw[o.src0]; }

@@ -19,7 +19,7 @@ struct ConvArgs {
     const void *src0, *src1;
     int c0_stride, c1_stride;   // channel stride (= padded channel count) of the source buffers
     int c0_used;                // channels of the virtual concat that come from src0 (multiple of 32)
-    int up0, up1;
+    int up0, up1;               // 0 none | 1 nearest | (up0 only) 2 bilinear, align_corners=False (KxK stride-1 convs)
     int Hs0, Ws0, Hs1, Ws1;     // stored sizes of the sources (== Hin, Win when not resized)
     float sy0, sx0, sy1, sx1;   // float(Hs) / Hin, float(Ws) / Win of the resized sources
     int N, Hin, Win;            // virtual (post-resize) input size

@@ -55,8 +55,12 @@ class Plan:
         """Adds conv(+BN)(+residual)(+act); returns the destination tensor id (None for external outputs)."""
         pad = k // 2 if pad is None else pad
         t0 = self.tensors[src0]
-        down_in = t0['down'] // (2 if up0 else 1)
-        assert t0['down'] % (2 if up0 else 1) == 0
+        if up0 == 'bilinear':  # source read through a bilinear resize to the input size (nominal down factor 1)
+            assert src1 is None and stride == 1 and k > 1
+            down_in = 1
+        else:
+            down_in = t0['down'] // (2 if up0 else 1)
+            assert t0['down'] % (2 if up0 else 1) == 0
         cin = t0['c'] + (self.tensors[src1]['c'] if src1 is not None else 0)
         if src1 is not None:
             assert self.tensors[src1]['down'] // (2 if up1 else 1) == down_in
@@ -297,14 +301,14 @@ for _k in _RESNETS:
 BACKBONES['U22'] = ('unet', 'U22')
 
 
-def _readout(P, x, cmid, cout, prefix, act, act_scale, out_index, k=7, fuse=True):
+def _readout(P, x, cmid, cout, prefix, act, act_scale, out_index, k=7, fuse=True, up0=False):
     """ReadOut (commons.py:461-511): conv kxk(bias) -> BN -> ReLU -> Dropout2d(eval: identity) -> conv 1x1(bias)."""
     if fuse and FUSE_READOUT and _pad32(cmid) in (32, 64, 128, 256) and cout <= 32:
         # one kernel: conv kxk + BN + ReLU -> (bf16, LDS) -> 1x1 conv + final activation -> fp32 NCHW head map
         P.conv(x, cmid, k, w=prefix + 'block.0.', bn=prefix + 'block.1.', bias=True, act='relu', out_index=out_index,
-               fuse=dict(w=prefix + 'block.4.', cout=cout, act=act, act_scale=act_scale))
+               fuse=dict(w=prefix + 'block.4.', cout=cout, act=act, act_scale=act_scale), up0=up0)
         return
-    t = P.conv(x, cmid, k, w=prefix + 'block.0.', bn=prefix + 'block.1.', bias=True, act='relu')
+    t = P.conv(x, cmid, k, w=prefix + 'block.0.', bn=prefix + 'block.1.', bias=True, act='relu', up0=up0)
     P.conv(t, cout, 1, w=prefix + 'block.4.', bias=True, act=act, act_scale=act_scale, out_index=out_index)
 
 
@@ -312,7 +316,7 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
                refinement_margin: float = 3., refinement_buckets: int = 1, order_weights: bool = True,
                backbone_kwargs: dict = None, fuse_readout: bool = True, uncertainty_head: bool = False,
                contour_head_channels: int = None, refinement_head_channels: int = None,
-               kernel_sizes: dict = None) -> Plan:
+               kernel_sizes: dict = None, fuse_bilinear: bool = True) -> Plan:
     """Plan of ``Cpn<backbone>`` (celldetection/models/cpn.py:287-439,771-2061; heads: CPNCore.__init__
     cpn.py:125-236).  ``kernel_sizes``: optional {'score'|'location'|'fourier'|'uncertainty'|'refinement': k}
     (the reference's ``kernel_size_<head>`` kwargs, default 7)."""
@@ -363,10 +367,15 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
         # cpn.py:277-278: bilinear resize of the features to the input size.  FPN: always (f0 lives at stride 2);
         # ResNet + UNet: the bridge level is 2 * ceil(H / 2) pixels high, i.e. H + 1 for odd H (no-op alias otherwise);
         # U22: level 0 has the input size by construction (3x3 convs, padding 1)
-        if family == 'fpn' or enc != 'U22':
+        # bf16 / fp8 plans: the resize is fused into the head conv's halo loader (up0 = 'bilinear': the full-resolution
+        # 256-channel map of the FPN models is never written); the fp32 verification plan keeps the separate op
+        resize = family == 'fpn' or enc != 'U22'
+        kr = ks.get('refinement', 7)
+        fused_resize = resize and fuse_bilinear and kr > 1
+        if resize and not fused_resize:
             r = P.bilinear_to_input(r)
         _readout(P, r, cm0, 2 * refinement_buckets, 'core.refinement_head.', 'tanh_scaled', float(refinement_margin),
-                 _lib.OUT_REFINEMENT, k=ks.get('refinement', 7), fuse=fuse_readout)
+                 _lib.OUT_REFINEMENT, k=kr, fuse=fuse_readout, up0='bilinear' if fused_resize else False)
     P.meta = dict(backbone=backbone, order=order, head_down=scale, refinement=refinement, in_channels=in_channels,
                   score_channels=score_channels, refinement_buckets=refinement_buckets,
                   uncertainty_head=bool(uncertainty_head))
@@ -540,7 +549,7 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=Non
         d.src1 = -1 if op['src1'] is None else op['src1']
         d.res = -1 if op['res'] is None else op['res']
         d.dst = -1 if op['dst'] is None else op['dst']
-        d.up0, d.up1, d.res_up = int(op['up0']), int(op['up1']), int(op['res_up'])
+        d.up0, d.up1, d.res_up = (2 if op['up0'] == 'bilinear' else int(op['up0'])), int(op['up1']), int(op['res_up'])
         d.c0_used = c0p if op['src1'] is not None else cinp
         d.kh = d.kw = k
         d.stride, d.pad = op['stride'], op['pad']
@@ -595,7 +604,7 @@ def reference_flops(plan: Plan, H, W):
         if op['op'] != 'conv':
             continue
         t0 = plan.tensors[op['src0']]
-        down_in = t0['down'] // (2 if op['up0'] else 1)
+        down_in = 1 if op['up0'] == 'bilinear' else t0['down'] // (2 if op['up0'] else 1)
         ho, wo = H // (down_in * op['stride']), W // (down_in * op['stride'])
         f = 2. * ho * wo * op['cout'] * (op['cin'] // op['groups']) * op['k'] ** 2
         # the reference runs the UNet inner 1x1 after the upsample (4x the pixels), unet.py:213-218

@@ -56,8 +56,10 @@ typedef struct {
     int32_t op;               /* CPN_OP_*                                                                   */
     int32_t src0, src1, res;  /* tensor ids (-1 = none). src1: second source of a virtual channel concat      */
     int32_t dst;              /* tensor id, or -1 when the op writes an external fp32 NCHW output             */
-    int32_t up0, up1, res_up; /* source / residual is nearest-resized (PyTorch 'nearest': floor(dst*in/out)) to the
-                               * size of the other concat source / of the output; a lone up0 source: exact x2       */
+    int32_t up0, up1, res_up; /* 1: source / residual is nearest-resized (PyTorch 'nearest': floor(dst*in/out)) to the
+                               * size of the other concat source / of the output; a lone up0 source: exact x2.
+                               * up0 == 2: src0 is read through a BILINEAR resize (align_corners=False) to the input
+                               * size H x W (cpn.py:277-278; k x k stride-1 single-source convs of bf16 / fp8 plans) */
     int32_t c0_used;          /* channels of the concat taken from src0 (multiple of 32)                      */
     int32_t kh, kw, stride, pad;
     int32_t bundles, cin_b, cout_b; /* grouped convs run as `bundles` dense convs of cin_b -> cout_b channels  */

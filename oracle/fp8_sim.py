@@ -76,7 +76,12 @@ def _simulate(plan, state_dict, effective_weights, act_scales, x, T, outs, ei, _
         else:
             e = effective_weights[ei]
             ei += 1
-            xin = up(T[op['src0']]) if op['up0'] else T[op['src0']]
+            if op['up0'] == 'bilinear':  # resize fused into the conv's loader: blended values are re-quantised with
+                t0 = T[op['src0']]        # the source tensor's scale (codes), exactly like the separate op did
+                xin = t0 if t0.shape[2:] == x.shape[2:] else _q(
+                    F.interpolate(t0, x.shape[2:], mode='bilinear', align_corners=False), act_scales[op['src0']])
+            else:
+                xin = up(T[op['src0']]) if op['up0'] else T[op['src0']]
             if op['src1'] is not None:
                 xin = torch.cat((xin, up(T[op['src1']]) if op['up1'] else T[op['src1']]), 1)
             y = F.conv2d(xin.double(), e['w'], e['b'], op['stride'], op['pad'], 1, op['groups']).float()

@@ -42,13 +42,16 @@ def from_nhwc(y, c):
 
 
 def run_conv(dev, *, n, h, w, cin, cout, k, stride=1, groups=1, bias=True, bn=True, act='relu', cin1=0, up0=False,
-             up1=False, res=False, res_up=False, out_f32=False, act_scale=3., seed=0, fuse_cout=0, fuse_act='none'):
+             up1=False, res=False, res_up=False, out_f32=False, act_scale=3., seed=0, fuse_cout=0, fuse_act='none',
+             bilinear=False):
     """Builds a one-conv plan, runs cpn_conv2d, returns (got, ref) as fp32 NCHW CPU tensors."""
     from celldetection_amd import _lib, graph
     g = torch.Generator().manual_seed(seed)
     P = graph.Plan()
     hin, win = h, w
-    s0 = P.tensor(cin, 2 if up0 else 1)
+    s0 = P.tensor(cin, 2 if (up0 or bilinear) else 1)
+    if bilinear:  # source stored at half resolution, read through the fused bilinear resize (MODE_BL)
+        up0 = 'bilinear'
     s1 = P.tensor(cin1, 2 if up1 else 1) if cin1 else None
     r = P.tensor(cout, (2 if res_up else 1) * stride) if res else None
     P.conv(s0, cout, k, w='c.', bn='b.' if bn else None, bias=bias, stride=stride, groups=groups, act=act,
@@ -94,7 +97,10 @@ def run_conv(dev, *, n, h, w, cin, cout, k, stride=1, groups=1, bias=True, bn=Tr
     # ---- reference: fp32 conv on the same bf16-rounded operands with the folded weights
     wf, bf = graph._fold(sd, P.ops[0])
     wf = wf.float().to(torch.bfloat16).float()
-    xin = F.interpolate(x0, scale_factor=2, mode='nearest') if up0 else x0
+    if bilinear:  # blended values are rounded to bf16 before they enter the MFMA (like the materialised tensor was)
+        xin = F.interpolate(x0, scale_factor=2, mode='bilinear', align_corners=False).to(torch.bfloat16).float()
+    else:
+        xin = F.interpolate(x0, scale_factor=2, mode='nearest') if up0 else x0
     if cin1:
         xin = torch.cat((xin, F.interpolate(x1, scale_factor=2, mode='nearest') if up1 else x1), 1)
     ref = F.conv2d(xin, wf, bf.float(), stride, k // 2, 1, groups)
@@ -142,6 +148,10 @@ CONV_CASES = {
     'fused_head_64_tanh_th16': dict(n=4, h=256, w=256, cin=64, cout=64, k=7, fuse_cout=2, fuse_act='tanh_scaled', seed=5),
     'fused_head_64_tanh': dict(n=1, h=32, w=32, cin=64, cout=64, k=7, fuse_cout=2, fuse_act='tanh_scaled'),
     'fused_head_small': dict(n=1, h=32, w=64, cin=8, cout=8, k=7, fuse_cout=20, fuse_act='none'),
+    '7x7_bilinear_src_256': dict(n=1, h=64, w=64, cin=64, cout=256, k=7, bilinear=True),
+    '3x3_bilinear_src_32': dict(n=2, h=32, w=64, cin=16, cout=24, k=3, bilinear=True),
+    'fused_head_64_bilinear': dict(n=1, h=64, w=96, cin=64, cout=64, k=7, fuse_cout=2, fuse_act='tanh_scaled', bilinear=True),
+    'fused_head_256_bilinear': dict(n=1, h=32, w=64, cin=256, cout=256, k=7, fuse_cout=2, fuse_act='tanh_scaled', bilinear=True),
     'final_sigmoid': dict(n=2, h=32, w=32, cin=64, cout=1, k=1, bn=False, act='sigmoid', out_f32=True),
     'final_tanh': dict(n=1, h=64, w=32, cin=64, cout=2, k=1, bn=False, act='tanh_scaled', out_f32=True),
     'final_fourier': dict(n=1, h=32, w=32, cin=128, cout=20, k=1, bn=False, act='none', out_f32=True),

@@ -450,7 +450,7 @@ def test_fp8_precision_vs_reference_maps(dev, name):
     x = torch.as_tensor(g['x']).to(dev)
     model.precision = 'fp8'
     scales = model.calibrate_fp8(x)
-    assert len(scales) == len(model._plan.tensors) and min(scales) > 0
+    assert len(scales) == len(model.plan_for('fp8').tensors) and min(scales) > 0
     s, l, r, f = [t.cpu() for t in model.core_forward(x)]
     exp = dict(scores=torch.sigmoid(torch.as_tensor(g['core.scores'])), locations=torch.as_tensor(g['core.locations']),
                refinement=torch.as_tensor(g['core.refinement']), fourier=torch.as_tensor(g['core.fourier']))
@@ -475,8 +475,8 @@ def test_fp8_precision_vs_reference_maps(dev, name):
     from celldetection_amd import _lib, graph
     eff = []
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    graph.pack(model._plan, sd, 'cpu', precision='fp8', act_scales=scales, effective_weights=eff)
-    sim = fp8_sim.simulate(model._plan, sd, eff, scales, torch.as_tensor(g['x']))
+    graph.pack(model.plan_for('fp8'), sd, 'cpu', precision='fp8', act_scales=scales, effective_weights=eff)
+    sim = fp8_sim.simulate(model.plan_for('fp8'), sd, eff, scales, torch.as_tensor(g['x']))
     for key, got, idx in (('scores', s, _lib.OUT_SCORES), ('locations', l, _lib.OUT_LOCATIONS),
                           ('fourier', f, _lib.OUT_FOURIER), ('refinement', r, _lib.OUT_REFINEMENT)):
         e_sim = ((sim[idx] - exp[key]).norm() / (exp[key].norm() + 1e-12)).item()
@@ -565,3 +565,85 @@ def test_stitching_with_cross_tile_duplicates(dev):
     exbr = inference.tiled_inference(sf.StubModel(), img, rank=0, world_size=1, stitching_rule='ex_br', **kw)
     n_exp = sum(int(g[f'tile{i}.keep_border_exbr'].sum()) for i in range(int(g['n_tiles'])))
     assert exbr['scores'].shape[0] == n_exp
+
+
+def _invariants(model, y, x, size):
+    """Size-independent properties of a forward result (per image): NMS order / threshold, boxes = contour extrema,
+    contours inside the image."""
+    H, W = size
+    for i in range(x.shape[0]):
+        s, c, b = y['scores'][i], y['contours'][i], y['boxes'][i]
+        if s.numel() == 0:
+            continue
+        assert bool((s[:-1] >= s[1:]).all()) and float(s.min()) > model.score_thresh
+        assert torch.equal(b, torch.cat((c.min(1).values, c.max(1).values), 1))
+        assert float(c.min()) >= 0 and float(c[..., 0].max()) <= W - 1 and float(c[..., 1].max()) <= H - 1
+
+
+def test_full_size_properties_config1_resnet18fpn(dev):
+    """BASELINE.json configs[1] at full size: CpnResNet18FPN, bf16, 8 x 3x512x512 (refinement head reads its 256-channel
+    features through the fused bilinear loader).  Invariants on the batch + one tile against the fp32 CPU oracle."""
+    import sys
+    import cpn_oracle as orc
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import build_model
+    model, sd = build_model('CpnResNet18FPN', dev)
+    x = torch.rand(8, 3, 512, 512, generator=torch.Generator().manual_seed(101)).to(dev)
+    y = model(x)
+    assert min(len(s) for s in y['scores']) > 5, [len(s) for s in y['scores']]
+    y2 = model(x)
+    for k in KEYS:  # determinism
+        for a, b in zip(y[k], y2[k]):
+            assert torch.equal(a, b), k
+    yi = model(x[3:4])  # batch independence
+    for k in KEYS:
+        assert torch.equal(yi[k][0], y[k][3]), k
+    _invariants(model, y, x, (512, 512))
+    b, s = y['boxes'][0].cpu().numpy(), y['scores'][0].cpu().numpy()
+    np.testing.assert_array_equal(orc.nms(b, s, model.nms_thresh), np.arange(len(s)))  # NMS idempotent
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    ref = orc.cpn_forward({k: v.cpu() for k, v in sd.items()}, x[:1].cpu(), nms=False)
+    got = model(x[:1], nms=False)
+    rate = _iou_match_rate(got['boxes'][0].cpu().numpy(), ref['boxes'][0])
+    n_ref, n_got = len(ref['scores'][0]), len(got['scores'][0])
+    print('configs[1] tile 0: proposals', n_got, 'oracle', n_ref, 'IoU>0.5 match rate', rate)
+    assert abs(n_ref - n_got) <= max(3, 0.1 * n_ref) and rate > .9
+    # the fp32 verification path on the same tile: index sets equal, coordinates within 1e-4 of the oracle
+    model.precision = 'fp32'
+    got32 = model(x[:1], nms=False)
+    assert len(got32['scores'][0]) == n_ref
+    np.testing.assert_allclose(got32['contours'][0].cpu().numpy(), ref['contours'][0], rtol=0, atol=2e-3)
+    bad = float((np.abs(got32['contours'][0].cpu().numpy() - ref['contours'][0]) > 1e-4).mean())
+    print('configs[1] fp32 path: fraction of contour coordinates off by > 1e-4:', bad)
+    assert bad < 5e-3
+
+
+def test_full_size_properties_config4_resnet50fpn_fp8(dev):
+    """BASELINE.json configs[4], the per-GPU share: CpnResNet50FPN, fp8 (e4m3), 8 x 3x1024x1024.  Invariants on the
+    batch, bf16 and fp8 proposals of one tile IoU-matched against the fp32 CPU oracle."""
+    import sys
+    import cpn_oracle as orc
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import build_model
+    model, sd = build_model('CpnResNet50FPN', dev, tile=1024, calib_tiles=1)
+    x = torch.rand(8, 3, 1024, 1024, generator=torch.Generator().manual_seed(102)).to(dev)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    ref = orc.cpn_forward({k: v.cpu() for k, v in sd.items()}, x[:1].cpu(), nms=False)
+    n_ref = len(ref['scores'][0])
+    got = model(x[:1], nms=False)
+    rate = _iou_match_rate(got['boxes'][0].cpu().numpy(), ref['boxes'][0])
+    print('configs[4] tile 0 bf16: proposals', len(got['scores'][0]), 'oracle', n_ref, 'IoU>0.5 match rate', rate)
+    assert abs(n_ref - len(got['scores'][0])) <= max(3, 0.1 * n_ref) and rate > .9
+    model.precision = 'fp8'
+    model.calibrate_fp8(x[:1])
+    y = model(x)
+    assert min(len(s) for s in y['scores']) > 5
+    _invariants(model, y, x, (1024, 1024))
+    y2 = model(x)
+    for k in KEYS:
+        for a, b in zip(y[k], y2[k]):
+            assert torch.equal(a, b), k
+    got8 = model(x[:1], nms=False)
+    rate8 = _iou_match_rate(got8['boxes'][0].cpu().numpy(), ref['boxes'][0])
+    print('configs[4] tile 0 fp8: proposals', len(got8['scores'][0]), 'oracle', n_ref, 'IoU>0.5 match rate', rate8)
+    assert abs(n_ref - len(got8['scores'][0])) <= 0.25 * n_ref and rate8 > .75

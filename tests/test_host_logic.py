@@ -155,7 +155,7 @@ def test_fp8_packing_passes_plan_validation(name):
     from ctypes import c_void_p
     spec = ALL_SPECS[name]
     model = getattr(cda.models, spec['cls'])(**spec['kwargs'])
-    plan = model._plan
+    plan = model.plan_for('fp8')
     tens, ops, wblob, bblob, mblob, op_scales = graph.pack(plan, model.state_dict(), 'cpu', precision='fp8',
                                                            act_scales=[0.01 + 0.001 * i for i in range(len(plan.tensors))])
     assert wblob.dtype == torch.uint8 and all(t.channels % 64 == 0 for t in tens)

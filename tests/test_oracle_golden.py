@@ -171,7 +171,7 @@ def test_fp8_simulator_against_reference_maps(name):
     from celldetection_amd import _lib, graph
     g, sd = _load_model_fixture(name)
     spec = MODEL_SPECS[name]
-    plan = getattr(cda.models, spec['cls'])(**spec['kwargs'])._plan
+    plan = getattr(cda.models, spec['cls'])(**spec['kwargs']).plan_for('fp8')
     x = torch.as_tensor(g['x'])
     torch.set_num_threads(4)
     exp = {_lib.OUT_SCORES: torch.sigmoid(torch.as_tensor(g['core.scores'])),

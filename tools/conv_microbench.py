@@ -22,6 +22,8 @@ CASES = {
     'ref7': dict(n=16, h=512, w=512, cin=64, cout=64, k=7),
     'c64': dict(n=16, h=512, w=512, cin=64, cout=64, k=3),
     'grp': dict(n=16, h=32, w=32, cin=1024, cout=1024, k=3, groups=32),
+    'bl7': dict(n=8, h=512, w=512, cin=256, cout=256, k=7, bilinear=True),  # FPN refinement head: bilinear-resized source
+    'bl7s': dict(n=2, h=256, w=256, cin=256, cout=256, k=7, bilinear=True),
 }
 
 
@@ -42,7 +44,8 @@ def run_fp8(name, P, sd, cfg, reps):
     def codes(*shape):
         return torch.randn(*shape, device=dev).mul_(64).clamp_(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
 
-    x0 = codes(n, h, w, p64(cin))
+    bl = cfg.get('bilinear', False)
+    x0 = codes(n, h // 2 if bl else h, w // 2 if bl else w, p64(cin))
     x1 = codes(n, h // 2, w // 2, p64(cin1)) if cin1 else None
     dst = torch.empty(n, h, w, p64(cout), dtype=torch.uint8, device=dev)
     lib = _lib.load()
@@ -74,7 +77,11 @@ def run(name, reps=20):
     P = graph.Plan()
     s0 = P.tensor(cin, 1)
     s1 = P.tensor(cin1, 2) if cin1 else None
-    P.conv(s0, cout, k, w='c.', bn=None, bias=True, act='relu', groups=groups, src1=s1, up1=bool(cin1))
+    bl = cfg.get('bilinear', False)
+    if bl:
+        P.tensors[s0]['down'] = 2
+    P.conv(s0, cout, k, w='c.', bn=None, bias=True, act='relu', groups=groups, src1=s1, up1=bool(cin1),
+           up0='bilinear' if bl else False)
     sd = {'c.weight': torch.randn(cout, (cin + cin1) // groups, k, k) * .05, 'c.bias': torch.randn(cout) * .1}
     if ZERO:
         sd = {k_: torch.zeros_like(v_) for k_, v_ in sd.items()}
@@ -82,7 +89,7 @@ def run(name, reps=20):
         return run_fp8(name, P, sd, cfg, reps)
     tens, ops, wblob, bblob = graph.pack(P, sd, dev)
     p32 = lambda c: (c + 31) // 32 * 32
-    x0 = torch.randn(n, h, w, p32(cin), device=dev).to(torch.bfloat16)
+    x0 = torch.randn(n, h // 2 if bl else h, w // 2 if bl else w, p32(cin), device=dev).to(torch.bfloat16)
     x1 = torch.randn(n, h // 2, w // 2, p32(cin1), device=dev).to(torch.bfloat16) if cin1 else None
     if ZERO:
         x0.zero_()
