@@ -6,10 +6,11 @@ loop.  Everything computes in hand-written HIP kernels behind the C ABI of ``lib
 (``include/cpn_hip.h``); there is no CPU fallback.
 """
 from . import cpn as models  # ``cd.models.CpnResNeXt101UNet`` -> ``celldetection_amd.models.CpnResNeXt101UNet``
-from . import inference, labels, ops, preprocess, synth, util
+from . import h5, inference, labels, ops, preprocess, synth, util
+from .h5 import from_h5, to_h5
 from .labels import contours2labels
 from .util import (dict2model, fetch_model, get_tiling_slices, load_model, model2dict, save_fetchable_model)
 
 __version__ = '0.1.0'
-__all__ = ['models', 'ops', 'util', 'synth', 'inference', 'labels', 'contours2labels', 'preprocess', 'fetch_model', 'load_model', 'save_fetchable_model', 'dict2model',
+__all__ = ['models', 'ops', 'util', 'synth', 'inference', 'labels', 'contours2labels', 'preprocess', 'h5', 'to_h5', 'from_h5', 'fetch_model', 'load_model', 'save_fetchable_model', 'dict2model',
            'model2dict', 'get_tiling_slices']

@@ -544,26 +544,6 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
         CPN_HALO_AT_TRANSITION(IA, CHUNK_CHANGED)                                                              \
     }
 
-#ifdef CPN_SPREAD_HALO
-    // the first item of chunk c+1 sits floor(ntaps/2) or more steps behind the transition that frees its buffer, and a
-    // slice issued at the transition into step s has landed (vmcnt(0) at the end of s) before step s+1 reads: spreading
-    // the tile over those transitions keeps the DMA queue of a step at "2 weight slabs + one slice"
-    const int hq_rounds = (hinstr + C::NWAVES - 1) / C::NWAVES;
-    const int hq_avail = max(1, ntaps >> 1);
-    const int hq_step = C::NWAVES * ((hq_rounds + hq_avail - 1) / hq_avail);
-    int hq_next = hinstr, hq_chunk = 0, bl_pending = -1;
-#define CPN_HALO_AT_TRANSITION(IA, CHUNK_CHANGED)                                                              \
-    if (!pw) {                                                                                                 \
-        if ((CHUNK_CHANGED) && (IA).c + 1 < nchunks) {                                                         \
-            hq_chunk = (IA).c + 1;                                                                             \
-            hq_next = 0;                                                                                       \
-        }                                                                                                      \
-        if (hq_next < hinstr) {                                                                                \
-            CPN_EXP_H(HALO_DMA_RANGE(hq_chunk, hq_next, min(hq_next + hq_step, hinstr)));                      \
-            hq_next += hq_step;                                                                                \
-        }                                                                                                      \
-    }
-#else
     // MODE_BL: the next chunk's tile is blended in registers (global loads + VALU + ds_write), which needs ~50 VGPRs:
     // it is deferred to the END of the loop iteration, where only one fragment set is live (done at the transition,
     // between the loads and the MFMAs of the last group, the e4m3 instantiation spilled 138 VGPRs).  Any point of the
@@ -574,7 +554,6 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
         if constexpr (BL) bl_pending = (IA).c + 1;                                                             \
         else CPN_EXP_H(HALO_DMA((IA).c + 1));                                                                  \
     }
-#endif
 #define CPN_BL_FLUSH()                                                                                         \
     if constexpr (BL) {                                                                                        \
         if (bl_pending >= 0) {                                                                                 \

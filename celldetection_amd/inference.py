@@ -55,14 +55,15 @@ def unpack_detections(buf: torch.Tensor, samples: int, order: int) -> 'OrderedDi
     return out
 
 
-def gather_detections(buf: torch.Tensor, group=None) -> torch.Tensor:
+def gather_detections(buf: torch.Tensor, group=None, _force: bool = False) -> torch.Tensor:
     """Variable-length all-gather of per-rank [K_r, D] buffers -> [sum K_r, D] in rank order (on every rank).
-    Two collectives: all_gather of the counts, all_gather of the payload padded to the maximum count."""
+    Two collectives: all_gather of the counts, all_gather of the payload padded to the maximum count.
+    (``_force``: run the collectives on a one-rank communicator too -- the single-GPU RCCL smoke test.)"""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return buf
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not _force:
         return buf
     count = torch.tensor([buf.shape[0]], dtype=torch.int64, device=buf.device)
     counts = [torch.zeros_like(count) for _ in range(world)]

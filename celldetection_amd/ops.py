@@ -288,6 +288,8 @@ def compact_scores(scores: Tensor, thresh: float, extra_flag: Tensor = None):
     scores [N,1,h,w] fp32 -> (indices int32 [P] (device), per-image counts (host list), flag value or None).
     One host sync (the D2H copy of the counts), like the reference's torch.where."""
     _need_cuda(scores)
+    if scores.ndim != 4 or scores.shape[1] != 1:
+        raise ValueError(f'compact_scores expects a [N, 1, h, w] score map, got shape {tuple(scores.shape)}')
     lib = _lib.load()
     N, _, h, w = scores.shape
     s = scores.contiguous().float()

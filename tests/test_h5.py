@@ -1,0 +1,33 @@
+"""HDF5 result files: to_h5 / from_h5 round trip through libhdf5's C API."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from celldetection_amd import h5
+
+
+@pytest.mark.skipif(not h5.hdf5_available(), reason='libhdf5 not present')
+def test_result_file_roundtrip(tmp_path):
+    rng = np.random.default_rng(0)
+    k, s, o = 23, 32, 5
+    out = dict(contours=rng.random((k, s, 2)).astype(np.float32), boxes=rng.random((k, 4)).astype(np.float32),
+               scores=torch.rand(k), classes=np.ones(k, np.int64), locations=rng.random((k, 2)).astype(np.float32),
+               fourier=rng.standard_normal((k, o, 4)).astype(np.float32),
+               contour_proposals=rng.random((k, s, 2)).astype(np.float32), labels=rng.integers(0, 9, (40, 50, 2)).astype(np.int32))
+    args = dict(model='ginoro', tile_size=512, stride=384, nms_thresh=None)
+    f = str(tmp_path / 'slide.h5')
+    h5.to_h5(f, **out, attributes=dict(contours=dict(args=json.dumps(args))))  # cpn_inference.py:822-823
+    assert open(f, 'rb').read(8) == b'\x89HDF\r\n\x1a\n'
+    names = list(out)
+    *arrays, attrs = h5.from_h5(f, *names, attributes=True)
+    for name, a in zip(names, arrays):
+        exp = out[name].numpy() if isinstance(out[name], torch.Tensor) else out[name]
+        assert a.dtype == exp.dtype and a.shape == exp.shape, name
+        np.testing.assert_array_equal(a, exp)
+    assert json.loads(attrs['contours']['args']) == args
+    # empty result sets and replacing a dataset in an existing file
+    h5.to_h5(f, mode='a', scores=np.zeros((0,), np.float32), contours=np.zeros((0, s, 2), np.float32))
+    sc, con, boxes = h5.from_h5(f, 'scores', 'contours', 'boxes')
+    assert sc.shape == (0,) and con.shape == (0, s, 2) and boxes.shape == (k, 4)
