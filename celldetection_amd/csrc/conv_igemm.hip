@@ -265,10 +265,8 @@ __device__ __forceinline__ void ds_read16(frag_t &d, unsigned addr) {
 }
 template <int N, int WN, int WM>
 __device__ __forceinline__ void wait_frags(frag_t (&w)[WN], frag_t (&p)[WM]) {
-    static_assert((WN == 4 && WM == 4) || (WN == 2 && (WM == 4 || WM == 2 || WM == 1)) || (WN == 1 && (WM == 2 || WM == 1)), "frag shape");
-    if constexpr (WN == 4 && WM == 4)
-        asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]) : "n"(N));
-    else if constexpr (WN == 2 && WM == 4)
+    static_assert((WN == 2 && (WM == 4 || WM == 2 || WM == 1)) || (WN == 1 && (WM == 2 || WM == 1)), "frag shape");
+    if constexpr (WN == 2 && WM == 4)
         asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(w[0]), "+v"(w[1]), "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]) : "n"(N));
     else if constexpr (WN == 2 && WM == 2)
         asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(w[0]), "+v"(w[1]), "+v"(p[0]), "+v"(p[1]) : "n"(N));
@@ -282,9 +280,7 @@ __device__ __forceinline__ void wait_frags(frag_t (&w)[WN], frag_t (&p)[WM]) {
 // step boundary: all my DMA landed + all my LDS reads returned (fragment set named "+v" as above)
 template <int WN, int WM>
 __device__ __forceinline__ void wait_all(frag_t (&w)[WN], frag_t (&p)[WM]) {
-    if constexpr (WN == 4 && WM == 4)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]) :: "memory");
-    else if constexpr (WN == 2 && WM == 4)
+    if constexpr (WN == 2 && WM == 4)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]) :: "memory");
     else if constexpr (WN == 2 && WM == 2)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(p[0]), "+v"(p[1]) :: "memory");
@@ -299,10 +295,6 @@ template <int WN, int WM, int FRAG_STRIDE>
 __device__ __forceinline__ void load_frags(frag_t (&w)[WN], frag_t (&p)[WM], unsigned paddr, unsigned waddr) {
     ds_read16<0>(w[0], waddr);
     if constexpr (WN > 1) ds_read16<32 * REC>(w[1], waddr);
-    if constexpr (WN > 2) {
-        ds_read16<64 * REC>(w[2], waddr);
-        ds_read16<96 * REC>(w[3], waddr);
-    }
     ds_read16<0>(p[0], paddr);
     if constexpr (WM > 1) ds_read16<FRAG_STRIDE>(p[1], paddr);
     if constexpr (WM > 2) {
@@ -1005,11 +997,7 @@ int launch_conv(const ConvArgs &a, hipStream_t stream) {
     if (c.TH == 16) return launch_cfg<16, 64, 2, 2>(a, stream);
     if (c.TH == 8) {
         switch (c.BN) {
-#ifdef CPN_EXP_W44
-            case 256: return launch_cfg<8, 256, 4, 4>(a, stream);
-#else
             case 256: return launch_cfg<8, 256, 4, 2>(a, stream);
-#endif
             case 128: return launch_cfg<8, 128, 2, 2>(a, stream);
             case 64: return launch_cfg<8, 64, 2, 2>(a, stream);
             default: return launch_cfg<8, 32, 2, 1>(a, stream);
