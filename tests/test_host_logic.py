@@ -175,3 +175,34 @@ def test_fp8_packing_passes_plan_validation(name):
         assert not bool(((codes & 0x7f) == 0x7f).any()), op['w']  # no e4m3 NaN codes
         if items % 2:  # the padding slab of the last item is all zero
             assert int(codes.reshape(d.bundles, items + 1, -1)[:, -1].max()) == 0
+
+
+def test_backbone_kwargs_whitelist_and_model2dict():
+    """Constructor options the HIP graph does not model must fail loudly unless they carry the reference's default
+    (a checkpoint trained with inputs_mean=0.5 would otherwise load and silently compute something else)."""
+    u8 = {'backbone_kwargs': {'base_channels': 8}}
+    cda.models.CpnU22(3, backbone_kwargs=dict(u8, inputs_mean=0., inputs_std=1., pretrained=False))
+    for bad in (dict(u8, inputs_mean=.5), dict(u8, inputs_std=(.2, .2, .2)), dict(u8, interpolate='bilinear'),
+                {'backbone_kwargs': {'base_channels': 8, 'block_cls': 'ResBlock'}}, dict(u8, made_up_option=1)):
+        with pytest.raises(NotImplementedError):
+            cda.models.CpnU22(3, backbone_kwargs=bad)
+    with pytest.raises(NotImplementedError):
+        cda.models.CpnResNet18FPN(3, backbone_kwargs={'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8, 'fused_initial': True}})
+    m = cda.models.CpnU22(3, backbone_kwargs=u8)
+    m.score_thresh, m.samples = .5, 64
+    d = cda.model2dict(m)
+    assert d['model'] == 'CpnU22' and d['updated_kwargs'] == {'score_thresh': .5, 'samples': 64}
+    assert d['kwargs']['backbone_kwargs'] == u8 and d['kwargs']['score_thresh'] == .9
+    m2 = cda.dict2model(d)
+    assert m2.score_thresh == .5 and m2.samples == 64 and list(m2.state_dict()) == list(m.state_dict())
+
+
+def test_plans_per_precision():
+    """bf16 plans fuse the bilinear resize into the refinement head's loader; fp8 / fp32 plans keep the separate op."""
+    m = cda.models.CpnResNet18FPN(3, backbone_kwargs={'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}})
+    kinds = lambda p: [o['op'] for o in p.ops]
+    assert 'bilinear' not in kinds(m.plan_for('bf16')) and 'bilinear' in kinds(m.plan_for('fp8'))
+    assert any(o.get('up0') == 'bilinear' for o in m.plan_for('bf16').ops if o['op'] == 'conv')
+    assert not any(o.get('fuse') for o in m.plan_for('fp32').ops if o['op'] == 'conv')
+    u = cda.models.CpnU22(3, backbone_kwargs={'backbone_kwargs': {'base_channels': 8}})
+    assert 'bilinear' not in kinds(u.plan_for('fp8'))  # level 0 of a U22 has the input size by construction

@@ -2,7 +2,7 @@
 # Round-end GPU pass (run on the MI355X box through gpurun, from the repo root):
 #   tools/gpu_round_pass.sh <tag> [tests] [bench] [profile] [fp8]
 # writes everything under gpurun_out/ (the summaries that should be judged are then copied into profiles/).
-TAG=${1:-r01}; shift
+TAG=${1:-r02}; shift
 WHAT=${*:-tests bench profile}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
@@ -28,6 +28,13 @@ profile)
     "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of tools/run_graph_only.py 5 (${TAG}); see profiles/${TAG}_rocprofv3_summary.txt"
   grep -h "^{" $P/trace.log > gpurun_out/${TAG}_bench_lines_under_rocprof.txt
   grep -A8 "run_graph_only" gpurun_out/${TAG}_rocprofv3_summary.txt | cut -c1-150;;
+slide)
+  timeout 600 python bench.py --workload slide > gpurun_out/${TAG}_bench_slide_n1.json 2> gpurun_out/${TAG}_bench_slide.err; cut -c1-900 gpurun_out/${TAG}_bench_slide_n1.json
+  CPN_BENCH_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --workload slide --slide 4096 > gpurun_out/${TAG}_bench_slide_rccl1.json 2> gpurun_out/${TAG}_bench_slide_rccl1.err; cut -c1-300 gpurun_out/${TAG}_bench_slide_rccl1.json;;
+configs)
+  timeout 600 python bench.py --model CpnResNet18FPN --batch 8 --no-cpu-baseline --profile-layers > gpurun_out/${TAG}_bench_cfg1.json 2> gpurun_out/${TAG}_cfg1_layers.txt; cut -c1-200 gpurun_out/${TAG}_bench_cfg1.json
+  timeout 600 python bench.py --model CpnResNet50FPN --batch 8 --tile 1024 --precision fp8 --no-cpu-baseline --steps 10 > gpurun_out/${TAG}_bench_cfg4_fp8.json 2> gpurun_out/${TAG}_cfg4.err; cut -c1-200 gpurun_out/${TAG}_bench_cfg4_fp8.json
+  timeout 600 python bench.py --model CpnResNet50FPN --batch 4 --tile 1024 --precision fp8 --no-cpu-baseline --steps 10 --profile-layers > gpurun_out/${TAG}_bench_cfg4_fp8_b4.json 2> gpurun_out/${TAG}_cfg4_b4_layers.txt; cut -c1-200 gpurun_out/${TAG}_bench_cfg4_fp8_b4.json; tail -4 gpurun_out/${TAG}_cfg4_b4_layers.txt;;
 fp8)
   timeout 600 python bench.py --precision fp8 --no-cpu-baseline > gpurun_out/${TAG}_bench_fp8_n1.json 2> gpurun_out/${TAG}_bench_fp8.err; cat gpurun_out/${TAG}_bench_fp8_n1.json | cut -c1-300
   (timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $P/f8trace -o b -- python bench.py --precision fp8 --steps 5 --warmup 2 --no-cpu-baseline) > $P/f8trace.log 2>&1
