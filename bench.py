@@ -11,7 +11,10 @@ Workloads
   tiles (default; BASELINE.json configs[2], the configuration the metric is quoted on): one *step* = one pass of the
       whole hot path (input conversion -> ResNeXt101-UNet conv stack -> 4 heads -> compaction -> Fourier decode +
       refinement + boxes -> per-image NMS) over one batch of 16 synthetic 3x512x512 tiles per GPU, inputs resident in
-      HBM.  Tiles are independent: no data-path collective, weak scaling.
+      HBM.  Tiles are independent: no data-path collective, weak scaling.  The K timed steps run the way the tile loop
+      of the product runs them (CPN.forward_pipelined: conv graph of step i+1 enqueued on one HIP stream before the
+      post-processing of step i runs on a second one); every step's whole work finishes inside the timed region.
+      --no-pipeline: one synchronous forward() per step.
   slide (BASELINE.json configs[3]): one *step* = the whole tiled-inference loop over a synthetic 3x16384x16384 uint8
       slide resident on every rank (1849 tiles 512/384, strided tile -> rank sharding, on-device crops, border
       removal, ONE packed all-gather of the per-rank detections over RCCL, global NMS on every rank).  Fixed total
@@ -197,8 +200,10 @@ def main():
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp8'],
                     help="conv-graph precision; 'fp8' (e4m3, K=64 scaled MFMA) is BASELINE.json configs[4] groundwork, "
                          'the headline metric is quoted on bf16')
-    ap.add_argument('--pipeline', action='store_true',
-                    help='two-stream throughput mode (CPN.forward_pipelined); default: synchronous forward() per step')
+    ap.add_argument('--pipeline', dest='pipeline', action='store_true', default=True,
+                    help='(default) throughput mode of the tile loop, CPN.forward_pipelined: the conv graph of step i+1 is '
+                         'enqueued before the post-processing of step i; all work of the K steps completes inside the timed region')
+    ap.add_argument('--no-pipeline', dest='pipeline', action='store_false', help='synchronous forward() per step')
     ap.add_argument('--profile-layers', action='store_true', help='print per-op timings to stderr')
     args = ap.parse_args()
     if args.steps is None:

@@ -2,6 +2,7 @@
 under torch.distributed.run with one rank, and the collectives of the slide path (count all-gather, padded payload
 all-gather, MAX all-reduce, barrier) run on it.  The multi-rank logic itself is covered by the gloo tests."""
 import os
+import socket
 import subprocess
 import sys
 
@@ -17,7 +18,10 @@ def test_rccl_one_rank_collectives_and_slide_loop():
         pytest.skip('needs a GPU')
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr', '127.0.0.1',
-           '--master-port', '29517', os.path.join(ROOT, 'tests', 'rccl_probe.py')]
+           '--master-port', str(port), os.path.join(ROOT, 'tests', 'rccl_probe.py')]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
     assert r.returncode == 0 and 'RCCL_PROBE_OK' in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
