@@ -290,25 +290,49 @@ def forward_tiled(model, inputs: torch.Tensor, crop_size=1024, stride=512, borde
     slices = list(slices)
     h_tiles, w_tiles = shape
     nms_thresh = model.nms_thresh if nms_thresh is None else nms_thresh
-    coll = [dict(contours=[], scores=[], boxes=[]) for _ in range(n_img)]
+    dev = inputs.device
     jobs = [(j, i) for i in range(len(slices)) for j in range(n_img)
             if inputs_mask is None or bool(torch.any(inputs_mask[j][(...,) + slices[i]]))]
-    for b0 in range(0, len(jobs), batch_size):
-        chunk = jobs[b0:b0 + batch_size]
-        tiles = torch.stack([inputs[j][(...,) + slices[i]] for j, i in chunk])
-        offs = torch.tensor([[slices[i][1].start, slices[i][0].start] for _, i in chunk], dtype=torch.int64)
-        y = model(tiles, offsets=offs)
-        for n, (j, i) in enumerate(chunk):
+    meta = []
+
+    def batches():
+        for b0 in range(0, len(jobs), batch_size):
+            chunk = jobs[b0:b0 + batch_size]
+            tiles = torch.stack([inputs[j][(...,) + slices[i]] for j, i in chunk])
+            offs = torch.tensor([[slices[i][1].start, slices[i][0].start] for _, i in chunk], dtype=torch.int64)
+            meta.append((chunk, offs, tuple(tiles.shape[-2:])))
+            yield tiles, dict(offsets=offs)
+
+    # like tiled_inference: all detections of a forwarded batch are filtered by ONE border-rule launch, rows are
+    # selected once per image at the end
+    pending = []
+    for flat, counts in model.forward_pipelined(batches(), flat_output=True):
+        chunk, offs, size = meta.pop(0)
+        if flat['scores'].shape[0] == 0:
+            continue
+        sides = []
+        for _, i in chunk:
             h_i, w_i = np.unravel_index(i, shape)
-            boxes = y['boxes'][n]
-            keep = ((boxes[:, 2] - boxes[:, 0]) >= min_box_size) & ((boxes[:, 3] - boxes[:, 1]) >= min_box_size)
-            keep &= ops.remove_border_contours(y['contours'][n], tuple(tiles.shape[-2:]), border_removal, top=h_i > 0,
-                                               right=w_i < (w_tiles - 1), bottom=h_i < (h_tiles - 1), left=w_i > 0,
-                                               offsets=-offs[n])
-            for k in ('contours', 'scores', 'boxes'):
-                coll[j][k].append(y[k][n][keep])
+            sides.append((1 if h_i > 0 else 0) | (2 if w_i < (w_tiles - 1) else 0) |
+                         (4 if h_i < (h_tiles - 1) else 0) | (8 if w_i > 0 else 0))
+        sides_t = torch.tensor(sides, dtype=torch.int32).to(dev, non_blocking=True)
+        neg = (-offs).to(torch.float32).to(dev, non_blocking=True)
+        boxes = flat['boxes']
+        keep = ((boxes[:, 2] - boxes[:, 0]) >= min_box_size) & ((boxes[:, 3] - boxes[:, 1]) >= min_box_size)
+        keep &= ops.remove_border_contours_batched(flat['contours'], flat['b'], sides_t, neg, size, border_removal).bool()
+        img = torch.tensor([j for j, _ in chunk], dtype=torch.int64).to(dev, non_blocking=True)[flat['b'].long()]
+        pending.append((flat, keep, img))
+    coll = [dict(contours=[], scores=[], boxes=[]) for _ in range(n_img)]
+    if pending:
+        keep_all = torch.cat([k for _, k, _ in pending])
+        img_all = torch.cat([m for _, _, m in pending])
+        cat = {k: torch.cat([f[k] for f, _, _ in pending]) for k in ('contours', 'scores', 'boxes')}
+        for j in range(n_img):
+            sel = (keep_all & (img_all == j)).nonzero().squeeze(1)
+            if sel.numel():
+                for k in cat:
+                    coll[j][k].append(cat[k].index_select(0, sel))
     final = OrderedDict(contours=[], scores=[], boxes=[])
-    dev = inputs.device
     for j in range(n_img):
         if coll[j]['scores']:
             con, sco, box = (torch.cat(coll[j][k]) for k in ('contours', 'scores', 'boxes'))

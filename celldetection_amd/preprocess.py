@@ -36,7 +36,7 @@ def _order_statistics(x: torch.Tensor, ranks):
         bins = 256 if x.dtype == torch.uint8 else 65536
         hist = torch.zeros(bins, dtype=torch.int32, device=x.device)
         check(_lib.load().cpn_histogram(ptr(flat), _DT[x.dtype], n, ptr(hist), stream_ptr()), 'histogram')
-        cum = torch.cumsum(hist.to(torch.int64), 0).cpu().numpy()
+        cum = torch.cumsum(hist.to(torch.int64) & 0xFFFFFFFF, 0).cpu().numpy()  # bins are uint32 counters
         return [float(np.searchsorted(cum, r, side='right')) for r in ranks]
     flat = flat.float()
     return [float(torch.kthvalue(flat, r + 1).values.item()) for r in ranks]
