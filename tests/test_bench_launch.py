@@ -22,12 +22,17 @@ def _json_line(out):
     return json.loads(lines[0])
 
 
-def test_self_launch_two_ranks_gloo():
-    r = _run(['--gpus', '2', '--backend', 'gloo', '--dry-run'])
+import pytest
+
+
+@pytest.mark.parametrize('n', [2, 4])
+def test_self_launch_n_ranks_gloo(n):
+    r = _run(['--gpus', str(n), '--backend', 'gloo', '--dry-run'])
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
-    assert d['dry_run'] is True and d['n_gpus'] == 2 and d['world_size_seen'] == 2
-    assert d['gathered_detections'] == 3 * d['tiles'] + 1  # 3 per tile + rank (0 + 1): ragged per-rank counts
+    assert d['dry_run'] is True and d['n_gpus'] == n and d['world_size_seen'] == n
+    assert d['gathered_detections'] == 3 * d['tiles'] + n * (n - 1) // 2  # 3 per tile + rank: ragged per-rank counts
+    assert r.stdout.strip().count('\n') == 0  # ONE line on stdout, whatever the libraries print
 
 
 def test_single_rank_dry_run():
