@@ -140,14 +140,14 @@ class _Engine:
         x = x.contiguous()
         f32 = dict(dtype=torch.float32, device=self.device)
         meta = self.plan.meta
-        hh, ww = self.output_size(h, w, _lib.OUT_SCORES)  # head grid: any H x W (sizes propagated by the executor)
-        scores = torch.empty((n, meta.get('score_channels', 1), hh, ww), **f32)
-        locations = torch.empty((n, 2, hh, ww), **f32)
-        fourier = torch.empty((n, 4 * order_total, hh, ww), **f32)
-        ref = torch.empty((n, 2 * meta.get('refinement_buckets', 1), h, w), **f32) if refinement else None
-        if refinement and self.output_size(h, w, _lib.OUT_REFINEMENT) != (h, w):
-            raise RuntimeError('refinement head output does not have the input size')  # cpn.py:279 would resize it
-        self.last_uncertainty = torch.empty((n, 4, hh, ww), **f32) if meta.get('uncertainty_head') else None
+        # head grids: any H x W (sizes propagated by the executor; heads may read different features / use a stride)
+        scores = torch.empty((n, meta.get('score_channels', 1)) + self.output_size(h, w, _lib.OUT_SCORES), **f32)
+        locations = torch.empty((n, 2) + self.output_size(h, w, _lib.OUT_LOCATIONS), **f32)
+        fourier = torch.empty((n, 4 * order_total) + self.output_size(h, w, _lib.OUT_FOURIER), **f32)
+        ref = torch.empty((n, 2 * meta.get('refinement_buckets', 1)) + self.output_size(h, w, _lib.OUT_REFINEMENT),
+                          **f32) if refinement else None
+        self.last_uncertainty = torch.empty((n, 4) + self.output_size(h, w, _lib.OUT_UNCERTAINTY), **f32) \
+            if meta.get('uncertainty_head') else None
         flag = torch.zeros(1, dtype=torch.int32, device=self.device)
         # the kernels address activation tensors with 32-bit offsets / 2^31-byte buffer descriptors: split the batch when
         # a tensor of the graph would exceed that (e.g. 8 x 256 ch x 1024^2 in front of an FPN refinement head)
@@ -175,6 +175,8 @@ class _Engine:
             else:
                 _lib.check(lib.cpn_plan_run(self.handle, _lib.ptr(xi), dt, m, h, w, _lib.ptr(ws), need, outs,
                                             _lib.ptr(flag), _lib.stream_ptr()), 'plan_run')
+        if ref is not None and tuple(ref.shape[2:]) != (h, w):  # strided refinement head: `_equal_size(.., inputs)`, cpn.py:279
+            ref = _equal_size(ref, x)
         return scores, locations, ref, fourier, flag
 
 
@@ -203,13 +205,15 @@ class CPN(nn.Module):
                  backbone_kwargs: dict = None, **kwargs):
         super().__init__()
         unsupported = {k: v for k, v in kwargs.items() if (k in ('contour_head_stride', 'refinement_head_stride')
-                                                           and v not in (None, 1))
-                       or (k in ('contour_features', 'location_features', 'score_features', 'uncertainty_features')
-                           and v != '1') or (k == 'refinement_features' and v != '0')
+                                                           and v not in (None, 1, 2))
                        or (k == 'refinement_interpolation' and v != 'bilinear')
+                       or (k == 'refinement_full_res' and v is not True) or (k == 'fuse_kwargs' and v)
                        or (k.startswith('head_activation') and v != 'relu')}
         if unsupported:
             raise NotImplementedError(f'Unsupported CPN options on the HIP path: {unsupported}')
+        features = {name: kwargs[key] for name, key in (('score', 'score_features'), ('location', 'location_features'),
+                                                        ('contour', 'contour_features'), ('uncertainty', 'uncertainty_features'),
+                                                        ('refinement', 'refinement_features')) if kwargs.get(key) is not None}
         kernel_sizes = {k[len('kernel_size_'):]: int(v) for k, v in kwargs.items() if k.startswith('kernel_size_')}
         self.order = order
         self.nms_thresh = nms_thresh
@@ -232,7 +236,9 @@ class CPN(nn.Module):
                                  uncertainty_head=bool(uncertainty_head),
                                  contour_head_channels=kwargs.get('contour_head_channels'),
                                  refinement_head_channels=kwargs.get('refinement_head_channels'),
-                                 kernel_sizes=kernel_sizes)
+                                 kernel_sizes=kernel_sizes, features=features or None,
+                                 contour_head_stride=int(kwargs.get('contour_head_stride') or 1),
+                                 refinement_head_stride=int(kwargs.get('refinement_head_stride') or 1))
         # 'bf16' (MFMA performance path) | 'fp32' (verification path, ~100x slower) | 'fp8' (e4m3 activations and
         # weights on the K=64 scaled MFMA, 2x the bf16 rate; static activation scales from ``calibrate_fp8`` or, if
         # that was not called, from the first batch that is forwarded)
@@ -422,6 +428,8 @@ class CPN(nn.Module):
         refinement [N,2*buckets,H,W] or None; fourier [N,4*O,h,w]; uncertainty [N,4,h,w] or None (cpn.py:209-221).
         ``flat_output``: return ``(dict of flat [K, ...] tensors incl. 'b' = image index int32 [K], per-image counts)``
         instead of per-image lists (the slide loop filters all tiles of a batch at once)."""
+        if self.functional:
+            raise NotImplementedError("the 'functional' Fourier layout (cpn.py:591-592) is not supported on the HIP path")
         n = scores.shape[0]
         lb, ub = kwargs.get('scores_lower_bound'), kwargs.get('scores_upper_bound')
         ub = None if ub is None else _equal_size(ub.to(scores), scores)  # cpn.py:118-123

@@ -62,8 +62,8 @@ class Plan:
             down_in = t0['down'] // (2 if up0 else 1)
             assert t0['down'] % (2 if up0 else 1) == 0
         cin = t0['c'] + (self.tensors[src1]['c'] if src1 is not None else 0)
-        if src1 is not None:
-            assert self.tensors[src1]['down'] // (2 if up1 else 1) == down_in
+        if src1 is not None and not up1:  # (a resized second source takes the size of the first one: any ratio)
+            assert self.tensors[src1]['down'] == down_in
         down_out = down_in * stride
         dst = self.tensor(cout, down_out) if out_index is None else None
         self.conv_keys(w, cout, cin // groups, k, bias)
@@ -254,6 +254,8 @@ def _generalized_unet(P, feats, channels, strides, prefix):
         entries_layer[i] = P.entries[mark:]
         del P.entries[mark:]
         results[i] = last
+    results[depth] = feats[-1]  # the dict of the reference ends with the deepest encoder feature itself (unet.py:207-249)
+    out_list = list(out_list) + [channels[-1]] if len(out_list) <= depth else list(out_list)
     for i in sorted(entries_inner):
         P.entries += entries_inner[i]
     for i in sorted(entries_layer):
@@ -261,7 +263,7 @@ def _generalized_unet(P, feats, channels, strides, prefix):
     return results, out_list
 
 
-def _fpn(P, feats, channels, prefix, fpn_channels):
+def _fpn(P, feats, channels, prefix, fpn_channels, live=(0, 1)):
     """FeaturePyramidNetwork (fpn.py:79-134; forward = torchvision): ConvNorm(norm=Identity) 1x1 laterals with bias,
     top-down nearest upsample + add (fused as an upsampled residual), 3x3 output convs.  Levels whose outputs the CPN
     never reads (layer_blocks 2..4, 'pool') are skipped but their parameters stay in the state dict."""
@@ -275,7 +277,7 @@ def _fpn(P, feats, channels, prefix, fpn_channels):
                       res=last, res_up=last is not None)
         lat_entries[idx] = P.entries[mark:]
         del P.entries[mark:]
-        if idx <= 1:
+        if idx in live:
             outs[idx] = P.conv(last, fpn_channels, 3, w=f'{prefix}layer_blocks.{idx}.0.', bias=True)
         else:  # dead level: keep the parameters only
             P.conv_keys(f'{prefix}layer_blocks.{idx}.0.', fpn_channels, fpn_channels, 3, True)
@@ -301,14 +303,14 @@ for _k in _RESNETS:
 BACKBONES['U22'] = ('unet', 'U22')
 
 
-def _readout(P, x, cmid, cout, prefix, act, act_scale, out_index, k=7, fuse=True, up0=False):
+def _readout(P, x, cmid, cout, prefix, act, act_scale, out_index, k=7, fuse=True, up0=False, stride=1):
     """ReadOut (commons.py:461-511): conv kxk(bias) -> BN -> ReLU -> Dropout2d(eval: identity) -> conv 1x1(bias)."""
     if fuse and FUSE_READOUT and _pad32(cmid) in (32, 64, 128, 256) and cout <= 32:
         # one kernel: conv kxk + BN + ReLU -> (bf16, LDS) -> 1x1 conv + final activation -> fp32 NCHW head map
         P.conv(x, cmid, k, w=prefix + 'block.0.', bn=prefix + 'block.1.', bias=True, act='relu', out_index=out_index,
-               fuse=dict(w=prefix + 'block.4.', cout=cout, act=act, act_scale=act_scale), up0=up0)
+               fuse=dict(w=prefix + 'block.4.', cout=cout, act=act, act_scale=act_scale), up0=up0, stride=stride)
         return
-    t = P.conv(x, cmid, k, w=prefix + 'block.0.', bn=prefix + 'block.1.', bias=True, act='relu', up0=up0)
+    t = P.conv(x, cmid, k, w=prefix + 'block.0.', bn=prefix + 'block.1.', bias=True, act='relu', up0=up0, stride=stride)
     P.conv(t, cout, 1, w=prefix + 'block.4.', bias=True, act=act, act_scale=act_scale, out_index=out_index)
 
 
@@ -316,10 +318,19 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
                refinement_margin: float = 3., refinement_buckets: int = 1, order_weights: bool = True,
                backbone_kwargs: dict = None, fuse_readout: bool = True, uncertainty_head: bool = False,
                contour_head_channels: int = None, refinement_head_channels: int = None,
-               kernel_sizes: dict = None, fuse_bilinear: bool = True) -> Plan:
+               kernel_sizes: dict = None, fuse_bilinear: bool = True, contour_head_stride: int = 1,
+               refinement_head_stride: int = 1, features: dict = None) -> Plan:
     """Plan of ``Cpn<backbone>`` (celldetection/models/cpn.py:287-439,771-2061; heads: CPNCore.__init__
     cpn.py:125-236).  ``kernel_sizes``: optional {'score'|'location'|'fourier'|'uncertainty'|'refinement': k}
-    (the reference's ``kernel_size_<head>`` kwargs, default 7)."""
+    (the reference's ``kernel_size_<head>`` kwargs, default 7).  ``contour_head_stride`` / ``refinement_head_stride``: stride
+    (1 or 2) of the k x k conv of the ReadOut heads (commons.py:494).  ``features``: optional {'score'|'location'|
+    'contour'|'uncertainty'|'refinement': key or [key, key]} = the reference's ``<head>_features`` kwargs (cpn.py:135-139):
+    decoder level '0', '1', ... or 'encoder.<k>' (UNet family); two keys are fused like ``Fuse2d`` (commons.py:640-674:
+    the second feature nearest-resized to the first one's size, concat, 1x1 conv + BN + ReLU)."""
+    if contour_head_stride not in (1, 2) or refinement_head_stride not in (1, 2):
+        raise NotImplementedError('head strides other than 1 and 2 are not supported by the HIP conv kernel')
+    feats_cfg = dict(score='1', location='1', contour='1', uncertainty='1', refinement='0')
+    feats_cfg.update(features or {})
     if backbone not in BACKBONES:
         raise ValueError(f'Unsupported backbone {backbone!r}; supported: {sorted(BACKBONES)}')
     if score_channels < 1 or refinement_buckets < 1:
@@ -339,43 +350,75 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
     else:
         ekw = dict(bkw.get('backbone_kwargs') or {})
         feats, channels, strides = _resnet(P, x, in_channels, bp + 'body.', enc, **ekw)
+    def _keys(v):
+        return [str(k) for k in v] if isinstance(v, (list, tuple)) else [str(v)]
+
+    wanted = {k for name, v in feats_cfg.items() for k in _keys(v)
+              if (name != 'uncertainty' or uncertainty_head) and (name != 'refinement' or refinement)}
     if family == 'unet':
         results, out_list = _generalized_unet(P, feats, channels, strides, bp + 'unet.')
-        f0, f1 = results[0], results[1]
-        c0, c1 = out_list[0], out_list[1]
-        scale = P.tensors[f1]['down']
+        level = {str(i): (results[i], out_list[i]) for i in results}
+        level.update({f'encoder.{i}': (feats[i], channels[i]) for i in range(len(feats))})
     else:
         fc = bkw.get('fpn_channels', 256)
-        outs = _fpn(P, feats, channels, bp + 'fpn.', fc)
-        f0, f1 = outs[0], outs[1]
-        c0 = c1 = fc
-        scale = P.tensors[f1]['down']
-    cm1 = c1 if contour_head_channels is None else int(contour_head_channels)
-    cm0 = c0 if refinement_head_channels is None else int(refinement_head_channels)
+        live = sorted({int(k) for k in wanted if k.isdigit()} | {0, 1})
+        if any(i >= len(feats) for i in live):
+            raise ValueError(f'FPN feature keys must be < {len(feats)}: {sorted(wanted)}')
+        outs = _fpn(P, feats, channels, bp + 'fpn.', fc, live=live)
+        level = {str(i): (outs[i], fc) for i in outs}
+    for k in wanted:
+        if k not in level:
+            raise NotImplementedError(f'feature key {k!r} is not available on the HIP path for {backbone} '
+                                      f'(available: {sorted(level)})')
+
+    def _head_input(name, fuse_prefix):
+        """-> (tensor id, channels) of a head's input; two keys: Fuse2d = 1x1 conv + BN + ReLU over the virtual concat
+        [first | second nearest-resized to the first's size] (channels_out = channels of the first key, cpn.py:88-100)."""
+        keys = _keys(feats_cfg[name])
+        (t0, ch0) = level[keys[0]]
+        if len(keys) == 1:
+            return t0, ch0
+        if len(keys) > 2:
+            raise NotImplementedError('Fuse2d over more than two features is not supported on the HIP path')
+        (t1, _) = level[keys[1]]
+        t = P.conv(t0, ch0, 1, w=fuse_prefix + 'block.0.', bn=fuse_prefix + 'block.1.', bias=True, act='relu', src1=t1,
+                   up1=True)
+        return t, ch0
+
+    f1s, c1 = _head_input('score', 'core.score_fuse.')
+    scale = P.tensors[f1s]['down'] * contour_head_stride
+    cm1 = None if contour_head_channels is None else int(contour_head_channels)
+    cm0 = None if refinement_head_channels is None else int(refinement_head_channels)
     # binary: sigmoid fused into the head; multi-class: raw logits, softmax/argmax in cpn_class_scores (cpn.py:583-585)
-    _readout(P, f1, cm1, score_channels, 'core.score_head.', 'sigmoid' if score_channels == 1 else 'none', 0.,
-             _lib.OUT_SCORES, k=ks.get('score', 7), fuse=fuse_readout)
-    _readout(P, f1, cm1, 2, 'core.location_head.', 'none', 0., _lib.OUT_LOCATIONS, k=ks.get('location', 7),
-             fuse=fuse_readout)
-    _readout(P, f1, cm1, order * 4, 'core.fourier_head.', 'none', 0., _lib.OUT_FOURIER, k=ks.get('fourier', 7),
-             fuse=fuse_readout)
+    hs = contour_head_stride
+    _readout(P, f1s, cm1 or c1, score_channels, 'core.score_head.', 'sigmoid' if score_channels == 1 else 'none', 0.,
+             _lib.OUT_SCORES, k=ks.get('score', 7), fuse=fuse_readout, stride=hs)
+    fl, cl = _head_input('location', 'core.location_fuse.')
+    _readout(P, fl, cm1 or cl, 2, 'core.location_head.', 'none', 0., _lib.OUT_LOCATIONS, k=ks.get('location', 7),
+             fuse=fuse_readout, stride=hs)
+    ff, cf = _head_input('contour', 'core.fourier_fuse.')
+    _readout(P, ff, cm1 or cf, order * 4, 'core.fourier_head.', 'none', 0., _lib.OUT_FOURIER, k=ks.get('fourier', 7),
+             fuse=fuse_readout, stride=hs)
     if uncertainty_head:  # cpn.py:209-221: 4 channels, sigmoid
-        _readout(P, f1, cm1, 4, 'core.uncertainty_head.', 'sigmoid', 0., _lib.OUT_UNCERTAINTY,
-                 k=ks.get('uncertainty', 7), fuse=fuse_readout)
+        fu, cu = _head_input('uncertainty', 'core.uncertainty_fuse.')
+        _readout(P, fu, cm1 or cu, 4, 'core.uncertainty_head.', 'sigmoid', 0., _lib.OUT_UNCERTAINTY,
+                 k=ks.get('uncertainty', 7), fuse=fuse_readout, stride=hs)
     if refinement:
-        r = f0
+        r, c0 = _head_input('refinement', 'core.refinement_fuse.')
+        cm0 = cm0 or c0
         # cpn.py:277-278: bilinear resize of the features to the input size.  FPN: always (f0 lives at stride 2);
         # ResNet + UNet: the bridge level is 2 * ceil(H / 2) pixels high, i.e. H + 1 for odd H (no-op alias otherwise);
         # U22: level 0 has the input size by construction (3x3 convs, padding 1)
         # bf16 / fp8 plans: the resize is fused into the head conv's halo loader (up0 = 'bilinear': the full-resolution
         # 256-channel map of the FPN models is never written); the fp32 verification plan keeps the separate op
-        resize = family == 'fpn' or enc != 'U22'
+        resize = family == 'fpn' or enc != 'U22' or _keys(feats_cfg['refinement']) != ['0']
         kr = ks.get('refinement', 7)
-        fused_resize = resize and fuse_bilinear and kr > 1
+        fused_resize = resize and fuse_bilinear and kr > 1 and refinement_head_stride == 1
         if resize and not fused_resize:
             r = P.bilinear_to_input(r)
         _readout(P, r, cm0, 2 * refinement_buckets, 'core.refinement_head.', 'tanh_scaled', float(refinement_margin),
-                 _lib.OUT_REFINEMENT, k=kr, fuse=fuse_readout, up0='bilinear' if fused_resize else False)
+                 _lib.OUT_REFINEMENT, k=kr, fuse=fuse_readout, up0='bilinear' if fused_resize else False,
+                 stride=refinement_head_stride)
     P.meta = dict(backbone=backbone, order=order, head_down=scale, refinement=refinement, in_channels=in_channels,
                   score_channels=score_channels, refinement_buckets=refinement_buckets,
                   uncertainty_head=bool(uncertainty_head))

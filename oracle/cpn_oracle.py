@@ -147,14 +147,28 @@ def _fpn(feats, sd, p):
     return OrderedDict((str(i), r) for i, r in enumerate(results))
 
 
-def _readout(x, sd, p):
-    """ReadOut: conv kxk (bias, pad k//2) -> BN -> ReLU -> Dropout(eval: id) -> conv1x1, commons.py:461-511."""
+def _readout(x, sd, p, stride=1):
+    """ReadOut: conv kxk (bias, pad k//2, stride) -> BN -> ReLU -> Dropout(eval: id) -> conv1x1, commons.py:461-511."""
     k = sd[p + 'block.0.weight'].shape[-1]
-    x = F.relu(_bn(_conv(x, sd, p + 'block.0.', padding=k // 2), sd, p + 'block.1.'))
+    x = F.relu(_bn(_conv(x, sd, p + 'block.0.', stride=stride, padding=k // 2), sd, p + 'block.1.'))
     return _conv(x, sd, p + 'block.4.')
 
 
-def core_forward(state_dict, x, refinement_margin=3., with_uncertainty=False):
+def _head_features(feats, keys, sd, fuse_prefix):
+    """_resolve_features (cpn.py:103-106) + Fuse2d (commons.py:640-674): a list of keys is resized (nearest) to the
+    first feature's size, concatenated and passed through conv1x1 -> BN -> ReLU."""
+    if not isinstance(keys, (list, tuple)):
+        return feats[keys]
+    xs = [feats[k] for k in keys]
+    size = xs[0].shape[-2:]
+    x = torch.cat([(F.interpolate(t, size) if t.shape[-2:] != size else t) for t in xs], 1)
+    if len(xs) == 1:
+        return x
+    return F.relu(_bn(_conv(x, sd, fuse_prefix + 'block.0.'), sd, fuse_prefix + 'block.1.'))
+
+
+def core_forward(state_dict, x, refinement_margin=3., with_uncertainty=False, contour_head_stride=1,
+                 refinement_head_stride=1, features=None):
     """CPNCore.forward, models/cpn.py:238-283 -> (raw scores, locations, refinement, fourier), all fp32 NCHW
     (+ the sigmoid uncertainty map [N,4,h,w] or None as fifth element when ``with_uncertainty``).
 
@@ -172,20 +186,27 @@ def core_forward(state_dict, x, refinement_margin=3., with_uncertainty=False):
         else:
             feats = _unet_encoder(x, sd, p + 'body.')
             bridges = 0
+        enc = feats
         if _has(sd, p + 'unet.'):
             feats = _generalized_unet(feats, sd, p + 'unet.', bridges)
+            feats[str(len(feats))] = list(enc.values())[-1]  # the dict ends with the deepest encoder feature (unet.py:244)
+            feats.update({f'encoder.{k}': v for k, v in enc.items()})  # keep_features (unet.py:247-248)
         else:
             feats = _fpn(feats, sd, p + 'fpn.')
-        f1, f0 = feats['1'], feats['0']
-        scores = _readout(f1, sd, 'core.score_head.')
-        locations = _readout(f1, sd, 'core.location_head.')
-        fourier = _readout(f1, sd, 'core.fourier_head.')
+        fk = dict(score='1', location='1', contour='1', uncertainty='1', refinement='0')
+        fk.update(features or {})  # the <head>_features kwargs of CPNCore (cpn.py:135-139)
+        hs = contour_head_stride
+        scores = _readout(_head_features(feats, fk['score'], sd, 'core.score_fuse.'), sd, 'core.score_head.', hs)
+        locations = _readout(_head_features(feats, fk['location'], sd, 'core.location_fuse.'), sd, 'core.location_head.', hs)
+        fourier = _readout(_head_features(feats, fk['contour'], sd, 'core.fourier_fuse.'), sd, 'core.fourier_head.', hs)
         uncertainty = None
         if _has(sd, 'core.uncertainty_head.'):  # cpn.py:209-221,266-271: ReadOut with final sigmoid
-            uncertainty = torch.sigmoid(_readout(f1, sd, 'core.uncertainty_head.'))
+            uncertainty = torch.sigmoid(_readout(_head_features(feats, fk['uncertainty'], sd, 'core.uncertainty_fuse.'), sd,
+                                                 'core.uncertainty_head.', hs))
+        f0 = _head_features(feats, fk['refinement'], sd, 'core.refinement_fuse.')
         if f0.shape[2:] != x.shape[2:]:  # cpn.py:277-278
             f0 = F.interpolate(f0, x.shape[2:], mode='bilinear', align_corners=False)
-        refinement = torch.tanh(_readout(f0, sd, 'core.refinement_head.')) * refinement_margin
+        refinement = torch.tanh(_readout(f0, sd, 'core.refinement_head.', refinement_head_stride)) * refinement_margin
         if refinement.shape[2:] != x.shape[2:]:
             refinement = F.interpolate(refinement, x.shape[2:], mode='bilinear', align_corners=False)
     if with_uncertainty:

@@ -83,6 +83,17 @@ MODEL_SPECS = {
                    (1, 3, 75, 101)),
     'CpnU22_300': ('CpnU22', dict(in_channels=3, backbone_kwargs={'backbone_kwargs': {'base_channels': 8}}),
                    (1, 3, 300, 300)),
+    # head options of CPNCore (cpn.py:125-236): strided ReadOut heads, heads reading other / fused (Fuse2d) features
+    'CpnU22_strided': ('CpnU22', dict(in_channels=3, contour_head_stride=2, refinement_head_stride=2,
+                                      backbone_kwargs={'backbone_kwargs': {'base_channels': 8}}), (2, 3, 64, 96)),
+    'CpnResNet18FPN_fuse': ('CpnResNet18FPN', dict(in_channels=3, score_features=['1', '2'], contour_features=['1', '2'],
+                                                   location_features=['1', '2'], backbone_kwargs={
+                                                       'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}),
+                            (1, 3, 64, 96)),
+    'CpnResNet50UNet_feats': ('CpnResNet50UNet', dict(in_channels=3, score_features='2', contour_features='2',
+                                                      location_features='2', refinement_features=['0', 'encoder.0'],
+                                                      backbone_kwargs={'backbone_kwargs': {'base_channel': 8}}),
+                              (1, 3, 64, 64)),
 }
 
 

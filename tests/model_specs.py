@@ -55,7 +55,22 @@ SIZE_SPECS = {
     'CpnU22_odd': dict(cls='CpnU22', kwargs=dict(in_channels=3, backbone_kwargs=_U8), cpn_kwargs=dict(_DEF)),
     'CpnU22_300': dict(cls='CpnU22', kwargs=dict(in_channels=3, backbone_kwargs=_U8), cpn_kwargs=dict(_DEF)),
 }
-ALL_SPECS = dict(MODEL_SPECS, **VARIANT_SPECS, **SIZE_SPECS)
+# head options of CPNCore: strided heads, other / fused (Fuse2d) input features; ``core_kwargs`` = the matching arguments of
+# the oracle's conv graph
+HEAD_SPECS = {
+    'CpnU22_strided': dict(cls='CpnU22', kwargs=dict(in_channels=3, contour_head_stride=2, refinement_head_stride=2,
+                                                     backbone_kwargs=_U8), cpn_kwargs=dict(_DEF),
+                           core_kwargs=dict(contour_head_stride=2, refinement_head_stride=2)),
+    'CpnResNet18FPN_fuse': dict(cls='CpnResNet18FPN', kwargs=dict(
+        in_channels=3, score_features=['1', '2'], contour_features=['1', '2'], location_features=['1', '2'],
+        backbone_kwargs={'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}), cpn_kwargs=dict(_DEF),
+        core_kwargs=dict(features=dict(score=['1', '2'], contour=['1', '2'], location=['1', '2']))),
+    'CpnResNet50UNet_feats': dict(cls='CpnResNet50UNet', kwargs=dict(
+        in_channels=3, score_features='2', contour_features='2', location_features='2',
+        refinement_features=['0', 'encoder.0'], backbone_kwargs=_R8), cpn_kwargs=dict(_DEF),
+        core_kwargs=dict(features=dict(score='2', contour='2', location='2', refinement=['0', 'encoder.0']))),
+}
+ALL_SPECS = dict(MODEL_SPECS, **VARIANT_SPECS, **SIZE_SPECS, **HEAD_SPECS)
 
 
 def ref_template_state_dict(name, fixture=None):

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from model_specs import ALL_SPECS, MODEL_SPECS, SIZE_SPECS, VARIANT_SPECS
+from model_specs import ALL_SPECS, HEAD_SPECS, MODEL_SPECS, SIZE_SPECS, VARIANT_SPECS
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
@@ -647,3 +647,27 @@ def test_full_size_properties_config4_resnet50fpn_fp8(dev):
     rate8 = _iou_match_rate(got8['boxes'][0].cpu().numpy(), ref['boxes'][0])
     print('configs[4] tile 0 fp8: proposals', len(got8['scores'][0]), 'oracle', n_ref, 'IoU>0.5 match rate', rate8)
     assert abs(n_ref - len(got8['scores'][0])) <= 0.25 * n_ref and rate8 > .75
+
+
+@pytest.mark.parametrize('name', list(HEAD_SPECS))
+def test_head_options(dev, name):
+    """Strided ReadOut heads, heads on other decoder / encoder features, Fuse2d over two features: bf16 stack within the
+    bf16 tolerance, fp32 path end to end at the north-star tolerance, post-processing on the reference's maps exact."""
+    model, g = build(name, dev)
+    x = torch.as_tensor(g['x']).to(dev)
+    n, size = x.shape[0], tuple(x.shape[-2:])
+    maps = [torch.sigmoid(torch.as_tensor(g['core.scores'])).to(dev), torch.as_tensor(g['core.locations']).to(dev),
+            torch.as_tensor(g['core.refinement']).to(dev), torch.as_tensor(g['core.fourier']).to(dev)]
+    check_exact('nms', model.postprocess(*maps, size), g, n)
+    check_exact('offs', model.postprocess(*maps, size, offsets=torch.as_tensor(g['offsets'])), g, n)
+    exp = dict(scores=torch.sigmoid(torch.as_tensor(g['core.scores'])), locations=torch.as_tensor(g['core.locations']),
+               refinement=torch.as_tensor(g['core.refinement']), fourier=torch.as_tensor(g['core.fourier']))
+    for precision, tol in (('bf16', 6e-2), ('fp32', 2e-4)):
+        model.precision = precision
+        got = dict(zip(('scores', 'locations', 'refinement', 'fourier'), [t.cpu() for t in model.core_forward(x)]))
+        for key, e in exp.items():
+            assert got[key].shape == e.shape, (key, got[key].shape, e.shape)
+            rel = ((got[key] - e).norm() / (e.norm() + 1e-12)).item()
+            print(name, precision, key, f'relL2 {rel:.3e}')
+            assert rel < tol, (name, precision, key, rel)
+    check_exact('nms', model(x), g, n, raw_atol=5e-4, flip_frac=1e-3)  # fp32 path, whole forward

@@ -8,7 +8,7 @@ import torch
 
 import cpn_oracle as orc
 from celldetection_amd.synth import synth_state_dict
-from model_specs import ALL_SPECS, MODEL_SPECS, SIZE_SPECS, VARIANT_SPECS, ref_template_state_dict
+from model_specs import ALL_SPECS, HEAD_SPECS, MODEL_SPECS, SIZE_SPECS, VARIANT_SPECS, ref_template_state_dict
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
@@ -254,3 +254,22 @@ def test_arbitrary_input_sizes(name):
     _check_outputs('offs', orc.cpn_postprocess(*maps, input_size=size, offsets=g['offsets'], **kw), g, n)
     _check_outputs('bounds', orc.cpn_postprocess(*maps, input_size=size, scores_upper_bound=g['scores_upper_bound'],
                                                  scores_lower_bound=g['scores_lower_bound'], **kw), g, n)
+
+
+@pytest.mark.parametrize('name', list(HEAD_SPECS))
+def test_head_options(name):
+    """CPNCore head options (cpn.py:125-236): strided ReadOut heads (maps at half the resolution, refinement map
+    bilinear-resized back to the input size), heads reading another decoder level / an encoder feature, Fuse2d over two
+    features -- the oracle's conv graph and post-processing against the reference's outputs."""
+    g, sd = _load_model_fixture(name)
+    spec = HEAD_SPECS[name]
+    x = torch.as_tensor(g['x'])
+    torch.set_num_threads(4)
+    s, l, r, f = orc.core_forward(sd, x, **spec['core_kwargs'])
+    for got, key in ((s, 'scores'), (l, 'locations'), (r, 'refinement'), (f, 'fourier')):
+        assert got.shape == g[f'core.{key}'].shape, (key, got.shape, g[f'core.{key}'].shape)
+        np.testing.assert_allclose(got.numpy(), g[f'core.{key}'], rtol=1e-4, atol=1e-3)
+    n, size = x.shape[0], tuple(x.shape[-2:])
+    maps = (g['core.scores'], g['core.locations'], g['core.refinement'], g['core.fourier'])
+    _check_outputs('nms', orc.cpn_postprocess(*maps, input_size=size, **spec['cpn_kwargs']), g, n)
+    _check_outputs('offs', orc.cpn_postprocess(*maps, input_size=size, offsets=g['offsets'], **spec['cpn_kwargs']), g, n)
