@@ -309,6 +309,7 @@ def main():
 
     # per-op timing of ONE more graph execution (outside the timed region): backbone-stack fraction of the roofline
     backbone = None
+    dominant = None
     prof = None
     if rank == 0:
         try:
@@ -325,6 +326,16 @@ def main():
                         'algorithmic_gflop': bb_gf * args.batch,
                         'note': 'backbone conv stack (body + unet incl. input/maxpool helpers) of one per-op-timed graph '
                                 'execution outside the timed region'}
+        # the dominant kernel instantiation, conv_igemm_kernel<8,256,4,2,1>: dense k x k stride-1 convs with >= 256 output
+        # channels (8 decoder 3x3 + 3 head 7x7 convs of CpnResNeXt101UNet), from the same per-op timing
+        dom = [p for p in prof if p['op'] == 'conv' and (p['k'] or 0) > 1 and p['groups'] == 1 and p['stride'] == 1
+               and (p['cout'] or 0) >= 256 and (p['cin'] or 0) >= 64]
+        if dom:
+            d_ms, d_gf = sum(p['ms'] for p in dom), sum(p['gflop'] for p in dom)
+            dominant = {'kernel': 'conv_igemm_kernel<8,256,4,2,1>' if args.precision == 'bf16' else 'cpn_fp8::conv_igemm_kernel<8,256,4,2,1>',
+                        'launches_per_graph': len(dom), 'avg_launch_us': 1e3 * d_ms / len(dom), 'gflop_per_graph': d_gf,
+                        'achieved': d_gf / d_ms, 'frac': d_gf / d_ms / (PEAK_BF16_TFLOPS * (2 if args.precision == 'fp8' else 1)),
+                        'share_of_graph_time': d_ms / tot}
         if args.profile_layers:
             for p in prof:
                 if p['op'] == 'conv':
@@ -367,7 +378,7 @@ def main():
                                    '(+ input/maxpool helpers), timed with HIP events on the launch stream',
                          'launch_ms': conv_ms, 'algorithmic_gflop_per_launch': gf * args.batch,
                          'executed_gflop_per_launch': executed, 'executed_frac': executed / conv_ms / peak,
-                         'backbone_stack': backbone},
+                         'backbone_stack': backbone, 'dominant_kernel': dominant},
         }
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(sd, args.tile)

@@ -26,8 +26,14 @@ def contours2labels(contours, size, rounded=True, clip=True, initial_depth=1, ga
     if np.dtype(dtype) != np.int32:
         raise NotImplementedError("contours2labels on the HIP path produces dtype 'int32' (the reference's default)")
     if not isinstance(contours, torch.Tensor):
-        contours = torch.as_tensor(np.stack([np.asarray(c, np.float32) for c in contours]) if len(contours)
-                                   else np.zeros((0, 1, 2), np.float32))
+        # List[Array[num_points, 2]] with different lengths: pad by repeating the last point (a zero-length edge draws the
+        # same pixel again and takes no part in the scanline fill -> identical raster)
+        arrs = [np.asarray(c.detach().cpu() if isinstance(c, torch.Tensor) else c, np.float32).reshape(-1, 2) for c in contours]
+        smax = max([len(a) for a in arrs] + [1])
+        arrs = [np.concatenate((a, np.repeat(a[-1:], smax - len(a), 0))) if 0 < len(a) < smax else a for a in arrs]
+        arrs = [a for a in arrs if len(a)]
+        contours = torch.as_tensor(np.stack(arrs) if arrs else np.zeros((0, 1, 2), np.float32))
+        contours = contours.cuda() if torch.cuda.is_available() else contours
     if not contours.is_cuda:
         raise RuntimeError('celldetection_amd.contours2labels runs on the MI355X only (got a CPU tensor).')
     lib = _lib.load()

@@ -66,6 +66,9 @@ def test_contours2labels_matches_oracle(k, size, spread, s):
     assert tuple(got.shape) == exp.shape, (got.shape, exp.shape)
     np.testing.assert_array_equal(got.cpu().numpy(), exp)
     assert got.dtype == torch.int32
+    if k == 60:  # List[Array[num_points, 2]] of different lengths (the reference's second input form)
+        ragged = [c[:len(c) - (i % 5)] for i, c in enumerate(con)]
+        np.testing.assert_array_equal(cda.contours2labels(ragged, size).cpu().numpy(), lo.contours2labels(ragged, size))
     exp2 = lo.contours2labels(con, size, gap=0, initial_depth=2)
     got2 = cda.contours2labels(torch.as_tensor(con).cuda(), size, gap=0, initial_depth=2)
     np.testing.assert_array_equal(got2.cpu().numpy(), exp2)
