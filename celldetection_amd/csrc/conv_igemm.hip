@@ -368,6 +368,10 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     constexpr int WITEM = BN * REC;   // one item's weight slab tile
     constexpr int WBUF = 2 * WITEM;   // one step's weights
     const int ldsW_off = nhb * halo_buf;
+    constexpr int IPR = PITCH / 16;  // halo DMA instructions per halo row (16 pixel records of 64 B each)
+    static_assert(PITCH % 16 == 0, "a halo row must be a whole number of DMA instructions");
+    typedef __attribute__((address_space(3))) unsigned lds_u32_t;
+    lds_u32_t *const coltab = (lds_u32_t *) (smem + ldsW_off + 2 * WBUF);  // column offset table (see below)
 
     HaloGeo G;
     G.sub = PW ? a.stride : 1;
@@ -429,16 +433,29 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
         const unsigned soff_ = (unsigned) (from0_ ? cin_ : cin_ - c0_used) * (unsigned) ES;                    \
         unsigned char *dstb_ = smem + (c_ & nhb_mask) * halo_buf;                                              \
         const int q1_ = (Q1);                                                                                  \
+        const int up_ = from0_ ? G.up0 : G.up1, Hs_ = from0_ ? G.Hs0 : G.Hs1;                                  \
+        const float sy_ = from0_ ? G.sy0 : G.sy1;                                                              \
+        const unsigned rowb_ = (unsigned) ((from0_ ? G.Ws0 * G.c0_stride : G.Ws1 * G.c1_stride) * ES);          \
+        const int img_ = G.n * Hs_;                                                                            \
+        unsigned col_[IPR];                                                                                    \
+        if constexpr (!BL) {                                                                                   \
+            _Pragma("unroll") for (int j_ = 0; j_ < IPR; ++j_)                                                 \
+                col_[j_] = coltab[(from0_ ? 0 : IPR * 64) + j_ * 64 + lane];                                   \
+        }                                                                                                      \
         _Pragma("nounroll") for (int q_ = (Q0) + wave; q_ < q1_; q_ += C::NWAVES) {                            \
             if constexpr (BL) {                                                                                \
                 halo_bilinear_store<PITCH>(G, q_, lane, (const unsigned char *) a.src0 + soff_, dstb_ + (q_ << 10)); \
             } else {                                                                                           \
-                int o0_, o1_;                                                                                  \
-                halo_src_offsets<PITCH>(G, q_, lane, o0_, o1_);                                                \
-                const int off_ = from0_ ? o0_ : o1_;                                                           \
-                const unsigned voff_ = off_ >= 0 ? (unsigned) off_ * (unsigned) ES : OOB_LANE;                 \
-                if (from0_) bdma16(rs0, voff_, soff_, dstb_ + (q_ << 10));                                     \
-                else bdma16(rs1, voff_, soff_, dstb_ + (q_ << 10));                                            \
+                const int row_ = q_ / IPR, seg_ = q_ - row_ * IPR;          /* wave-uniform */                 \
+                const int iy_ = G.iy0 + row_ * G.sub;                                                          \
+                const bool ok_ = iy_ >= 0 && iy_ < G.Hin;                                                      \
+                const int ys_ = up_ ? nearest_src(iy_, sy_, Hs_) : iy_;                                        \
+                unsigned v_ = col_[0];                                                                         \
+                _Pragma("unroll") for (int j_ = 1; j_ < IPR; ++j_) v_ = seg_ == j_ ? col_[j_] : v_;           \
+                v_ = ok_ ? v_ : OOB_LANE;          /* rows above / below the image: every lane reads zeros */   \
+                const unsigned s_ = ok_ ? (unsigned) (img_ + ys_) * rowb_ + soff_ : 0u;                        \
+                if (from0_) bdma16(rs0, v_, s_, dstb_ + (q_ << 10));                                           \
+                else bdma16(rs1, v_, s_, dstb_ + (q_ << 10));                                                  \
             }                                                                                                  \
         }                                                                                                      \
     }
@@ -556,6 +573,27 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
 
     ItemState i0{0, 0, 0};                 // first item of the current step
     ItemState i1 = next_item(i0, KH, KW);  // second item of the current step
+
+    // ---- halo DMA source offsets are separable: the per-lane part depends only on the halo COLUMN (instruction q covers
+    // halo row q / IPR, columns (q % IPR) * 16 ..+15: the source column incl. nearest upsampling, the swizzled 16-byte
+    // part, out-of-image -> OOB), the row part is wave-uniform and travels in the scalar offset of the buffer
+    // instruction.  The column parts of both sources live in a small LDS table (2 x IPR x 64 dwords) filled once:
+    // recomputing them per instruction (div / float nearest / bounds, ~50 VALU) cost 6 % of a 3x3 conv and 17 % of
+    // the 64-channel layers (profiles/r02_dma_ablation.txt, HCONTIG vs HCONTIGC).
+    if (!BL) {  // (the 1x1 fast path stages its first tiles through the generic path, too)
+        for (int e = tid; e < 2 * IPR * 64; e += C::THREADS) {
+            const int s = e >= IPR * 64, r = e - s * IPR * 64, ln = r & 63;
+            const int hx = (r >> 6) * 16 + (ln >> 2);
+            const int ix = G.ix0 + hx * G.sub;
+            unsigned v = OOB_LANE;
+            if (hx < G.HWreal && ix >= 0 && ix < G.Win) {
+                const int xs = (s ? G.up1 : G.up0) ? nearest_src(ix, s ? G.sx1 : G.sx0, s ? G.Ws1 : G.Ws0) : ix;
+                v = (unsigned) ((xs * (s ? G.c1_stride : G.c0_stride) + ((ln & 3) ^ ((hx >> 2) & 3)) * EPP) * ES);
+            }
+            coltab[e] = v;
+        }
+        __syncthreads();
+    }
 
     // ---- prologue: stage step 0, open it, stage step 1, first fragment reads
     HALO_DMA(0);
@@ -918,7 +956,7 @@ static size_t lds_bytes(const ConvArgs &a, int TH, int BN) {
     const int nchunks = a.cin_b / 32;
     const size_t halo_buf = (size_t) ((HH * pitch * 4 + 63) / 64) * 1024;
     const int nhb = (a.KH * a.KW == 1) ? 4 : (nchunks > 1 ? 2 : 1);
-    return nhb * halo_buf + 2 * 2 * (size_t) BN * REC;
+    return nhb * halo_buf + 2 * 2 * (size_t) BN * REC + 2 * (size_t) (pitch / 16) * 256;  // + column offset table
 }
 
 // the epilogue's per-wave fp32 staging tiles (32 pixels x (WN*32 channels + pad)) reuse the main-loop LDS
