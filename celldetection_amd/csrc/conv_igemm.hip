@@ -30,6 +30,7 @@
 //     block-diagonal packed weights.
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 
 #include "cpn_kernels.h"
 
@@ -140,7 +141,8 @@ __device__ __forceinline__ void bdma16(rsrc_t rsrc, unsigned lane_off, unsigned 
 }
 
 // pointwise stride 1 / KxK stride 1 / KxK stride 2 / KxK stride 1 whose source is read through a bilinear resize
-enum Mode : int { MODE_PW = 0, MODE_S1 = 1, MODE_S2 = 2, MODE_BL = 3 };
+// MODE_S1R = MODE_S1 with the weight operand loaded from L2 straight into registers (dense KxK, >= 9 taps, 8x256 tile)
+enum Mode : int { MODE_PW = 0, MODE_S1 = 1, MODE_S2 = 2, MODE_BL = 3, MODE_S1R = 4 };
 
 template <int MODE>
 struct ModeCfg {
@@ -303,6 +305,20 @@ __device__ __forceinline__ void load_frags(frag_t (&w)[WN], frag_t (&p)[WM], uns
     }
 }
 
+// pixel fragments only (MODE_S1R: the weight fragments come from global memory)
+template <int WM, int FRAG_STRIDE>
+__device__ __forceinline__ void load_pfrags(frag_t (&p)[WM], unsigned paddr) {
+    static_assert(WM == 4, "register-weight loop: 128-pixel wave tile");
+    ds_read16<0>(p[0], paddr);
+    ds_read16<FRAG_STRIDE>(p[1], paddr);
+    ds_read16<2 * FRAG_STRIDE>(p[2], paddr);
+    ds_read16<3 * FRAG_STRIDE>(p[3], paddr);
+}
+template <int N, int WM>
+__device__ __forceinline__ void wait_pfrags(frag_t (&p)[WM]) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]) : "n"(N));
+}
+
 struct ItemState {  // one K item = (32-channel chunk c, filter tap (ky, kx)); wave-uniform scalars
     int c, ky, kx;
 };
@@ -328,6 +344,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     constexpr int PITCH = ModeCfg<MODE>::PITCH;
     constexpr bool PW = MODE == MODE_PW;
     constexpr bool BL = MODE == MODE_BL;
+    constexpr bool RW = MODE == MODE_S1R;  // weights: global -> registers (no weight tiles in LDS, no per-step barrier)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -471,7 +488,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
 
     // stages the (two) weight slabs of the next step in order into weight buffer BUF
 #define W_DMA(BUF)                                                                                             \
-    {                                                                                                          \
+    if constexpr (!RW) {                                                                                       \
         const unsigned s0_ = wsoff, s1_ = wsoff + item_bytes;                                                  \
         _Pragma("unroll") for (int it = 0; it < C::W_INSTR_WAVE; ++it)                                         \
             bdma16(rsw, w_voff[it], w_k[it] ? s1_ : s0_, smem + w_m0[it] + (BUF) * WBUF);                      \
@@ -656,6 +673,78 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
 #undef MMA8
 #undef CAT8
 #else
+    if constexpr (RW) {
+        // ---- MODE_S1R: weight fragments straight from L2 into registers in MFMA layout (the packed slab rows are the
+        // fragment rows; lane -> row l31 of the 32-row fragment, 16-byte part 2*khalf + lhi, same swizzle as the LDS
+        // tiles).  Four register sets (item 0/1 x k-half 0/1) are refilled for the step after next as soon as their
+        // MFMAs have issued: ~1.75 items of prefetch distance, vmcnt tracked by the compiler.  The LDS holds only
+        // the halo tiles: one third fewer LDS reads, no weight DMA, and the workgroup barrier is needed only twice
+        // per 32-channel chunk (buffer hand-over + tile landed) instead of once per step.
+        frag_t W0a[WN], W0b[WN], W1a[WN], W1b[WN], pA[WM], pB[WM];
+        // (the packed slabs are not swizzled: part p of a row lives at byte 16 p; the XOR swizzle is applied by the DMA path only)
+        const unsigned wl0 = (unsigned) ((wave_n * WN * 32 + l31) * REC + (lhi << 4)), wl1 = wl0 + 32u;
+#define VLOADW(DST, WL, SOFF)                                                                                  \
+    _Pragma("unroll") for (int j = 0; j < WN; ++j)                                                             \
+        DST[j] = __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(rsw, (int) ((WL) + j * 32 * REC), (int) (SOFF), 0))
+#define LOADP(PF, PADDR) load_pfrags<WM, FRAG_STRIDE>(PF, lds0 + (PADDR))
+#define MMAP(WF, PF, PENDING)                                                                                  \
+    {                                                                                                          \
+        wait_pfrags<PENDING, WM>(PF);                                                                          \
+        _Pragma("unroll") for (int j = 0; j < WN; ++j)                                                         \
+            _Pragma("unroll") for (int f = 0; f < WM; ++f) CPN_EXP_MMA(acc[j][f], WF[j], PF[f]);               \
+    }
+        unsigned so = wsoff;  // slab of the first item of the current step
+        VLOADW(W0a, wl0, so); VLOADW(W0b, wl1, so);
+        VLOADW(W1a, wl0, so + item_bytes); VLOADW(W1b, wl1, so + item_bytes);
+        unsigned pa = ITEM_PADDR(i0.c, i0.ky, i0.kx);
+        LOADP(pA, pa);
+        bool land_due = nchunks > 1;  // chunk 1's tile was issued in the prologue
+        for (int st = 0; st + 1 < nsteps; ++st) {
+            so += 2 * item_bytes;
+            LOADP(pB, pa ^ 32u);
+            MMAP(W0a, pA, WM);
+            VLOADW(W0a, wl0, so);
+            pa = ITEM_PADDR(i1.c, i1.ky, i1.kx);
+            LOADP(pA, pa);
+            MMAP(W0b, pB, WM);
+            VLOADW(W0b, wl1, so);
+            LOADP(pB, pa ^ 32u);
+            MMAP(W1a, pA, WM);
+            VLOADW(W1a, wl0, so + item_bytes);
+            const ItemState n0i = next_item(i1, KH, KW);
+            const bool changed = n0i.c != i0.c;
+            if (changed || land_due) {
+                // all my reads of the finished chunk returned; my halo DMA of the previous hand-over (>= 8 weight loads
+                // older than now: VMEM returns in order) landed; after the barrier that holds for every wave
+                wait_pfrags<0, WM>(pB);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                land_due = false;
+                if (changed && n0i.c + 1 < nchunks) {
+                    HALO_DMA(n0i.c + 1);
+                    land_due = true;
+                }
+            }
+            pa = ITEM_PADDR(n0i.c, n0i.ky, n0i.kx);
+            LOADP(pA, pa);
+            MMAP(W1b, pB, WM);
+            VLOADW(W1b, wl1, so + item_bytes);
+            wait_pfrags<0, WM>(pA);
+            i0 = n0i;
+            i1 = next_item(n0i, KH, KW);
+        }
+        LOADP(pB, pa ^ 32u);
+        MMAP(W0a, pA, WM);
+        pa = ITEM_PADDR(i1.c, i1.ky, i1.kx);
+        LOADP(pA, pa);
+        MMAP(W0b, pB, WM);
+        LOADP(pB, pa ^ 32u);
+        MMAP(W1a, pA, WM);
+        MMAP(W1b, pB, 0);
+#undef VLOADW
+#undef LOADP
+#undef MMAP
+    } else {
     frag_t wA[WN], pA[WM], wB[WN], pB[WM];
     constexpr int NF = WN + WM;  // ds_reads per group
     unsigned pa = ITEM_PADDR(i0.c, i0.ky, i0.kx);
@@ -697,6 +786,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     LOAD_GROUP(wB, pB, pa ^ 32u, wa ^ 32u);
     MMA_GROUP(wA, pA, NF);
     MMA_GROUP(wB, pB, 0);
+    }
 #endif
 #undef HALO_DMA
 #undef HALO_DMA_RANGE
@@ -945,7 +1035,11 @@ struct TileChoice {
 static int conv_mode(const ConvArgs &a) {
     if (a.KH == 1 && a.KW == 1 && a.pad == 0) return MODE_PW;  // incl. strided 1x1: the tile gathers only its outputs
     if (a.up0 == 2) return MODE_BL;
-    return a.stride == 2 ? MODE_S2 : MODE_S1;
+    if (a.stride == 2) return MODE_S2;
+    // MODE_S1R is opt-in (CPN_RW=1; read per call so that tests can toggle it): on random operands it runs within 1 % of
+    // the LDS-weight loop (both sit on the same power wall), on all-zero operands 7x7 +8 % / 3x3 -4 %
+    const char *e = getenv("CPN_RW");
+    return (!CPN_FP8 && e && atoi(e) != 0 && a.KH * a.KW >= 9) ? MODE_S1R : MODE_S1;  // (8x256 tile only)
 }
 
 static size_t lds_bytes(const ConvArgs &a, int TH, int BN) {
@@ -992,6 +1086,11 @@ static int launch_cfg(const ConvArgs &a, hipStream_t stream) {
     switch (conv_mode(a)) {
         case MODE_PW: return launch_mode<TH, BN, WM, WN, MODE_PW>(a, stream);
         case MODE_S1: return launch_mode<TH, BN, WM, WN, MODE_S1>(a, stream);
+        case MODE_S1R:
+#if !CPN_FP8
+            if constexpr (TH == 8 && BN == 256 && WM == 4 && WN == 2) return launch_mode<TH, BN, WM, WN, MODE_S1R>(a, stream);
+#endif
+            return launch_mode<TH, BN, WM, WN, MODE_S1>(a, stream);
 #if !CPN_FP8  // bf16 only: the e4m3 kernel has no registers to spare for the in-register blend (it spilled, and ran at
               // 0.16 of its plain rate); fp8 plans keep the separate resize op, which moves half the bytes of a bf16 one
         case MODE_BL: return launch_mode<TH, BN, WM, WN, MODE_BL>(a, stream);

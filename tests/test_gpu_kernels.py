@@ -143,6 +143,10 @@ CONV_CASES = {
     '7x7_head': dict(n=1, h=32, w=64, cin=64, cout=64, k=7),
     '7x7_head_256': dict(n=1, h=32, w=32, cin=256, cout=256, k=7),
     '7x7_stem_s2': dict(n=2, h=64, w=64, cin=3, cout=64, k=7, stride=2, bias=False),
+    # sizes at which the flagship 8x256 tile is what launch_conv selects (see test_conv_register_weight_loop, too)
+    '3x3_256_flagship_tile': dict(n=8, h=128, w=128, cin=64, cout=256, k=3),
+    '3x3_256_flagship_concat_up': dict(n=8, h=128, w=128, cin=32, cout=256, k=3, cin1=64, up1=True, seed=7),
+    'fused_head_256_flagship_tile': dict(n=8, h=128, w=128, cin=96, cout=256, k=7, fuse_cout=20, fuse_act='none', seed=9),
     'fused_head_256': dict(n=1, h=32, w=64, cin=64, cout=256, k=7, fuse_cout=20, fuse_act='none'),
     'fused_head_128_sigmoid': dict(n=2, h=32, w=32, cin=32, cout=128, k=3, fuse_cout=1, fuse_act='sigmoid'),
     'fused_head_64_tanh_th16': dict(n=4, h=256, w=256, cin=64, cout=64, k=7, fuse_cout=2, fuse_act='tanh_scaled', seed=5),
@@ -173,6 +177,24 @@ def test_conv(dev, name):
     allowed = int(1e-4 * err.numel()) if name.startswith('fused_head') else 0
     assert bad <= allowed and err.max().item() < (5e-2 * max(scale, 1.) if allowed else float('inf')), \
         f'{name}: {bad} / {err.numel()} elements off; max abs err {err.max().item():.4e}, ref max {scale:.3e}'
+
+
+FLAGSHIP_CASES = ['3x3_256_flagship_tile', '3x3_256_flagship_concat_up', 'fused_head_256_flagship_tile']
+
+
+@pytest.mark.parametrize('name', FLAGSHIP_CASES)
+def test_conv_register_weight_loop(dev, name, monkeypatch):
+    """CPN_RW=1 selects MODE_S1R (weight fragments from L2 straight into registers, no weight tiles in LDS, two
+    barriers per chunk) for dense KxK convs on the 8x256 tile.  Same K order and MFMA sequence as the LDS-weight loop:
+    the outputs must be bit-identical, and both within the usual tolerance of the fp32 reference."""
+    monkeypatch.setenv('CPN_RW', '0')
+    lds, ref, f32 = run_conv(dev, **CONV_CASES[name])
+    monkeypatch.setenv('CPN_RW', '1')
+    rw, _, _ = run_conv(dev, **CONV_CASES[name])
+    assert torch.equal(rw, lds), f'{name}: register-weight loop differs from the LDS-weight loop ' \
+                                 f'(max abs {(rw - lds).abs().max().item():.3e})'
+    scale = max(ref.abs().max().item(), 1.)
+    assert (rw - ref).abs().max().item() < 5e-2 * scale
 
 
 def test_maxpool_bilinear_input(dev):
