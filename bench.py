@@ -284,7 +284,7 @@ def main():
     ev = []  # HIP events around every conv-graph execution (the dominant kernel family), on its launch stream
     t0 = time.perf_counter()
     if not args.pipeline:
-        for i in range(args.steps):
+        for _ in range(args.steps):
             y = run_step(ev)
     else:
         # throughput mode of the tile loop: conv graph of step i+1 enqueued before the post-processing of step i

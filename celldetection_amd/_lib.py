@@ -5,7 +5,7 @@ importing the binding raises, and every op raises ``RuntimeError`` on failure wi
 """
 import ctypes
 import os
-from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_uint8, c_void_p)
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_void_p)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CPN_HIP_LIB') or os.path.join(HERE, 'libcpn_hip.so')  # env: kernel A/B tuning only

@@ -14,7 +14,6 @@ from ctypes import c_void_p
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import _lib, graph, ops
 
@@ -130,7 +129,7 @@ class _Engine:
     def run(self, x: torch.Tensor, order_total: int, refinement: bool, _timed=None, _absmax=None):
         """x: [N,C,H,W] float32 in [0,1] (or uint8) on self.device -> (scores, locations, refinement, fourier, flag)."""
         lib = _lib.load()
-        n, c, h, w = x.shape
+        n, _, h, w = x.shape
         if x.dtype == torch.uint8:
             dt = 1
         else:

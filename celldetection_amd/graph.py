@@ -13,9 +13,7 @@ Reference structures mirrored (file:line relative to the reference repository):
   ReadOut heads / CPNCore     celldetection/models/commons.py:461-511, celldetection/models/cpn.py:126-283
 """
 import math
-from collections import OrderedDict
 
-import numpy as np
 import torch
 
 from . import _lib

@@ -12,7 +12,7 @@ import ctypes.util
 import glob
 import json
 import os
-from ctypes import POINTER, byref, c_char_p, c_int, c_int64, c_size_t, c_uint, c_uint64, c_void_p
+from ctypes import POINTER, c_char_p, c_int, c_int64, c_size_t, c_uint, c_uint64, c_void_p
 
 import numpy as np
 

@@ -198,7 +198,7 @@ def tiled_inference(model, img: torch.Tensor, crop_size=(1024, 1024), strides=(7
     else:
         results = (_lists_to_flat(forward_fn(t, kw.pop('offsets'), **kw), dev) for t, kw in batches())
     pending = []  # (flat tensors of a batch, keep mask): rows are selected once, after the loop
-    for flat, counts in results:
+    for flat, _ in results:
         idxs, offs, size = meta.pop(0)
         samples, order = flat['contours'].shape[1], flat['fourier'].shape[1]
         if flat['scores'].shape[0] == 0:
@@ -306,7 +306,7 @@ def forward_tiled(model, inputs: torch.Tensor, crop_size=1024, stride=512, borde
     # like tiled_inference: all detections of a forwarded batch are filtered by ONE border-rule launch, rows are
     # selected once per image at the end
     pending = []
-    for flat, counts in model.forward_pipelined(batches(), flat_output=True):
+    for flat, _ in model.forward_pipelined(batches(), flat_output=True):
         chunk, offs, size = meta.pop(0)
         if flat['scores'].shape[0] == 0:
             continue

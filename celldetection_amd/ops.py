@@ -340,7 +340,7 @@ def gather_channels(maps: Tensor, indices: Tensor):
     """maps [N,C,h,w] fp32, indices int32 [P] (linear (b,y,x) pixel indices of ``compact_scores``) -> [P,C]."""
     _need_cuda(maps, indices)
     m = maps.contiguous().float()
-    N, C, h, w = m.shape
+    _, C, h, w = m.shape
     P = int(indices.shape[0])
     out = torch.empty((P, C), dtype=torch.float32, device=m.device)
     check(_lib.load().cpn_gather_channels(ptr(m), ptr(indices.contiguous()), P, C, h, w, ptr(out), stream_ptr()),
