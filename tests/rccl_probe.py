@@ -4,7 +4,6 @@ distributed code path, and compares with the non-distributed result."""
 import os
 import sys
 
-import numpy as np
 import torch
 import torch.distributed as td
 

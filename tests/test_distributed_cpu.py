@@ -6,7 +6,6 @@ import socket
 from collections import OrderedDict
 
 import numpy as np
-import pytest
 import torch
 import torch.multiprocessing as mp
 

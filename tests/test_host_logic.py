@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 import celldetection_amd as cda
 from celldetection_amd import _lib, graph
-from model_specs import ALL_SPECS, MODEL_SPECS, ref_template_state_dict
+from model_specs import ALL_SPECS, ref_template_state_dict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, 'tests', 'golden')

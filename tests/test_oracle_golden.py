@@ -8,7 +8,7 @@ import torch
 
 import cpn_oracle as orc
 from celldetection_amd.synth import synth_state_dict
-from model_specs import ALL_SPECS, HEAD_SPECS, MODEL_SPECS, SIZE_SPECS, VARIANT_SPECS, ref_template_state_dict
+from model_specs import HEAD_SPECS, MODEL_SPECS, SIZE_SPECS, VARIANT_SPECS, ref_template_state_dict
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 

@@ -1,5 +1,4 @@
 """``torch.library`` registration of the HIP ops (BASELINE north_star: "PyTorch-ROCm custom ops over a thin C ABI")."""
-import numpy as np
 import pytest
 import torch
 
