@@ -205,6 +205,9 @@ def main():
                          'enqueued before the post-processing of step i; all work of the K steps completes inside the timed region')
     ap.add_argument('--no-pipeline', dest='pipeline', action='store_false', help='synchronous forward() per step')
     ap.add_argument('--profile-layers', action='store_true', help='print per-op timings to stderr')
+    ap.add_argument('--sparse-heads', action='store_true',
+                    help='EXPERIMENTAL (not validated on hardware yet): score-gated location / Fourier heads -- evaluated at the '
+                         'proposal pixels only, identical outputs (csrc/sparse_heads.hip); bf16 only')
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 30 if args.workload == 'tiles' else 1
@@ -256,6 +259,10 @@ def main():
         model.precision = 'fp8'
         model.calibrate_fp8(x[:2])  # static activation scales from a bf16 run on two tiles
 
+    if args.sparse_heads:
+        if args.precision != 'bf16':
+            raise SystemExit('--sparse-heads: bf16 only')
+        model.sparse_heads = True
     eng = model.engine(dev)  # pack the weights / create the native plan now (set-up, not a step), also when --warmup 0
     state = {}
 
@@ -267,7 +274,8 @@ def main():
         state['maps'] = model.core_forward(x)
         e1.record()
         events.append((e0, e1))
-        state['y'] = model.postprocess(*state['maps'], (args.tile, args.tile), flag=model._last_flag)
+        state['y'] = model.postprocess(*state['maps'], (args.tile, args.tile), flag=model._last_flag,
+                                       sparse=model._last_sparse)
         return state['y']
 
     for _ in range(args.warmup):
@@ -358,7 +366,7 @@ def main():
         executed = eng.executed_flops(args.batch, args.tile, args.tile) / 1e9
         traffic, traffic_src = load_traffic(args.model, args.batch, args.tile, args.precision)
         ndet = sum(len(s) for s in y['scores'])
-        n_launch = sum(1 for op in eng.plan.ops if op['op'] == 'conv')
+        n_launch = sum(1 for op in eng.plan.ops if op['op'] == 'conv' and not op.get('deferred'))
         out = {
             'metric': f'tiles/sec (3x{args.tile}x{args.tile}) {args.model}', 'value': value, 'unit': 'tiles/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
@@ -371,7 +379,9 @@ def main():
                        'world_size_seen_by_rccl': world,
                        'parallelism': f'tile-sharded x{world}, one process per GPU, no data-path collective',
                        'step_mode': 'forward() per step' if not args.pipeline else
-                       'forward_pipelined(): post-processing of step i overlaps the conv graph of step i+1'},
+                       'forward_pipelined(): post-processing of step i overlaps the conv graph of step i+1',
+                       'heads': 'score-gated location / Fourier heads (exact; evaluated at the proposals only, outside the '
+                                'HIP-event bracket of the conv graph)' if args.sparse_heads else 'dense (reference graph)'},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
                          'traffic': traffic, 'traffic_source': traffic_src,
                          'kernel': f'conv_igemm_kernel: one conv-graph execution = {n_launch} launches of the kernel family '

@@ -10,11 +10,11 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CPN_HIP_LIB') or os.path.join(HERE, 'libcpn_hip.so')  # env: kernel A/B tuning only
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 PRECISION_BF16, PRECISION_F32, PRECISION_FP8 = 0, 1, 2
 E_INVALID, E_UNSUPPORTED, E_WORKSPACE = -1, -2, -3
 
-OP_INPUT, OP_CONV, OP_MAXPOOL, OP_BILINEAR = 0, 1, 2, 3
+OP_INPUT, OP_CONV, OP_MAXPOOL, OP_BILINEAR, OP_CONV_DEFERRED = 0, 1, 2, 3, 4
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH_SCALED = 0, 1, 2, 3
 OUT_SCORES, OUT_LOCATIONS, OUT_FOURIER, OUT_REFINEMENT, OUT_UNCERTAINTY = 0, 1, 2, 3, 4
 NUM_OUTPUTS = 5
@@ -72,6 +72,14 @@ _SIGNATURES = [
                                   c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int32, c_void_p, c_void_p, c_void_p]),
+    ('cpn_decode_gathered', ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                           c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_int32, c_void_p, c_void_p, c_void_p]),
+    ('cpn_sparse_heads', ctypes.c_int, [POINTER(OpDesc), POINTER(OpDesc), c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                        c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ('cpn_plan_tensor_info', ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, POINTER(c_int64),
+                                            POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
     ('cpn_fouriers2contours', ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                              c_void_p, c_void_p]),
     ('cpn_local_refinement', ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32,

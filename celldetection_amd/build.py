@@ -25,6 +25,7 @@ SOURCES = {
     'decode_nms.hip': ['-ffp-contract=off'],
     'nms_binned.hip': ['-ffp-contract=off'],
     'labels.hip': [],
+    'sparse_heads.hip': [],
     'cpn_abi.hip': [],
 }
 HEADERS = ['cpn_kernels.h', 'cpn_error.h', 'conv_igemm.hip', os.path.join('..', '..', 'include', 'cpn_hip.h')]

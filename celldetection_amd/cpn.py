@@ -78,6 +78,10 @@ class _Engine:
         self.handle = handle
         self.plan = plan
         self._ws = None
+        self.sparse_requested = False
+        self.sparse = plan.meta.get('sparse_heads') if precision == 'bf16' else None  # dict(ops=(i, j), src=tensor id)
+        self._ws_ring, self._ws_turn = [None, None], 0
+        self.last_sparse = None
 
     def __del__(self):
         handle, self.handle = getattr(self, 'handle', None), None
@@ -91,6 +95,12 @@ class _Engine:
         need = int(_lib.load().cpn_plan_workspace_bytes(self.handle, n, h, w))
         if need < 0:
             _lib.check(need, 'plan_workspace_bytes')
+        if self.sparse:  # the head source of run i is read by the post-processing of run i while run i+1 may already be
+            self._ws_turn ^= 1  # enqueued (forward_pipelined): two arenas in turn
+            ws = self._ws_ring[self._ws_turn]
+            if ws is None or ws.numel() < need:
+                ws = self._ws_ring[self._ws_turn] = torch.empty(need, dtype=torch.uint8, device=self.device)
+            return ws, need
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
@@ -141,8 +151,11 @@ class _Engine:
         meta = self.plan.meta
         # head grids: any H x W (sizes propagated by the executor; heads may read different features / use a stride)
         scores = torch.empty((n, meta.get('score_channels', 1)) + self.output_size(h, w, _lib.OUT_SCORES), **f32)
-        locations = torch.empty((n, 2) + self.output_size(h, w, _lib.OUT_LOCATIONS), **f32)
-        fourier = torch.empty((n, 4 * order_total) + self.output_size(h, w, _lib.OUT_FOURIER), **f32)
+        gated = bool(self.sparse) and _timed is None and _absmax is None
+        if self.sparse and not gated:
+            raise NotImplementedError('per-op profiling / calibration runs need a plan without score-gated heads')
+        locations = None if gated else torch.empty((n, 2) + self.output_size(h, w, _lib.OUT_LOCATIONS), **f32)
+        fourier = None if gated else torch.empty((n, 4 * order_total) + self.output_size(h, w, _lib.OUT_FOURIER), **f32)
         ref = torch.empty((n, 2 * meta.get('refinement_buckets', 1)) + self.output_size(h, w, _lib.OUT_REFINEMENT),
                           **f32) if refinement else None
         self.last_uncertainty = torch.empty((n, 4) + self.output_size(h, w, _lib.OUT_UNCERTAINTY), **f32) \
@@ -157,6 +170,9 @@ class _Engine:
         nb = max(1, min(n, limit // per_image))
         if _timed is not None and nb < n:
             raise ValueError('per-op profiling needs a batch whose tensors stay below 2^31 elements')
+        if gated and nb < n:
+            raise NotImplementedError('score-gated heads need the whole batch in one graph run (tensors below 2^31 bytes): '
+                                      'forward a smaller batch or set model.sparse_heads = False')
         ws, need = self.workspace(nb, h, w)
         outputs = (scores, locations, fourier, ref, self.last_uncertainty)
         for i0 in range(0, n, nb):
@@ -176,6 +192,16 @@ class _Engine:
                                             _lib.ptr(flag), _lib.stream_ptr()), 'plan_run')
         if ref is not None and tuple(ref.shape[2:]) != (h, w):  # strided refinement head: `_equal_size(.., inputs)`, cpn.py:279
             ref = _equal_size(ref, x)
+        self.last_sparse = None
+        if gated:  # where the heads' source tensor lives in this run's arena (it stays intact until the arena's next turn)
+            from ctypes import c_int32, c_int64
+            off, th, tw, cs = c_int64(0), c_int32(0), c_int32(0), c_int32(0)
+            _lib.check(lib.cpn_plan_tensor_info(self.handle, n, h, w, int(self.sparse['src']), off, th, tw, cs),
+                       'plan_tensor_info')
+            ia, ib = self.sparse['ops']
+            self.last_sparse = dict(ws=ws, features_ptr=ws.data_ptr() + int(off.value), grid=(n, int(th.value), int(tw.value)),
+                                    channel_stride=int(cs.value), op_a=self.ops_desc[ia], op_b=self.ops_desc[ib],
+                                    weights=self.wblob, bias=self.bblob, order_total=order_total)
         return scores, locations, ref, fourier, flag
 
 
@@ -242,6 +268,10 @@ class CPN(nn.Module):
         # weights on the K=64 scaled MFMA, 2x the bf16 rate; static activation scales from ``calibrate_fp8`` or, if
         # that was not called, from the first batch that is forwarded)
         self.precision = 'bf16'
+        # score-gated location / Fourier heads (bf16 only; csrc/sparse_heads.hip): the two heads are evaluated at the
+        # proposal pixels only -- CPN.forward reads nothing else of their maps (cpn.py:613-637); outputs are identical.
+        # Opt-in (EXPERIMENTAL until validated on hardware): set ``model.sparse_heads = True``
+        self.sparse_heads = False
         self._fp8_scales = None
         self._plan = graph.build_plan(**self._plan_kwargs)  # bf16: fused ReadOut tails + fused bilinear head source
         self._alt_plans = {}
@@ -285,8 +315,12 @@ class CPN(nn.Module):
         """Layer plan per precision: bf16 fuses the ReadOut tails and the bilinear resize in front of the refinement head;
         fp8 keeps that resize as its own op (on e4m3 codes; also the plan its bf16 calibration run uses, so that the
         tensor ids of the activation scales match); fp32 (verification) fuses nothing."""
-        if precision == 'bf16':
+        if precision == 'bf16' and not self.sparse_heads:
             return self._plan
+        if precision == 'bf16':  # score-gated heads: same entries / weights, the two head convs are deferred ops
+            if 'bf16+sparse' not in self._alt_plans:
+                self._alt_plans['bf16+sparse'] = graph.build_plan(**self._plan_kwargs, sparse_heads=True)
+            return self._alt_plans['bf16+sparse']
         if precision not in self._alt_plans:
             extra = dict(fuse_bilinear=False) if precision == 'fp8' else dict(fuse_readout=False, fuse_bilinear=False)
             self._alt_plans[precision] = graph.build_plan(**self._plan_kwargs, **extra)
@@ -299,7 +333,9 @@ class CPN(nn.Module):
                                'There is no CPU fallback in the product path.')
         if self.precision not in ('bf16', 'fp32', 'fp8'):
             raise ValueError("precision must be 'bf16', 'fp32' or 'fp8'")
-        if self._engine is None or self._engine.device != device or self._engine.precision != self.precision:
+        sparse = bool(self.sparse_heads) and self.precision == 'bf16'
+        if self._engine is None or self._engine.device != device or self._engine.precision != self.precision or \
+                self._engine.sparse_requested != sparse:
             if self.precision == 'fp8':
                 if self._fp8_scales is None:
                     if calibration_input is None:
@@ -312,6 +348,7 @@ class CPN(nn.Module):
                 self._engine = _Engine(self.plan_for('fp8'), self.state_dict(), device, 'fp8', act_scales=self._fp8_scales)
             else:
                 self._engine = _Engine(self.plan_for(self.precision), self.state_dict(), device, self.precision)
+            self._engine.sparse_requested = sparse
         return self._engine
 
     @torch.no_grad()
@@ -340,6 +377,7 @@ class CPN(nn.Module):
         scores, locations, refinement, fourier, flag = eng.run(inputs, self.core.order, self.refinement)
         self._last_flag = flag
         self._last_uncertainty = eng.last_uncertainty  # fifth CPNCore output (cpn.py:283), [N,4,h,w] or None
+        self._last_sparse = eng.last_sparse  # score-gated heads: locations / fourier are None, evaluated in postprocess
         return scores, locations, refinement, fourier
 
     @torch.no_grad()
@@ -351,7 +389,7 @@ class CPN(nn.Module):
         original_size = tuple(inputs.shape[-2:])
         scores, locations, refinement, fourier = self.core_forward(inputs)
         return self.postprocess(scores, locations, refinement, fourier, original_size, nms=nms, flag=self._last_flag,
-                                uncertainty=self._last_uncertainty, **kwargs)
+                                uncertainty=self._last_uncertainty, sparse=self._last_sparse, **kwargs)
 
     @torch.no_grad()
     def forward_pipelined(self, batches, nms=True, _events=None, **kwargs):
@@ -365,14 +403,17 @@ class CPN(nn.Module):
         s_conv, s_post = self._streams(dev)
         caller = torch.cuda.current_stream(dev)
         pending = None
+        post_done = [None]  # event after the most recent post-processing (score-gated heads: arena hand-back)
 
         def finish(item):
-            maps, unc, flag, size, kw, ev = item
+            maps, unc, flag, size, kw, ev, sparse = item
             with torch.cuda.stream(s_post):
                 s_post.wait_event(ev)
-                out = self.postprocess(*maps, size, nms=nms, flag=flag, uncertainty=unc, **dict(kwargs, **kw))
+                out = self.postprocess(*maps, size, nms=nms, flag=flag, uncertainty=unc, sparse=sparse,
+                                       **dict(kwargs, **kw))
                 done = torch.cuda.Event()
                 done.record(s_post)
+            post_done[0] = done
             caller.wait_event(done)  # the caller's stream may consume the outputs
             if isinstance(out, tuple):  # flat_output: (dict of flat tensors, per-image counts)
                 for t in out[0].values():
@@ -388,6 +429,10 @@ class CPN(nn.Module):
             if not x.is_cuda:
                 raise RuntimeError('celldetection_amd.CPN.forward needs GPU inputs (no CPU fallback).')
             s_conv.wait_stream(caller)  # x was produced on the caller's stream
+            if self.sparse_heads and post_done[0] is not None:
+                # score-gated heads: this run re-uses the arena of the run before the previous one, whose head source
+                # was read by that batch's post-processing (finished before post_done[0] was recorded)
+                s_conv.wait_event(post_done[0])
             with torch.cuda.stream(s_conv):
                 if _events is not None:  # (start, end) HIP events around the conv graph, on its launch stream
                     e0 = torch.cuda.Event(enable_timing=True)
@@ -400,8 +445,10 @@ class CPN(nn.Module):
                 for t in maps + (self._last_uncertainty, self._last_flag):
                     if t is not None:
                         t.record_stream(s_post)
+                if self._last_sparse is not None:  # the arena holding the heads' source is read on the post stream
+                    self._last_sparse['ws'].record_stream(s_post)
                 x.record_stream(s_conv)
-            cur = (maps, self._last_uncertainty, self._last_flag, tuple(x.shape[-2:]), kw, ev)
+            cur = (maps, self._last_uncertainty, self._last_flag, tuple(x.shape[-2:]), kw, ev, self._last_sparse)
             if pending is not None:
                 yield finish(pending)
             pending = cur
@@ -421,7 +468,7 @@ class CPN(nn.Module):
 
     @torch.no_grad()
     def postprocess(self, scores, locations, refinement, fourier, original_size, nms=True, flag=None,
-                    uncertainty=None, flat_output=False, **kwargs):
+                    uncertainty=None, flat_output=False, sparse=None, **kwargs):
         """CPN.forward after the core (cpn.py:575-734) on given head maps: ``scores`` [N,1,h,w] probabilities (sigmoid
         already applied; binary CPNs) or [N,classes,h,w] raw logits (multi-class, cpn.py:583-585); locations [N,2,h,w];
         refinement [N,2*buckets,H,W] or None; fourier [N,4*O,h,w]; uncertainty [N,4,h,w] or None (cpn.py:209-221).
@@ -452,9 +499,19 @@ class CPN(nn.Module):
         if flag_v:
             raise AssertionError('Inputs should be in interval (0.0, 1.0)')  # models/commons.py:696-697
         iters = self.refinement_iterations if (self.refinement and refinement is not None) else 0
+        gathered = locations is None
+        if gathered:  # score-gated heads: location / Fourier head values of the proposals only (ops.sparse_heads)
+            if sparse is None:
+                raise ValueError('postprocess: locations / fourier maps are missing and no score-gated head context given')
+            locations, fourier = ops.sparse_heads(sparse['op_a'], sparse['op_b'], sparse['features_ptr'],
+                                                  sparse['channel_stride'], sparse['grid'], indices, sparse['weights'],
+                                                  sparse['bias'])
+            if tuple(sparse['grid'][1:]) != tuple(scores.shape[-2:]):
+                raise RuntimeError('score-gated heads: head grid and score grid differ')
         flat = ops.decode_proposals(indices, scores, locations, fourier, refinement if iters > 0 else None,
                                     size=original_size, order=order, samples=self.samples, iterations=iters,
-                                    offsets=kwargs.get('offsets'), num_buckets=self.core.refinement_buckets)
+                                    offsets=kwargs.get('offsets'), num_buckets=self.core.refinement_buckets,
+                                    gathered=gathered)
         offs = [0]
         for c in counts:
             offs.append(offs[-1] + c)

@@ -83,7 +83,8 @@ static void propagate_dims(const cpn_plan *p, int H, int W, ShapePlan &sp) {
                 if (sp.th[o.src0] + 2 * o.pad < o.kh || sp.tw[o.src0] + 2 * o.pad < o.kw) bad("input too small for the max-pool");
                 break;
             case CPN_OP_BILINEAR: sp.th[o.dst] = H; sp.tw[o.dst] = W; break;
-            case CPN_OP_CONV: {
+            case CPN_OP_CONV:
+            case CPN_OP_CONV_DEFERRED: {
                 int hv, wv;
                 if (o.up0 && o.up1) { bad("conv: both sources resized"); break; }
                 if (o.up0 == 2) { hv = H; wv = W; }  // bilinear resize of the source to the INPUT size (cpn.py:277-278)
@@ -129,8 +130,10 @@ static const ShapePlan &get_shape_plan(cpn_plan *p, int N, int H, int W) {
     for (int i = 0; i < (int) p->ops.size(); ++i) {
         const cpn_op_desc &o = p->ops[i];
         if (o.dst >= 0 && def[root[o.dst]] < 0) def[root[o.dst]] = i;
+        // (the sources of a deferred conv are read after the run, cpn_sparse_heads: they stay live to the end)
+        const int use = o.op == CPN_OP_CONV_DEFERRED ? (int) p->ops.size() : i;
         for (int s_ : {o.src0, o.src1, o.res})
-            if (s_ >= 0) last[root[s_]] = std::max(last[root[s_]], i);
+            if (s_ >= 0) last[root[s_]] = std::max(last[root[s_]], use);
         if (o.dst >= 0) last[root[o.dst]] = std::max(last[root[o.dst]], i);
     }
     std::vector<int> order;
@@ -271,7 +274,11 @@ int cpn_plan_create(cpn_plan **plan, const cpn_tensor_desc *tensors, int32_t n_t
                 delete p;
                 return fail(CPN_E_INVALID, "cpn_plan_create: tensor id out of range");
             }
-        if (o.op == CPN_OP_CONV) {
+        if (o.op == CPN_OP_CONV_DEFERRED && (precision != CPN_PRECISION_BF16 || o.fuse_cout <= 0 || o.dst >= 0)) {
+            delete p;
+            return fail(CPN_E_INVALID, "cpn_plan_create: a deferred conv must be a fused ReadOut head of a bf16 plan");
+        }
+        if (o.op == CPN_OP_CONV || o.op == CPN_OP_CONV_DEFERRED) {
             size_t wbytes = (size_t) o.bundles * o.cin_b * o.kh * o.kw * o.cout_b * 4;  // fp32 verification layout
             if (precision == CPN_PRECISION_BF16) {  // [bundle][items (+1 zero slab if odd)][cout_b][32] bf16
                 const size_t items = (size_t) (o.cin_b / 32) * o.kh * o.kw;
@@ -319,6 +326,21 @@ int cpn_plan_output_dims(cpn_plan *plan, int32_t H, int32_t W, int32_t out_index
     if (sp.error) return fail(sp.error, sp.message.c_str());
     *h = sp.out_h[out_index];
     *w = sp.out_w[out_index];
+    return 0;
+}
+
+int cpn_plan_tensor_info(cpn_plan *plan, int32_t N, int32_t H, int32_t W, int32_t tensor, int64_t *byte_offset,
+                         int32_t *h, int32_t *w, int32_t *channel_stride) {
+    if (!plan || N <= 0 || H <= 0 || W <= 0 || tensor < 0 || tensor >= (int) plan->tensors.size() || !byte_offset || !h ||
+        !w || !channel_stride)
+        return fail(CPN_E_INVALID, "cpn_plan_tensor_info: bad arguments");
+    const ShapePlan &sp = get_shape_plan(plan, N, H, W);
+    if (sp.error) return fail(sp.error, sp.message.c_str());
+    if (sp.offsets[tensor] < 0) return fail(CPN_E_INVALID, "cpn_plan_tensor_info: the tensor is never written");
+    *byte_offset = sp.offsets[tensor];
+    *h = sp.th[tensor];
+    *w = sp.tw[tensor];
+    *channel_stride = plan->tensors[tensor].channels;
     return 0;
 }
 
@@ -375,6 +397,7 @@ static int run_or_count(cpn_plan *plan, const void *input, int32_t in_dtype, int
                                                                                    : launch_bilinear(a, st)), "bilinear kernel");
                 break;
             }
+            case CPN_OP_CONV_DEFERRED: break;  // evaluated at the proposal pixels only (cpn_sparse_heads)
             case CPN_OP_CONV: {
                 int Hin, Win;  // virtual input size (see propagate_dims)
                 if (o.up0 == 2) { Hin = H; Win = W; }

@@ -165,6 +165,9 @@ struct DecodeArgs {
     Buckets bk;
 };
 
+// GATHERED: locations [P,2] / fourier [P,4*order_total] hold the head values of proposal p (cpn_sparse_heads) instead of
+// dense NCHW maps
+template <bool GATHERED>
 __global__ __launch_bounds__(DWAVES *WAVE) void decode_kernel(const DecodeArgs a) {
     __shared__ float coef_s[DWAVES][MAX_COEF];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -180,14 +183,15 @@ __global__ __launch_bounds__(DWAVES *WAVE) void decode_kernel(const DecodeArgs a
         y = rem / a.w;
         x = rem - y * a.w;
         for (int i = lane; i < a.order * 4; i += 64)
-            coef[i] = a.fourier[((size_t) b * a.order_total * 4 + i) * hw + (size_t) y * a.w + x];
+            coef[i] = GATHERED ? a.fourier[(size_t) p * a.order_total * 4 + i]
+                               : a.fourier[((size_t) b * a.order_total * 4 + i) * hw + (size_t) y * a.w + x];
     }
     __syncthreads();
     if (!active) return;
     const size_t pos = (size_t) y * a.w + x;
     // rel_location2abs_location, ops/cpn.py:15-41
-    const float lx = __fadd_rn(a.locations[((size_t) b * 2 + 0) * hw + pos], (float) x);
-    const float ly = __fadd_rn(a.locations[((size_t) b * 2 + 1) * hw + pos], (float) y);
+    const float lx = __fadd_rn(GATHERED ? a.locations[(size_t) p * 2] : a.locations[((size_t) b * 2 + 0) * hw + pos], (float) x);
+    const float ly = __fadd_rn(GATHERED ? a.locations[(size_t) p * 2 + 1] : a.locations[((size_t) b * 2 + 1) * hw + pos], (float) y);
     const float sx = (float) a.W / (float) a.w, sy = (float) a.H / (float) a.h;  // get_scale, ops/cpn.py:98-103
     float offx = 0.f, offy = 0.f;
     if (a.offsets) {
@@ -617,12 +621,12 @@ int cpn_compact(const float *scores, int32_t N, int32_t h, int32_t w, float thre
     return cpn::check_hip(hipGetLastError(), "cpn_compact");
 }
 
-int cpn_decode(const int32_t *indices, int32_t P, const float *scores, const float *locations, const float *fourier,
-               const float *refinement, int32_t N, int32_t h, int32_t w, int32_t H, int32_t W, int32_t order_total,
-               int32_t order, int32_t samples, int32_t iterations, const float *cos_table, const float *sin_table,
-               const float *offsets, float *contours, float *proposals, float *boxes, float *out_scores,
-               float *out_locations, float *out_fourier, int32_t *batch_index, int32_t buckets,
-               const int32_t *bucket_index, const float *bucket_weight, void *stream) {
+static int decode_impl(bool gathered, const int32_t *indices, int32_t P, const float *scores, const float *locations,
+                       const float *fourier, const float *refinement, int32_t N, int32_t h, int32_t w, int32_t H, int32_t W,
+                       int32_t order_total, int32_t order, int32_t samples, int32_t iterations, const float *cos_table,
+                       const float *sin_table, const float *offsets, float *contours, float *proposals, float *boxes,
+                       float *out_scores, float *out_locations, float *out_fourier, int32_t *batch_index, int32_t buckets,
+                       const int32_t *bucket_index, const float *bucket_weight, void *stream) {
     if (P < 0 || order < 1 || order > order_total || order * 4 > MAX_COEF || samples < 1)
         return cpn::fail(CPN_E_INVALID, "cpn_decode: bad arguments (need 1 <= order <= min(order_total, 64))");
     if (buckets > 1 && refinement && iterations > 0 && (!bucket_index || !bucket_weight))
@@ -633,8 +637,34 @@ int cpn_decode(const int32_t *indices, int32_t P, const float *scores, const flo
     DecodeArgs a{indices, P, scores, locations, fourier, refinement, N, h, w, H, W, order_total, order, samples,
                  iterations, cos_table, sin_table, offsets, contours, proposals, boxes, out_scores, out_locations,
                  out_fourier, batch_index, Buckets{buckets, bucket_index, bucket_weight, samples}};
-    hipLaunchKernelGGL(decode_kernel, dim3((P + DWAVES - 1) / DWAVES), dim3(DWAVES * WAVE), 0, (hipStream_t) stream, a);
+    if (gathered)
+        hipLaunchKernelGGL(decode_kernel<true>, dim3((P + DWAVES - 1) / DWAVES), dim3(DWAVES * WAVE), 0, (hipStream_t) stream, a);
+    else
+        hipLaunchKernelGGL(decode_kernel<false>, dim3((P + DWAVES - 1) / DWAVES), dim3(DWAVES * WAVE), 0, (hipStream_t) stream, a);
     return cpn::check_hip(hipGetLastError(), "cpn_decode");
+}
+
+int cpn_decode(const int32_t *indices, int32_t P, const float *scores, const float *locations, const float *fourier,
+               const float *refinement, int32_t N, int32_t h, int32_t w, int32_t H, int32_t W, int32_t order_total,
+               int32_t order, int32_t samples, int32_t iterations, const float *cos_table, const float *sin_table,
+               const float *offsets, float *contours, float *proposals, float *boxes, float *out_scores,
+               float *out_locations, float *out_fourier, int32_t *batch_index, int32_t buckets,
+               const int32_t *bucket_index, const float *bucket_weight, void *stream) {
+    return decode_impl(false, indices, P, scores, locations, fourier, refinement, N, h, w, H, W, order_total, order, samples,
+                       iterations, cos_table, sin_table, offsets, contours, proposals, boxes, out_scores, out_locations,
+                       out_fourier, batch_index, buckets, bucket_index, bucket_weight, stream);
+}
+
+int cpn_decode_gathered(const int32_t *indices, int32_t P, const float *scores, const float *locations,
+                        const float *fourier, const float *refinement, int32_t N, int32_t h, int32_t w, int32_t H,
+                        int32_t W, int32_t order_total, int32_t order, int32_t samples, int32_t iterations,
+                        const float *cos_table, const float *sin_table, const float *offsets, float *contours,
+                        float *proposals, float *boxes, float *out_scores, float *out_locations, float *out_fourier,
+                        int32_t *batch_index, int32_t buckets, const int32_t *bucket_index, const float *bucket_weight,
+                        void *stream) {
+    return decode_impl(true, indices, P, scores, locations, fourier, refinement, N, h, w, H, W, order_total, order, samples,
+                       iterations, cos_table, sin_table, offsets, contours, proposals, boxes, out_scores, out_locations,
+                       out_fourier, batch_index, buckets, bucket_index, bucket_weight, stream);
 }
 
 int cpn_fouriers2contours(const float *fourier, const float *locations, int32_t P, int32_t order, int32_t samples,

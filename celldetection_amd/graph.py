@@ -49,7 +49,7 @@ class Plan:
         return len(self.tensors) - 1
 
     def conv(self, src0, cout, k, *, w, bn=None, bias=False, stride=1, pad=None, groups=1, act='none', act_scale=0.,
-             src1=None, up0=False, up1=False, res=None, res_up=False, out_index=None, fuse=None):
+             src1=None, up0=False, up1=False, res=None, res_up=False, out_index=None, fuse=None, deferred=False):
         """Adds conv(+BN)(+residual)(+act); returns the destination tensor id (None for external outputs)."""
         pad = k // 2 if pad is None else pad
         t0 = self.tensors[src0]
@@ -71,7 +71,7 @@ class Plan:
             self.conv_keys(fuse['w'], fuse['cout'], cout, 1, True)
         self.ops.append(dict(op='conv', src0=src0, src1=src1, res=res, dst=dst, up0=up0, up1=up1, res_up=res_up, k=k,
                              stride=stride, pad=pad, groups=groups, cin=cin, cout=cout, w=w, bn=bn, bias=bias, act=act,
-                             act_scale=act_scale, out_index=out_index, fuse=fuse))
+                             act_scale=act_scale, out_index=out_index, fuse=fuse, deferred=bool(deferred)))
         return dst
 
     def maxpool(self, src, k, stride, pad):
@@ -301,13 +301,15 @@ for _k in _RESNETS:
 BACKBONES['U22'] = ('unet', 'U22')
 
 
-def _readout(P, x, cmid, cout, prefix, act, act_scale, out_index, k=7, fuse=True, up0=False, stride=1):
+def _readout(P, x, cmid, cout, prefix, act, act_scale, out_index, k=7, fuse=True, up0=False, stride=1, deferred=False):
     """ReadOut (commons.py:461-511): conv kxk(bias) -> BN -> ReLU -> Dropout2d(eval: identity) -> conv 1x1(bias)."""
     if fuse and FUSE_READOUT and _pad32(cmid) in (32, 64, 128, 256) and cout <= 32:
         # one kernel: conv kxk + BN + ReLU -> (bf16, LDS) -> 1x1 conv + final activation -> fp32 NCHW head map
         P.conv(x, cmid, k, w=prefix + 'block.0.', bn=prefix + 'block.1.', bias=True, act='relu', out_index=out_index,
-               fuse=dict(w=prefix + 'block.4.', cout=cout, act=act, act_scale=act_scale), up0=up0, stride=stride)
+               fuse=dict(w=prefix + 'block.4.', cout=cout, act=act, act_scale=act_scale), up0=up0, stride=stride,
+               deferred=deferred)
         return
+    assert not deferred, 'only fused ReadOut heads can be deferred'
     t = P.conv(x, cmid, k, w=prefix + 'block.0.', bn=prefix + 'block.1.', bias=True, act='relu', up0=up0, stride=stride)
     P.conv(t, cout, 1, w=prefix + 'block.4.', bias=True, act=act, act_scale=act_scale, out_index=out_index)
 
@@ -317,14 +319,18 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
                backbone_kwargs: dict = None, fuse_readout: bool = True, uncertainty_head: bool = False,
                contour_head_channels: int = None, refinement_head_channels: int = None,
                kernel_sizes: dict = None, fuse_bilinear: bool = True, contour_head_stride: int = 1,
-               refinement_head_stride: int = 1, features: dict = None) -> Plan:
+               refinement_head_stride: int = 1, features: dict = None, sparse_heads: bool = False) -> Plan:
     """Plan of ``Cpn<backbone>`` (celldetection/models/cpn.py:287-439,771-2061; heads: CPNCore.__init__
     cpn.py:125-236).  ``kernel_sizes``: optional {'score'|'location'|'fourier'|'uncertainty'|'refinement': k}
     (the reference's ``kernel_size_<head>`` kwargs, default 7).  ``contour_head_stride`` / ``refinement_head_stride``: stride
     (1 or 2) of the k x k conv of the ReadOut heads (commons.py:494).  ``features``: optional {'score'|'location'|
     'contour'|'uncertainty'|'refinement': key or [key, key]} = the reference's ``<head>_features`` kwargs (cpn.py:135-139):
     decoder level '0', '1', ... or 'encoder.<k>' (UNet family); two keys are fused like ``Fuse2d`` (commons.py:640-674:
-    the second feature nearest-resized to the first one's size, concat, 1x1 conv + BN + ReLU)."""
+    the second feature nearest-resized to the first one's size, concat, 1x1 conv + BN + ReLU).
+    ``sparse_heads``: score-gated location / Fourier heads -- CPN.forward reads their maps at the proposal pixels only
+    (cpn.py:613-637), so the two convs are packed but not executed by the graph (``deferred`` ops) and evaluated at the
+    proposals by ``ops.sparse_heads``; needs both heads fused, on the same plain feature, stride 1, same kernel size
+    and a hidden width of 128 or 256 (``Plan.meta['sparse_heads']`` = None when the plan does not qualify)."""
     if contour_head_stride not in (1, 2) or refinement_head_stride not in (1, 2):
         raise NotImplementedError('head strides other than 1 and 2 are not supported by the HIP conv kernel')
     feats_cfg = dict(score='1', location='1', contour='1', uncertainty='1', refinement='0')
@@ -392,11 +398,18 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
     _readout(P, f1s, cm1 or c1, score_channels, 'core.score_head.', 'sigmoid' if score_channels == 1 else 'none', 0.,
              _lib.OUT_SCORES, k=ks.get('score', 7), fuse=fuse_readout, stride=hs)
     fl, cl = _head_input('location', 'core.location_fuse.')
+    # score-gated heads: both heads on the same single feature key (then `_head_input` adds no op and the two share fl)
+    same_src = _keys(feats_cfg['contour']) == _keys(feats_cfg['location']) and len(_keys(feats_cfg['location'])) == 1
+    gate = bool(sparse_heads) and fuse_readout and FUSE_READOUT and same_src and hs == 1 and order * 4 <= 32 and \
+        _pad32(cm1 or cl) in (128, 256) and ks.get('location', 7) == ks.get('fourier', 7) and ks.get('location', 7) > 1
+    first_head_op = len(P.ops)
     _readout(P, fl, cm1 or cl, 2, 'core.location_head.', 'none', 0., _lib.OUT_LOCATIONS, k=ks.get('location', 7),
-             fuse=fuse_readout, stride=hs)
+             fuse=fuse_readout, stride=hs, deferred=gate)
     ff, cf = _head_input('contour', 'core.fourier_fuse.')
     _readout(P, ff, cm1 or cf, order * 4, 'core.fourier_head.', 'none', 0., _lib.OUT_FOURIER, k=ks.get('fourier', 7),
-             fuse=fuse_readout, stride=hs)
+             fuse=fuse_readout, stride=hs, deferred=gate)
+    assert not gate or (ff == fl and cf == cl)
+    sparse_meta = dict(ops=(first_head_op, first_head_op + 1), src=fl) if gate else None
     if uncertainty_head:  # cpn.py:209-221: 4 channels, sigmoid
         fu, cu = _head_input('uncertainty', 'core.uncertainty_fuse.')
         _readout(P, fu, cm1 or cu, 4, 'core.uncertainty_head.', 'sigmoid', 0., _lib.OUT_UNCERTAINTY,
@@ -419,7 +432,7 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
                  stride=refinement_head_stride)
     P.meta = dict(backbone=backbone, order=order, head_down=scale, refinement=refinement, in_channels=in_channels,
                   score_channels=score_channels, refinement_buckets=refinement_buckets,
-                  uncertainty_head=bool(uncertainty_head))
+                  uncertainty_head=bool(uncertainty_head), sparse_heads=sparse_meta)
     return P
 
 
@@ -585,7 +598,7 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=Non
                 packed = torch.cat((packed, torch.zeros_like(packed[:, :1])), 1)
             wparts.append(packed.contiguous().reshape(-1).to(wdt))
         bparts.append(bias.to(torch.float32))
-        d.op = _lib.OP_CONV
+        d.op = _lib.OP_CONV_DEFERRED if op.get('deferred') else _lib.OP_CONV
         d.src0 = op['src0']
         d.src1 = -1 if op['src1'] is None else op['src1']
         d.res = -1 if op['res'] is None else op['res']

@@ -4,7 +4,7 @@ Same names, argument meaning and return conventions as the reference (celldetect
 tensors must live on the GPU -- there is no CPU fallback in the product path (the CPU restatement lives in
 ``oracle/`` and is test infrastructure only).
 """
-from ctypes import c_int32, c_int64
+from ctypes import c_int32, c_int64, c_void_p
 from typing import List
 
 import numpy as np
@@ -348,14 +348,37 @@ def gather_channels(maps: Tensor, indices: Tensor):
     return out
 
 
+def sparse_heads(op_a, op_b, features_ptr: int, channel_stride: int, grid, indices: Tensor, weights: Tensor,
+                 bias: Tensor):
+    """Score-gated ReadOut heads (csrc/sparse_heads.hip): the two fused head convs ``op_a`` / ``op_b`` (``_lib.OpDesc``
+    of one plan, same NHWC bf16 source tensor at device address ``features_ptr`` with ``grid`` = (N, h, w)) evaluated only at
+    the proposal pixels ``indices`` (``compact_scores``).  -> (out_a [P, cout_a], out_b [P, cout_b]) fp32: bit-identical to
+    the dense head maps gathered at those pixels (CPN.forward reads nothing else of them, cpn.py:613-637)."""
+    _need_cuda(indices, weights, bias)
+    n, h, w = (int(v) for v in grid)
+    P = int(indices.shape[0])
+    f32 = dict(dtype=torch.float32, device=indices.device)
+    out_a, out_b = torch.empty((P, int(op_a.fuse_cout)), **f32), torch.empty((P, int(op_b.fuse_cout)), **f32)
+    if P:
+        check(_lib.load().cpn_sparse_heads(op_a, op_b, c_void_p(int(features_ptr)), int(channel_stride), n, h, w,
+                                           ptr(indices.contiguous()), P, ptr(weights), ptr(bias), ptr(out_a), ptr(out_b),
+                                           stream_ptr()), 'sparse_heads')
+    return out_a, out_b
+
+
 def decode_proposals(indices: Tensor, scores: Tensor, locations: Tensor, fourier: Tensor, refinement, *, size,
-                     order: int, samples: int, iterations: int, offsets=None, num_buckets: int = 1):
+                     order: int, samples: int, iterations: int, offsets=None, num_buckets: int = 1, gathered=False):
     """Fused proposal decode (celldetection/models/cpn.py:613-702): gather + rel->abs locations + Fourier synthesis +
-    rescale + local refinement + clamp + boxes (+ offsets).  Returns a dict of flat [P, ...] tensors + 'b' [P]."""
+    rescale + local refinement + clamp + boxes (+ offsets).  Returns a dict of flat [P, ...] tensors + 'b' [P].
+    ``gathered``: ``locations`` [P, 2] / ``fourier`` [P, 4 * order_total] hold the head values of the proposals
+    (``sparse_heads``) instead of dense [N, C, h, w] maps; the head grid is taken from ``scores``."""
     _need_cuda(indices, scores, locations, fourier)
     lib = _lib.load()
     H, W = size
-    N, c4, h, w = fourier.shape
+    if gathered:
+        N, (h, w), c4 = scores.shape[0], scores.shape[-2:], fourier.shape[1]
+    else:
+        N, c4, h, w = fourier.shape
     order_total = c4 // 4
     P = int(indices.shape[0])
     dev = fourier.device
@@ -374,7 +397,8 @@ def decode_proposals(indices: Tensor, scores: Tensor, locations: Tensor, fourier
     bidx, bw = bucket_tables(samples, num_buckets, dev) if (num_buckets > 1 and ref is not None) else (None, None)
     if ref is not None and ref.shape[1] != 2 * num_buckets:
         raise ValueError(f'refinement tensor must have {2 * num_buckets} channels, got {ref.shape[1]}')
-    check(lib.cpn_decode(ptr(indices), P, ptr(scores.contiguous()), ptr(locations.contiguous()),
+    check((lib.cpn_decode_gathered if gathered else lib.cpn_decode)(
+                         ptr(indices), P, ptr(scores.contiguous()), ptr(locations.contiguous()),
                          ptr(fourier.contiguous()), ptr(ref), N, h, w, H, W, order_total, order, samples,
                          int(iterations), ptr(cos_t), ptr(sin_t), ptr(offs), ptr(out['contours']),
                          ptr(out['contour_proposals']), ptr(out['boxes']), ptr(out['scores']), ptr(out['locations']),

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CPN_ABI_VERSION 6
+#define CPN_ABI_VERSION 7
 
 #define CPN_E_INVALID (-1)
 #define CPN_E_UNSUPPORTED (-2)
@@ -47,7 +47,10 @@ typedef struct {
     float scale;       /* CPN_PRECISION_FP8: value of one e4m3 code unit of this tensor; else unused */
 } cpn_tensor_desc;
 
-enum { CPN_OP_INPUT = 0, CPN_OP_CONV = 1, CPN_OP_MAXPOOL = 2, CPN_OP_BILINEAR = 3 };
+/* CPN_OP_CONV_DEFERRED (score-gated heads, cpn_sparse_heads below): a fused ReadOut head conv that cpn_plan_run does NOT
+ * execute -- its weights are packed and its output size is reported like a CPN_OP_CONV's, and its source tensor stays
+ * intact in the workspace until the end of the run (cpn_plan_tensor_info locates it). */
+enum { CPN_OP_INPUT = 0, CPN_OP_CONV = 1, CPN_OP_MAXPOOL = 2, CPN_OP_BILINEAR = 3, CPN_OP_CONV_DEFERRED = 4 };
 enum { CPN_ACT_NONE = 0, CPN_ACT_RELU = 1, CPN_ACT_SIGMOID = 2, CPN_ACT_TANH_SCALED = 3 };
 enum { CPN_OUT_SCORES = 0, CPN_OUT_LOCATIONS = 1, CPN_OUT_FOURIER = 2, CPN_OUT_REFINEMENT = 3, CPN_OUT_UNCERTAINTY = 4,
        CPN_NUM_OUTPUTS = 5 };
@@ -110,6 +113,11 @@ int64_t cpn_plan_workspace_bytes(cpn_plan *plan, int32_t N, int32_t H, int32_t W
  * the element count per image of the largest activation tensor (callers split batches at 2^31 elements). */
 int cpn_plan_output_dims(cpn_plan *plan, int32_t H, int32_t W, int32_t out_index, int32_t *h, int32_t *w);
 int64_t cpn_plan_max_tensor_elements(cpn_plan *plan, int32_t H, int32_t W);
+/* Location of activation tensor `tensor` inside the workspace of a (N, H, W) run: byte offset, spatial size and channel
+ * stride (padded channel count; NHWC, bf16 / e4m3 / fp32 by plan precision).  Only tensors that are live at the end of the
+ * run may be read afterwards -- the sources of CPN_OP_CONV_DEFERRED ops are. */
+int cpn_plan_tensor_info(cpn_plan *plan, int32_t N, int32_t H, int32_t W, int32_t tensor, int64_t *byte_offset,
+                         int32_t *h, int32_t *w, int32_t *channel_stride);
 /* 2*MAC FLOPs executed by the MFMA loops for that shape (includes channel/tile padding). */
 double cpn_plan_executed_flops(cpn_plan *plan, int32_t N, int32_t H, int32_t W);
 
@@ -191,6 +199,27 @@ int cpn_decode(const int32_t *indices, int32_t P, const float *scores, const flo
                const float *offsets, float *contours, float *proposals, float *boxes, float *out_scores,
                float *out_locations, float *out_fourier, int32_t *batch_index, int32_t buckets,
                const int32_t *bucket_index, const float *bucket_weight, void *stream);
+
+/* cpn_decode on GATHERED head values: locations [P,2] and fourier [P,4*order_total] hold the head outputs of proposal p
+ * (what cpn_sparse_heads writes) instead of dense maps; everything else as cpn_decode. */
+int cpn_decode_gathered(const int32_t *indices, int32_t P, const float *scores, const float *locations,
+                        const float *fourier, const float *refinement, int32_t N, int32_t h, int32_t w, int32_t H,
+                        int32_t W, int32_t order_total, int32_t order, int32_t samples, int32_t iterations,
+                        const float *cos_table, const float *sin_table, const float *offsets, float *contours,
+                        float *proposals, float *boxes, float *out_scores, float *out_locations, float *out_fourier,
+                        int32_t *batch_index, int32_t buckets, const int32_t *bucket_index, const float *bucket_weight,
+                        void *stream);
+
+/* Score-gated ReadOut heads (bf16 plans): evaluates two fused ReadOut heads (cpn_op_desc with fuse_cout > 0: k x k
+ * stride-1 'same' conv + BN + ReLU + 1x1 conv, celldetection/models/commons.py:461-511) that read the same NHWC bf16
+ * feature tensor [N,h,w,channel_stride] ONLY at the P pixels `indices` (cpn_compact's output) and writes out_a [P,
+ * op_a->fuse_cout] and out_b [P, op_b->fuse_cout] (fp32): bit-identical to the values the dense heads produce at those
+ * pixels.  CPN.forward reads the location / Fourier maps at the proposals only (celldetection/models/cpn.py:613-637); the
+ * dense maps are (N h w) / P times more work.  `weights` / `bias`: the plan's packed blobs (the ops' offsets index them).
+ * Both heads must share source, kernel size and hidden width (128 or 256). */
+int cpn_sparse_heads(const cpn_op_desc *op_a, const cpn_op_desc *op_b, const void *features, int32_t channel_stride,
+                     int32_t N, int32_t h, int32_t w, const int32_t *indices, int32_t P, const void *weights,
+                     const float *bias, float *out_a, float *out_b, void *stream);
 
 /* Standalone pieces of the decode (parity tests, reference ops API celldetection/ops/cpn.py). */
 int cpn_fouriers2contours(const float *fourier, const float *locations, int32_t P, int32_t order, int32_t samples,
