@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-end GPU pass (run on the MI355X box through gpurun, from the repo root):
-#   tools/gpu_round_pass.sh <tag> [tests] [bench] [profile] [fp8]
+#   tools/gpu_round_pass.sh <tag> [tests] [bench] [profile] [fp8] [slide] [configs] [sparse]
 # writes everything under gpurun_out/ (the summaries that should be judged are then copied into profiles/).
 TAG=${1:-r02}; shift
 WHAT=${*:-tests bench profile}
@@ -35,6 +35,10 @@ configs)
   timeout 600 python bench.py --model CpnResNet18FPN --batch 8 --no-cpu-baseline --profile-layers > gpurun_out/${TAG}_bench_cfg1.json 2> gpurun_out/${TAG}_cfg1_layers.txt; cut -c1-200 gpurun_out/${TAG}_bench_cfg1.json
   timeout 600 python bench.py --model CpnResNet50FPN --batch 8 --tile 1024 --precision fp8 --no-cpu-baseline --steps 10 > gpurun_out/${TAG}_bench_cfg4_fp8.json 2> gpurun_out/${TAG}_cfg4.err; cut -c1-200 gpurun_out/${TAG}_bench_cfg4_fp8.json
   timeout 600 python bench.py --model CpnResNet50FPN --batch 4 --tile 1024 --precision fp8 --no-cpu-baseline --steps 10 --profile-layers > gpurun_out/${TAG}_bench_cfg4_fp8_b4.json 2> gpurun_out/${TAG}_cfg4_b4_layers.txt; cut -c1-200 gpurun_out/${TAG}_bench_cfg4_fp8_b4.json; tail -4 gpurun_out/${TAG}_cfg4_b4_layers.txt;;
+sparse)  # score-gated heads (experimental): acceptance tests, then the bench line with and without them on the same box
+  CPN_TEST_EXPERIMENTAL=1 timeout 900 python -m pytest tests/test_gpu_sparse_heads.py -q > gpurun_out/${TAG}_pytest_sparse.log 2>&1; tail -5 gpurun_out/${TAG}_pytest_sparse.log
+  timeout 600 python bench.py --no-cpu-baseline --sparse-heads > gpurun_out/${TAG}_bench_sparse_n1.json 2> gpurun_out/${TAG}_bench_sparse.err; cut -c1-400 gpurun_out/${TAG}_bench_sparse_n1.json
+  timeout 600 python bench.py --no-cpu-baseline > gpurun_out/${TAG}_bench_dense_n1.json 2> /dev/null; cut -c1-200 gpurun_out/${TAG}_bench_dense_n1.json;;
 fp8)
   timeout 600 python bench.py --precision fp8 --no-cpu-baseline > gpurun_out/${TAG}_bench_fp8_n1.json 2> gpurun_out/${TAG}_bench_fp8.err; cat gpurun_out/${TAG}_bench_fp8_n1.json | cut -c1-300
   (timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $P/f8trace -o b -- python bench.py --precision fp8 --steps 5 --warmup 2 --no-cpu-baseline) > $P/f8trace.log 2>&1
