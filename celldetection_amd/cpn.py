@@ -503,11 +503,17 @@ class CPN(nn.Module):
         if gathered:  # score-gated heads: location / Fourier head values of the proposals only (ops.sparse_heads)
             if sparse is None:
                 raise ValueError('postprocess: locations / fourier maps are missing and no score-gated head context given')
-            locations, fourier = ops.sparse_heads(sparse['op_a'], sparse['op_b'], sparse['features_ptr'],
-                                                  sparse['channel_stride'], sparse['grid'], indices, sparse['weights'],
-                                                  sparse['bias'])
             if tuple(sparse['grid'][1:]) != tuple(scores.shape[-2:]):
                 raise RuntimeError('score-gated heads: head grid and score grid differ')
+            src = (sparse['features_ptr'], sparse['channel_stride'], sparse['grid'])
+            if int(indices.shape[0]) > ops.SPARSE_HEADS_MAX_DENSITY * scores.shape[0] * scores.shape[-2] * scores.shape[-1]:
+                # most pixels are proposals: the dense convs are cheaper (and produce the same values)
+                locations = ops.dense_head(sparse['op_a'], *src, sparse['weights'], sparse['bias'])
+                fourier = ops.dense_head(sparse['op_b'], *src, sparse['weights'], sparse['bias'])
+                gathered = False
+            else:
+                locations, fourier = ops.sparse_heads(sparse['op_a'], sparse['op_b'], *src, indices, sparse['weights'],
+                                                      sparse['bias'])
         flat = ops.decode_proposals(indices, scores, locations, fourier, refinement if iters > 0 else None,
                                     size=original_size, order=order, samples=self.samples, iterations=iters,
                                     offsets=kwargs.get('offsets'), num_buckets=self.core.refinement_buckets,

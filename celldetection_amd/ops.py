@@ -348,6 +348,22 @@ def gather_channels(maps: Tensor, indices: Tensor):
     return out
 
 
+# score-gated heads: above this fraction of proposal pixels the dense head convs are run instead (same values; the
+# gathered kernel re-reads the k x k neighbourhood per proposal, the dense one shares it between neighbouring pixels)
+SPARSE_HEADS_MAX_DENSITY = .5
+
+
+def dense_head(op, features_ptr: int, channel_stride: int, grid, weights: Tensor, bias: Tensor):
+    """One fused ReadOut head conv (``_lib.OpDesc``, also a deferred one) densely over the NHWC bf16 tensor at
+    ``features_ptr`` -> fp32 [N, cout, h, w]: what ``cpn_plan_run`` computes for a head that is not deferred."""
+    _need_cuda(weights, bias)
+    n, h, w = (int(v) for v in grid)
+    out = torch.empty((n, int(op.fuse_cout), h, w), dtype=torch.float32, device=weights.device)
+    check(_lib.load().cpn_conv2d(op, c_void_p(int(features_ptr)), int(channel_stride), ptr(None), 0, ptr(None), 0, ptr(out),
+                                 0, n, h, w, ptr(weights), ptr(bias), stream_ptr()), 'conv2d')
+    return out
+
+
 def sparse_heads(op_a, op_b, features_ptr: int, channel_stride: int, grid, indices: Tensor, weights: Tensor,
                  bias: Tensor):
     """Score-gated ReadOut heads (csrc/sparse_heads.hip): the two fused head convs ``op_a`` / ``op_b`` (``_lib.OpDesc``

@@ -110,6 +110,20 @@ def test_model_outputs_identical_with_score_gated_heads(dev):
                     assert torch.equal(a, b), k
 
 
+def test_dense_fallback_when_most_pixels_are_proposals(dev):
+    m = _model(dev)
+    x = torch.rand(2, 3, 96, 160, generator=torch.Generator().manual_seed(3)).to(dev)
+    m.score_thresh = 0.  # every head pixel is a proposal
+    ref = m(x, nms=False)
+    m.sparse_heads = True
+    got = m(x, nms=False)
+    assert sum(int(v.shape[0]) for v in ref['scores']) == 2 * 24 * 40
+    for k in ref:
+        if ref[k] is not None:
+            for a, b in zip(got[k], ref[k]):
+                assert torch.equal(a, b), k
+
+
 def test_full_size_batch_matches_dense(dev):
     """BASELINE configs[2] shape: CpnResNeXt101UNet, 16 x 3 x 512 x 512."""
     m = _model(dev, 'CpnResNeXt101UNet')
