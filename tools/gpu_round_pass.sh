@@ -37,6 +37,7 @@ configs)
   timeout 600 python bench.py --model CpnResNet50FPN --batch 4 --tile 1024 --precision fp8 --no-cpu-baseline --steps 10 --profile-layers > gpurun_out/${TAG}_bench_cfg4_fp8_b4.json 2> gpurun_out/${TAG}_cfg4_b4_layers.txt; cut -c1-200 gpurun_out/${TAG}_bench_cfg4_fp8_b4.json; tail -4 gpurun_out/${TAG}_cfg4_b4_layers.txt;;
 sparse)  # score-gated heads (experimental): acceptance tests, then the bench line with and without them on the same box
   CPN_TEST_EXPERIMENTAL=1 timeout 900 python -m pytest tests/test_gpu_sparse_heads.py -q > gpurun_out/${TAG}_pytest_sparse.log 2>&1; tail -5 gpurun_out/${TAG}_pytest_sparse.log
+  timeout 300 python tools/sparse_microbench.py > gpurun_out/${TAG}_sparse_microbench.txt 2>&1; cat gpurun_out/${TAG}_sparse_microbench.txt
   timeout 600 python bench.py --no-cpu-baseline --sparse-heads > gpurun_out/${TAG}_bench_sparse_n1.json 2> gpurun_out/${TAG}_bench_sparse.err; cut -c1-400 gpurun_out/${TAG}_bench_sparse_n1.json
   timeout 600 python bench.py --no-cpu-baseline > gpurun_out/${TAG}_bench_dense_n1.json 2> /dev/null; cut -c1-200 gpurun_out/${TAG}_bench_dense_n1.json;;
 fp8)
