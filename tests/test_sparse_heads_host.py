@@ -100,3 +100,53 @@ def test_model_switch_selects_the_plan():
     assert m.plan_for('bf16').meta['sparse_heads'] is not None
     assert m.plan_for('fp8').meta['sparse_heads'] is None and m.plan_for('fp32').meta['sparse_heads'] is None
     assert 'sparse_heads' not in m.hparams  # a run-time switch, not a constructor argument of the reference
+
+
+def test_postprocess_routes_gated_heads(monkeypatch):
+    """Control flow of CPN.postprocess with score-gated heads, with the GPU ops replaced by recording stubs: below
+    ops.SPARSE_HEADS_MAX_DENSITY the gathered kernel + gathered decode, above it the two dense convs + plain decode."""
+    from celldetection_amd import ops
+    m = cda.models.CpnResNet18FPN(3)
+    n, h, w = 2, 8, 10
+    scores = torch.rand(n, 1, h, w)
+    calls = []
+
+    def compact(select_map, thresh, extra_flag=None):
+        idx = (select_map.reshape(-1) > thresh).nonzero().squeeze(1).to(torch.int32)
+        b = idx // (h * w)
+        return idx, [int((b == i).sum()) for i in range(n)], 0
+
+    def sparse_heads(op_a, op_b, ptr_, cs, grid, indices, weights, bias):
+        calls.append(('sparse', ptr_, cs, tuple(grid), int(indices.numel())))
+        return torch.zeros(indices.numel(), 2), torch.zeros(indices.numel(), 20)
+
+    def dense_head(op, ptr_, cs, grid, weights, bias):
+        calls.append(('dense', op, ptr_, cs, tuple(grid)))
+        return torch.zeros(n, 2 if op == 'A' else 20, h, w)
+
+    def decode(indices, scores_, locations, fourier, refinement, *, size, order, samples, iterations, offsets, num_buckets,
+               gathered):
+        calls.append(('decode', gathered, tuple(locations.shape), tuple(fourier.shape)))
+        P = int(indices.numel())
+        z = lambda *s: torch.zeros((P,) + s)
+        return dict(contours=z(samples, 2), contour_proposals=z(samples, 2), boxes=z(4), scores=z(), locations=z(2),
+                    fourier=z(order, 4), b=(indices // (h * w)).to(torch.int32))
+
+    monkeypatch.setattr(ops, 'compact_scores', compact)
+    monkeypatch.setattr(ops, 'sparse_heads', sparse_heads)
+    monkeypatch.setattr(ops, 'dense_head', dense_head)
+    monkeypatch.setattr(ops, 'decode_proposals', decode)
+    ctx = dict(op_a='A', op_b='B', features_ptr=1234, channel_stride=256, grid=(n, h, w), weights=None, bias=None)
+    for thresh, route in ((.9, 'sparse'), (.1, 'dense')):
+        calls.clear()
+        m.score_thresh = thresh
+        out = m.postprocess(scores, None, None, None, (32, 40), nms=False, sparse=ctx)
+        P = int((scores > thresh).sum())
+        assert sum(len(v) for v in out['scores']) == P
+        if route == 'sparse':
+            assert calls[0] == ('sparse', 1234, 256, (n, h, w), P) and calls[1] == ('decode', True, (P, 2), (P, 20))
+        else:
+            assert [c[:2] for c in calls[:2]] == [('dense', 'A'), ('dense', 'B')]
+            assert calls[2] == ('decode', False, (n, 2, h, w), (n, 20, h, w))
+    with pytest.raises(ValueError):
+        m.postprocess(scores, None, None, None, (32, 40), nms=False)  # maps missing and no gated-head context
