@@ -26,6 +26,8 @@
 //     = W2[32][HID] x X (one (head, 32-proposal fragment) per wave) -> + bias2 -> activation -> out[head][proposal][c].
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "../../include/cpn_hip.h"
 #include "cpn_error.h"
 #include "cpn_kernels.h"
@@ -283,15 +285,15 @@ __global__ __launch_bounds__(64 * NWAVES) void sparse_heads_kernel(const Args a)
 
 template <int HID>
 static int launch(const Args &a, hipStream_t stream) {
-    static bool attr_set[64];
+    static std::atomic<bool> attr_set[64];  // per device ordinal (the dynamic-LDS limit is a per-device function attribute)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return (int) hipErrorInvalidDevice;
     const size_t lds = (size_t) 2 * MT * HID * 2 > (size_t) 4 * SLOT ? (size_t) 2 * MT * HID * 2 : (size_t) 4 * SLOT;
     auto kern = sparse_heads_kernel<HID>;
-    if (!attr_set[dev]) {
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int) e;
-        attr_set[dev] = true;
+        attr_set[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(kern, dim3((unsigned) ((a.P + MT - 1) / MT)), dim3(64 * NWAVES), lds, stream, a);
     return (int) hipGetLastError();
