@@ -322,7 +322,8 @@ def main():
     if rank == 0:
         try:
             prof = eng.profile(x, model.core.order, True)
-        except ValueError:  # the engine splits this batch (a tensor beyond the 32-bit addressing limit): no per-op timing
+        except (ValueError, NotImplementedError):  # the engine splits this batch (32-bit addressing limit), or the plan has
+            # score-gated heads: no per-op timing
             prof = None
     if prof is not None:
         tot = sum(p['ms'] for p in prof)
