@@ -206,3 +206,19 @@ def test_plans_per_precision():
     assert not any(o.get('fuse') for o in m.plan_for('fp32').ops if o['op'] == 'conv')
     u = cda.models.CpnU22(3, backbone_kwargs={'backbone_kwargs': {'base_channels': 8}})
     assert 'bilinear' not in kinds(u.plan_for('fp8'))  # level 0 of a U22 has the input size by construction
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w', [(2, 5, 7, 6, 9), (1, 3, 4, 1, 1), (1, 8, 8, 16, 5)])
+def test_subpixel_decomposition_is_exact(n, cin, cout, h, w):
+    """3x3 conv over a x2 nearest-upsampled map == four 2x2 convs on the low-resolution map (celldetection_amd/subpixel.py):
+    the algebra behind the planned decoder FLOP saving, incl. the zero padding at all four borders."""
+    import torch.nn.functional as F
+    from celldetection_amd import subpixel
+    g = torch.Generator().manual_seed(n * 100 + h)
+    x = torch.randn(n, cin, h, w, generator=g, dtype=torch.float64)
+    wt = torch.randn(cout, cin, 3, 3, generator=g, dtype=torch.float64)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode='nearest'), wt, padding=1)
+    got = subpixel.upsampled_conv_by_phases(x, wt)
+    assert got.shape == ref.shape
+    torch.testing.assert_close(got, ref, rtol=1e-12, atol=1e-12)
+    assert subpixel.collapse_upsampled_taps(wt).shape == (2, 2, cout, cin, 2, 2)
