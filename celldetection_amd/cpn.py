@@ -113,8 +113,23 @@ class _Engine:
         _lib.check(_lib.load().cpn_plan_output_dims(self.handle, h, w, out_index, oh, ow), 'plan_output_dims')
         return int(oh.value), int(ow.value)
 
+    def max_batch(self, n, h, w):
+        """Images per graph run: the kernels address activation tensors through 2^31-byte buffer descriptors / 32-bit
+        element offsets, so a batch whose largest tensor would exceed that is split (e.g. 8 x 256 ch x 1024^2 in front of
+        an FPN refinement head)."""
+        per_image = int(_lib.load().cpn_plan_max_tensor_elements(self.handle, h, w))
+        if per_image <= 0:
+            _lib.check(per_image or _lib.E_INVALID, 'plan_max_tensor_elements')
+        limit = (2 ** 31 - 1) // (2 if self.precision == 'bf16' else 1)  # sources: 2^31 bytes (fp32 path: elements)
+        return max(1, min(n, limit // per_image))
+
     def executed_flops(self, n, h, w):
-        return float(_lib.load().cpn_plan_executed_flops(self.handle, n, h, w))
+        """2*MAC FLOPs the MFMA loops execute for a batch of n (the sum over the sub-batches the engine splits it into)."""
+        lib, nb = _lib.load(), self.max_batch(n, h, w)
+        total = (n // nb) * float(lib.cpn_plan_executed_flops(self.handle, nb, h, w))
+        if n % nb:
+            total += float(lib.cpn_plan_executed_flops(self.handle, n % nb, h, w))
+        return total
 
     def profile(self, x: torch.Tensor, order_total: int, refinement: bool):
         """Per-op timing of one conv-graph execution: list of dicts(op, name, ms, gflop_executed)."""
@@ -161,18 +176,11 @@ class _Engine:
         self.last_uncertainty = torch.empty((n, 4) + self.output_size(h, w, _lib.OUT_UNCERTAINTY), **f32) \
             if meta.get('uncertainty_head') else None
         flag = torch.zeros(1, dtype=torch.int32, device=self.device)
-        # the kernels address activation tensors with 32-bit offsets / 2^31-byte buffer descriptors: split the batch when
-        # a tensor of the graph would exceed that (e.g. 8 x 256 ch x 1024^2 in front of an FPN refinement head)
-        per_image = int(lib.cpn_plan_max_tensor_elements(self.handle, h, w))
-        if per_image <= 0:
-            _lib.check(per_image or _lib.E_INVALID, 'plan_max_tensor_elements')
-        limit = (2 ** 31 - 1) // (2 if self.precision == 'bf16' else 1)  # sources: 2^31 bytes (fp32 path: elements)
-        nb = max(1, min(n, limit // per_image))
+        nb = self.max_batch(n, h, w)
         if _timed is not None and nb < n:
             raise ValueError('per-op profiling needs a batch whose tensors stay below 2^31 elements')
-        if gated and nb < n:
-            raise NotImplementedError('score-gated heads need the whole batch in one graph run (tensors below 2^31 bytes): '
-                                      'forward a smaller batch or set model.sparse_heads = False')
+        if gated and nb < n:  # (CPN.core_forward routes such batches to the dense plan)
+            raise NotImplementedError('score-gated heads need the whole batch in one graph run (tensors below 2^31 bytes)')
         ws, need = self.workspace(nb, h, w)
         outputs = (scores, locations, fourier, ref, self.last_uncertainty)
         for i0 in range(0, n, nb):
@@ -270,7 +278,8 @@ class CPN(nn.Module):
         self.precision = 'bf16'
         # score-gated location / Fourier heads (bf16 only; csrc/sparse_heads.hip): the two heads are evaluated at the
         # proposal pixels only -- CPN.forward reads nothing else of their maps (cpn.py:613-637); outputs are identical.
-        # Opt-in (EXPERIMENTAL until validated on hardware): set ``model.sparse_heads = True``
+        # Validated bit-identical on the MI355X (tests/test_gpu_sparse_heads.py); a run-time switch, default off so that the
+        # default graph is the reference's dense one: set ``model.sparse_heads = True``
         self.sparse_heads = False
         self._fp8_scales = None
         self._plan = graph.build_plan(**self._plan_kwargs)  # bf16: fused ReadOut tails + fused bilinear head source
@@ -280,6 +289,7 @@ class CPN(nn.Module):
         self.core.order = order
         self.core.refinement_buckets = refinement_buckets
         self._engine = None
+        self._engine_dense = None  # dense-plan fallback of a model with score-gated heads (batches the engine must split)
         self._hparams = {}
         self.max_imsize = None
         self.eval()
@@ -293,17 +303,17 @@ class CPN(nn.Module):
         self._hparams = dict(hp)
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
-        self._engine = None  # weights change -> repack on next forward
+        self._engine = self._engine_dense = None  # weights change -> repack on next forward
         self._fp8_scales = None
         return super().load_state_dict(state_dict, strict=strict, **kw)
 
     def repack(self):
         """Call after modifying parameters in place (the fp8 activation scales are stale then, too)."""
-        self._engine = None
+        self._engine = self._engine_dense = None
         self._fp8_scales = None
 
     def _apply(self, fn, *a, **k):
-        self._engine = None
+        self._engine = self._engine_dense = None
         return super()._apply(fn, *a, **k)
 
     def train(self, mode: bool = True):
@@ -374,6 +384,12 @@ class CPN(nn.Module):
     def core_forward(self, inputs: torch.Tensor):
         """CPNCore.forward (cpn.py:238-283) -> (scores(sigmoid applied), locations, refinement, fourier)."""
         eng = self.engine(inputs.device, calibration_input=inputs)
+        if eng.sparse and eng.max_batch(inputs.shape[0], *inputs.shape[-2:]) < inputs.shape[0]:
+            # the engine has to split this batch (2^31-byte tensors), but the gathered heads read the heads' source of the
+            # WHOLE batch after the run: such batches take the dense plan (same outputs)
+            if self._engine_dense is None or self._engine_dense.device != eng.device:
+                self._engine_dense = _Engine(self._plan, self.state_dict(), eng.device, 'bf16')
+            eng = self._engine_dense
         scores, locations, refinement, fourier, flag = eng.run(inputs, self.core.order, self.refinement)
         self._last_flag = flag
         self._last_uncertainty = eng.last_uncertainty  # fifth CPNCore output (cpn.py:283), [N,4,h,w] or None

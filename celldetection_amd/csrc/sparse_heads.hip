@@ -307,7 +307,7 @@ extern "C" int cpn_sparse_heads(const cpn_op_desc *op_a, const cpn_op_desc *op_b
                                 int32_t P, const void *weights, const float *bias, float *out_a, float *out_b,
                                 void *stream) {
     using namespace cpn;
-    if (!op_a || !op_b || !features || !weights || !out_a || !out_b || (P > 0 && !indices))
+    if (!op_a || !op_b || !features || !weights || !bias || !out_a || !out_b || (P > 0 && !indices))
         return fail(CPN_E_INVALID, "cpn_sparse_heads: null pointer");
     if (P < 0 || N <= 0 || h <= 0 || w <= 0) return fail(CPN_E_INVALID, "cpn_sparse_heads: bad sizes");
     if (P == 0) return 0;

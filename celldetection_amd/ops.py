@@ -349,8 +349,10 @@ def gather_channels(maps: Tensor, indices: Tensor):
 
 
 # score-gated heads: above this fraction of proposal pixels the dense head convs are run instead (same values; the
-# gathered kernel re-reads the k x k neighbourhood per proposal, the dense one shares it between neighbouring pixels)
-SPARSE_HEADS_MAX_DENSITY = .5
+# gathered kernel re-reads the k x k neighbourhood per proposal, the dense one shares it between neighbouring pixels).
+# Measured crossover on the MI355X (profiles/r03_sparse_density_sweep.txt, 16 x 256^2 head grid, 7x7 256->256): the
+# gathered kernel is 1.76x faster at density 0.5 and 0.92x at 1.0 -> break-even at ~0.9
+SPARSE_HEADS_MAX_DENSITY = .8
 
 
 def dense_head(op, features_ptr: int, channel_stride: int, grid, weights: Tensor, bias: Tensor):
