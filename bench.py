@@ -206,8 +206,11 @@ def main():
     ap.add_argument('--no-pipeline', dest='pipeline', action='store_false', help='synchronous forward() per step')
     ap.add_argument('--profile-layers', action='store_true', help='print per-op timings to stderr')
     ap.add_argument('--sparse-heads', action='store_true',
-                    help='EXPERIMENTAL (not validated on hardware yet): score-gated location / Fourier heads -- evaluated at the '
-                         'proposal pixels only, identical outputs (csrc/sparse_heads.hip); bf16 only')
+                    help='score-gated location / Fourier heads -- evaluated at the proposal pixels only, identical outputs '
+                         '(csrc/sparse_heads.hip); bf16 only.  The default line stays the dense reference graph')
+    ap.add_argument('--no-subpixel', action='store_true',
+                    help='A/B switch: run the UNet decoder convs over upsampled maps as the reference states them instead '
+                         'of their sub-pixel decomposition (model.subpixel = False)')
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 30 if args.workload == 'tiles' else 1
@@ -259,6 +262,8 @@ def main():
         model.precision = 'fp8'
         model.calibrate_fp8(x[:2])  # static activation scales from a bf16 run on two tiles
 
+    if args.no_subpixel:
+        model.subpixel = False
     if args.sparse_heads:
         if args.precision != 'bf16':
             raise SystemExit('--sparse-heads: bf16 only')

@@ -10,12 +10,13 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CPN_HIP_LIB') or os.path.join(HERE, 'libcpn_hip.so')  # env: kernel A/B tuning only
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 PRECISION_BF16, PRECISION_F32, PRECISION_FP8 = 0, 1, 2
 E_INVALID, E_UNSUPPORTED, E_WORKSPACE = -1, -2, -3
 
 OP_INPUT, OP_CONV, OP_MAXPOOL, OP_BILINEAR, OP_CONV_DEFERRED = 0, 1, 2, 3, 4
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH_SCALED = 0, 1, 2, 3
+SUBPIXEL_NONE, SUBPIXEL_HEAD, SUBPIXEL_PHASE, SUBPIXEL_LATERAL, SUBPIXEL_SCATTER = 0, 1, 2, 3, 4
 OUT_SCORES, OUT_LOCATIONS, OUT_FOURIER, OUT_REFINEMENT, OUT_UNCERTAINTY = 0, 1, 2, 3, 4
 NUM_OUTPUTS = 5
 
@@ -33,7 +34,7 @@ class OpDesc(Structure):
                 ('act', c_int32), ('act_scale', c_float), ('out_index', c_int32), ('cout_real', c_int32),
                 ('dst_coff', c_int32), ('in_channels', c_int32),
                 ('fuse_weight_offset', c_int64), ('fuse_bias_offset', c_int64), ('fuse_cout', c_int32),
-                ('fuse_act', c_int32), ('fuse_act_scale', c_float), ('mult_offset', c_int32)]
+                ('fuse_act', c_int32), ('fuse_act_scale', c_float), ('mult_offset', c_int32), ('subpixel', c_int32)]
 
 
 # every symbol include/cpn_hip.h declares: (name, restype, argtypes)

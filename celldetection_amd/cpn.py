@@ -282,7 +282,11 @@ class CPN(nn.Module):
         # default graph is the reference's dense one: set ``model.sparse_heads = True``
         self.sparse_heads = False
         self._fp8_scales = None
-        self._plan = graph.build_plan(**self._plan_kwargs)  # bf16: fused ReadOut tails + fused bilinear head source
+        # sub-pixel decomposition of the UNet decoder convs over x2-upsampled maps (bf16 plans; graph._two_conv_norm_relu):
+        # 4/9 of the MACs on the upsampled channels, taken wherever the upsampling is an exact x2.  A run-time switch.
+        self.subpixel = True
+        # bf16: fused ReadOut tails + fused bilinear head source + sub-pixel decoder convs
+        self._plan = graph.build_plan(**self._plan_kwargs, subpixel=True)
         self._alt_plans = {}
         for key, shape, kind in self._plan.entries:
             _register(self, key, shape, kind)
@@ -325,12 +329,15 @@ class CPN(nn.Module):
         """Layer plan per precision: bf16 fuses the ReadOut tails and the bilinear resize in front of the refinement head;
         fp8 keeps that resize as its own op (on e4m3 codes; also the plan its bf16 calibration run uses, so that the
         tensor ids of the activation scales match); fp32 (verification) fuses nothing."""
-        if precision == 'bf16' and not self.sparse_heads:
-            return self._plan
-        if precision == 'bf16':  # score-gated heads: same entries / weights, the two head convs are deferred ops
-            if 'bf16+sparse' not in self._alt_plans:
-                self._alt_plans['bf16+sparse'] = graph.build_plan(**self._plan_kwargs, sparse_heads=True)
-            return self._alt_plans['bf16+sparse']
+        if precision == 'bf16':
+            # score-gated heads: same entries / weights, the two head convs are deferred ops; sub-pixel decoder convs:
+            # same entries, the first conv of every UNet decoder level additionally carries its decomposition
+            key = (bool(self.sparse_heads), bool(self.subpixel))
+            if key == (False, True):
+                return self._plan
+            if key not in self._alt_plans:
+                self._alt_plans[key] = graph.build_plan(**self._plan_kwargs, sparse_heads=key[0], subpixel=key[1])
+            return self._alt_plans[key]
         if precision not in self._alt_plans:
             extra = dict(fuse_bilinear=False) if precision == 'fp8' else dict(fuse_readout=False, fuse_bilinear=False)
             self._alt_plans[precision] = graph.build_plan(**self._plan_kwargs, **extra)
@@ -343,7 +350,7 @@ class CPN(nn.Module):
                                'There is no CPU fallback in the product path.')
         if self.precision not in ('bf16', 'fp32', 'fp8'):
             raise ValueError("precision must be 'bf16', 'fp32' or 'fp8'")
-        sparse = bool(self.sparse_heads) and self.precision == 'bf16'
+        sparse = (bool(self.sparse_heads), bool(self.subpixel)) if self.precision == 'bf16' else None
         if self._engine is None or self._engine.device != device or self._engine.precision != self.precision or \
                 self._engine.sparse_requested != sparse:
             if self.precision == 'fp8':
@@ -388,7 +395,11 @@ class CPN(nn.Module):
             # the engine has to split this batch (2^31-byte tensors), but the gathered heads read the heads' source of the
             # WHOLE batch after the run: such batches take the dense plan (same outputs)
             if self._engine_dense is None or self._engine_dense.device != eng.device:
-                self._engine_dense = _Engine(self._plan, self.state_dict(), eng.device, 'bf16')
+                sh, self.sparse_heads = self.sparse_heads, False
+                try:
+                    self._engine_dense = _Engine(self.plan_for('bf16'), self.state_dict(), eng.device, 'bf16')
+                finally:
+                    self.sparse_heads = sh
             eng = self._engine_dense
         scores, locations, refinement, fourier, flag = eng.run(inputs, self.core.order, self.refinement)
         self._last_flag = flag

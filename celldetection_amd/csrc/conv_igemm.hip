@@ -142,12 +142,14 @@ __device__ __forceinline__ void bdma16(rsrc_t rsrc, unsigned lane_off, unsigned 
 
 // pointwise stride 1 / KxK stride 1 / KxK stride 2 / KxK stride 1 whose source is read through a bilinear resize
 // MODE_S1R = MODE_S1 with the weight operand loaded from L2 straight into registers (dense KxK, >= 9 taps, 8x256 tile)
-enum Mode : int { MODE_PW = 0, MODE_S1 = 1, MODE_S2 = 2, MODE_BL = 3, MODE_S1R = 4 };
+// MODE_PWR = MODE_PW with the register-weight loop of MODE_S1R (1x1 convs stream BOTH operands once per output tile: the
+// LDS-DMA issue path is their bottleneck, and the weight half of it moves to plain buffer loads)
+enum Mode : int { MODE_PW = 0, MODE_S1 = 1, MODE_S2 = 2, MODE_BL = 3, MODE_S1R = 4, MODE_PWR = 5 };
 
 template <int MODE>
 struct ModeCfg {
     static constexpr int S = MODE == MODE_S2 ? 2 : 1;                              // conv stride
-    static constexpr int PITCH = MODE == MODE_PW ? 32 : (MODE == MODE_S2 ? 80 : 48);  // halo row pitch (pixels)
+    static constexpr int PITCH = (MODE == MODE_PW || MODE == MODE_PWR) ? 32 : (MODE == MODE_S2 ? 80 : 48);  // halo row pitch (pixels)
 };
 
 template <int TH, int BN, int WM, int WN>
@@ -342,9 +344,9 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     using C = Cfg<TH, BN, WM, WN>;
     constexpr int S = ModeCfg<MODE>::S;
     constexpr int PITCH = ModeCfg<MODE>::PITCH;
-    constexpr bool PW = MODE == MODE_PW;
+    constexpr bool PW = MODE == MODE_PW || MODE == MODE_PWR;
     constexpr bool BL = MODE == MODE_BL;
-    constexpr bool RW = MODE == MODE_S1R;  // weights: global -> registers (no weight tiles in LDS, no per-step barrier)
+    constexpr bool RW = MODE == MODE_S1R || MODE == MODE_PWR;  // weights: global -> registers (no weight tiles in LDS)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -380,7 +382,8 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     const int nsteps = nitems >> 1;                   // (the packer pads an odd item count with an all-zero slab, so
                                                       // the K loop has no conditional tail)
     const int cout_b = a.cout_b;
-    const int cin0 = g * a.cin_b;
+    const int cin0 = a.phase ? 0 : g * a.cin_b;  // (sub-pixel phase conv: the four phases read the same channels)
+    const int pad_y = a.pad - (a.phase ? (g >> 1) : 0), pad_x = a.pad - (a.phase ? (g & 1) : 0);
     const int c0_used = a.c0_used;
     constexpr int WITEM = BN * REC;   // one item's weight slab tile
     constexpr int WBUF = 2 * WITEM;   // one step's weights
@@ -392,7 +395,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
 
     HaloGeo G;
     G.sub = PW ? a.stride : 1;
-    G.n = n; G.iy0 = oy0 * (PW ? a.stride : S) - a.pad; G.ix0 = ox0 * (PW ? a.stride : S) - a.pad;
+    G.n = n; G.iy0 = oy0 * (PW ? a.stride : S) - pad_y; G.ix0 = ox0 * (PW ? a.stride : S) - pad_x;
     G.Hin = a.Hin; G.Win = a.Win;
     G.up0 = a.up0; G.up1 = a.up1;
     G.Hs0 = a.Hs0; G.Ws0 = a.Ws0; G.Hs1 = a.Hs1; G.Ws1 = a.Ws1;
@@ -720,7 +723,18 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
                 asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 land_due = false;
-                if (changed && n0i.c + 1 < nchunks) {
+                if constexpr (PW) {
+                    // pointwise: every item is a chunk of its own -- stage the two chunks of step st + 2 into the ring
+                    // slots step st occupied (everybody's reads of step st returned: barrier above)
+                    const int idx2_ = 2 * (st + 1) + 2;
+                    if (idx2_ < nreal) {
+                        if (pw_fast) { PW_HALO_DMA(idx2_); } else { HALO_DMA(idx2_); }
+                        land_due = true;
+                    }
+                    if (idx2_ + 1 < nreal) {
+                        if (pw_fast) { PW_HALO_DMA(idx2_ + 1); } else { HALO_DMA(idx2_ + 1); }
+                    }
+                } else if (changed && n0i.c + 1 < nchunks) {
                     HALO_DMA(n0i.c + 1);
                     land_due = true;
                 }
@@ -817,7 +831,9 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
         const int part = lane % LPP, prow = lane / LPP;
         const int cob = n0 + wave_n * CW + part * 8;  // first of this lane's 8 channels within the bundle
         const bool ch_ok = cob < cout_b;
-        const int co = g * cout_b + cob;
+        const bool scat = a.phase == 2;  // phase g scatters to pixels (2 oy + py, 2 ox + px); channels / bias are shared
+        const int co = (scat ? 0 : g * cout_b) + cob;
+        const int spy = scat ? (g >> 1) : 0, spx = scat ? (g & 1) : 0, ssh = scat ? 1 : 0;
         float bias8[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
@@ -851,20 +867,27 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
         // bases are wave-uniform, lane offsets are 32-bit, ALL residual loads of the wave are issued before the first
         // staging pass, and a store costs ~25 instructions.
         constexpr int NIT = 32 / PPI;
-        const bool full_tile = oy0 + TH <= a.Hout && ox0 + TW <= a.Wout && n0 + BN <= cout_b && !a.res_up;
+        const bool full_tile = oy0 + TH <= a.Hout && ox0 + TW <= a.Wout && n0 + BN <= cout_b && a.res_up != 1;
         if (full_tile) {
-            const unsigned lane_off = (unsigned) ((prow * a.dst_stride + a.dst_coff + co) * ES);
-            const unsigned step = (unsigned) (PPI * a.dst_stride * ES);
+            const unsigned lane_off = (unsigned) ((((prow << ssh) + spx) * a.dst_stride + a.dst_coff + co) * ES);
+            const unsigned step = (unsigned) ((PPI << ssh) * a.dst_stride * ES);
             const bool has_res = a.res != nullptr;
             store8_t rr[WM][NIT];
             if (has_res) {
-                const unsigned rlane_off = (unsigned) ((prow * a.res_stride + co) * ES);
-                const unsigned rstep = (unsigned) (PPI * a.res_stride * ES);
+                // res_up 2: phase tensor [Hout/2][Wout/2][4 * res_cph] read pixel-shuffled -- pixel p of the row sits in
+                // low-resolution pixel p >> 1, phase column p & 1 (ox0 and PPI are even); the row phase is wave-uniform
+                static_assert(PPI % 2 == 0, "pixel-shuffled residual: even pixel count per store instruction");
+                const bool shuf = a.res_up == 2;
+                const unsigned rlane_off = shuf ? (unsigned) (((prow >> 1) * a.res_stride + (prow & 1) * a.res_cph + co) * ES)
+                                                : (unsigned) ((prow * a.res_stride + co) * ES);
+                const unsigned rstep = (unsigned) ((shuf ? PPI / 2 : PPI) * a.res_stride * ES);
 #pragma unroll
                 for (int f = 0; f < WM; ++f) {
                     const int oy = oy0 + wave_m * WM + f;
                     const unsigned char *rrow = (const unsigned char *) a.res +
-                                                (((size_t) n * a.Hout + oy) * a.Wout + ox0) * (size_t) a.res_stride * ES;
+                        (shuf ? (((size_t) n * a.Hr + (oy >> 1)) * a.Wr + (ox0 >> 1)) * (size_t) a.res_stride * ES +
+                                    (size_t) ((oy & 1) * 2 * a.res_cph) * ES
+                              : (((size_t) n * a.Hout + oy) * a.Wout + ox0) * (size_t) a.res_stride * ES);
 #pragma unroll
                     for (int it = 0; it < NIT; ++it) rr[f][it] = *(const store8_t *) (rrow + rlane_off + it * rstep);
                 }
@@ -873,7 +896,8 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
             for (int f = 0; f < WM; ++f) {
                 const int oy = oy0 + wave_m * WM + f;
                 unsigned char *drow = (unsigned char *) a.dst +
-                                      (((size_t) n * a.Hout + oy) * a.Wout + ox0) * (size_t) a.dst_stride * ES;
+                                      (((size_t) n * (a.Hout << ssh) + ((oy << ssh) + spy)) * (a.Wout << ssh) + (ox0 << ssh)) *
+                                          (size_t) a.dst_stride * ES;
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
 #pragma unroll
@@ -920,17 +944,22 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
                 if (!(ch_ok && oy < a.Hout && ox < a.Wout)) continue;
                 float v[8] = CPN_V8(v0, v1);
                 const size_t pix = ((size_t) n * a.Hout + oy) * a.Wout + ox;
+                const size_t dpix = scat ? ((size_t) n * 2 * a.Hout + 2 * oy + spy) * (2 * a.Wout) + 2 * ox + spx : pix;
                 if (a.res) {
                     size_t rpix = pix;
-                    if (a.res_up)
+                    int rco = co;
+                    if (a.res_up == 2) {  // pixel-shuffled phase tensor
+                        rpix = ((size_t) n * a.Hr + (oy >> 1)) * a.Wr + (ox >> 1);
+                        rco += ((oy & 1) * 2 + (ox & 1)) * a.res_cph;
+                    } else if (a.res_up)
                         rpix = ((size_t) n * a.Hr + nearest_src(oy, a.ry, a.Hr)) * a.Wr + nearest_src(ox, a.rx, a.Wr);
-                    add_res8(v, *(const store8_t *) ((const elem_t *) a.res + rpix * a.res_stride + co), a.res_scale);
+                    add_res8(v, *(const store8_t *) ((const elem_t *) a.res + rpix * a.res_stride + rco), a.res_scale);
                 }
                 if (a.act == ACT_RELU) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
-                *(store8_t *) ((elem_t *) a.dst + pix * a.dst_stride + a.dst_coff + co) = pack8(v, a.out_inv_scale);
+                *(store8_t *) ((elem_t *) a.dst + dpix * a.dst_stride + a.dst_coff + co) = pack8(v, a.out_inv_scale);
             }
         }
     } else if (a.out_mode == OUT_FUSED_HEAD) {
@@ -1033,7 +1062,10 @@ struct TileChoice {
 };
 
 static int conv_mode(const ConvArgs &a) {
-    if (a.KH == 1 && a.KW == 1 && a.pad == 0) return MODE_PW;  // incl. strided 1x1: the tile gathers only its outputs
+    if (a.KH == 1 && a.KW == 1 && a.pad == 0) {  // incl. strided 1x1: the tile gathers only its outputs
+        const char *e = getenv("CPN_PWR");  // opt-in experiment (read per call): register-weight loop, 8x256 tile only
+        return (!CPN_FP8 && e && atoi(e) != 0) ? MODE_PWR : MODE_PW;
+    }
     if (a.up0 == 2) return MODE_BL;
     if (a.stride == 2) return MODE_S2;
     // MODE_S1R is opt-in (CPN_RW=1; read per call so that tests can toggle it): on random operands it runs within 1 % of
@@ -1045,7 +1077,7 @@ static int conv_mode(const ConvArgs &a) {
 static size_t lds_bytes(const ConvArgs &a, int TH, int BN) {
     const int mode = conv_mode(a);
     const int S = mode == MODE_S2 ? 2 : 1;
-    const int pitch = mode == MODE_PW ? 32 : (mode == MODE_S2 ? 80 : 48);
+    const int pitch = (mode == MODE_PW || mode == MODE_PWR) ? 32 : (mode == MODE_S2 ? 80 : 48);
     const int HH = (TH - 1) * S + a.KH;
     const int nchunks = a.cin_b / 32;
     const size_t halo_buf = (size_t) ((HH * pitch * 4 + 63) / 64) * 1024;
@@ -1084,6 +1116,11 @@ static int launch_mode(const ConvArgs &a, hipStream_t stream) {
 template <int TH, int BN, int WM, int WN>
 static int launch_cfg(const ConvArgs &a, hipStream_t stream) {
     switch (conv_mode(a)) {
+        case MODE_PWR:
+#if !CPN_FP8
+            if constexpr (TH == 8 && BN == 256 && WM == 4 && WN == 2) return launch_mode<TH, BN, WM, WN, MODE_PWR>(a, stream);
+#endif
+            return launch_mode<TH, BN, WM, WN, MODE_PW>(a, stream);
         case MODE_PW: return launch_mode<TH, BN, WM, WN, MODE_PW>(a, stream);
         case MODE_S1: return launch_mode<TH, BN, WM, WN, MODE_S1>(a, stream);
         case MODE_S1R:
@@ -1131,7 +1168,13 @@ int launch_conv(const ConvArgs &a, hipStream_t stream) {
         c.TH = (a.cout_b == 64 && c.TH == 16) ? 16 : 8;
     }
     if (lds_bytes(a, c.TH, c.BN) > LDS_MAX) return (int) hipErrorInvalidValue;
-    if (c.TH == 16) return launch_cfg<16, 64, 2, 2>(a, stream);
+    if (c.TH == 16) {
+        // CPN_T64=1 (experiment, read per call): four waves of 4 rows x 32 px x 64 cout (8 MFMAs per 6 fragment reads, like
+        // the flagship tile) instead of eight waves of 2 rows (4 MFMAs per 4 reads: LDS-read bound)
+        const char *e = getenv("CPN_T64");
+        if (e && atoi(e) != 0) return launch_cfg<16, 64, 4, 2>(a, stream);
+        return launch_cfg<16, 64, 2, 2>(a, stream);
+    }
     if (c.TH == 8) {
         switch (c.BN) {
             case 256: return launch_cfg<8, 256, 4, 2>(a, stream);

@@ -34,6 +34,7 @@ int check_hip(hipError_t e, const char *where) {
 struct ShapePlan {
     std::vector<int64_t> offsets;  // per tensor (arena byte offsets)
     std::vector<int> th, tw;       // per tensor spatial size for this input size (propagated op by op: any H x W)
+    std::vector<char> skip;        // per op: not executed at this input size (sub-pixel triples: HEAD or PHASE + LATERAL)
     int out_h[CPN_NUM_OUTPUTS], out_w[CPN_NUM_OUTPUTS];  // sizes of the external fp32 outputs (0 = absent)
     int64_t total = 0;
     int64_t max_elems = 0;         // largest tensor of the graph, elements per image
@@ -73,8 +74,18 @@ static void propagate_dims(const cpn_plan *p, int H, int W, ShapePlan &sp) {
     sp.tw.assign(nt, 0);
     for (int i = 0; i < CPN_NUM_OUTPUTS; ++i) sp.out_h[i] = sp.out_w[i] = 0;
     auto bad = [&](const char *m) { sp.error = CPN_E_INVALID; sp.message = m; };
-    for (const cpn_op_desc &o : p->ops) {
+    sp.skip.assign(p->ops.size(), 0);
+    for (size_t oi = 0; oi < p->ops.size(); ++oi) {
+        const cpn_op_desc &o = p->ops[oi];
         if (sp.error) return;
+        if (o.op == CPN_OP_CONV && o.subpixel == CPN_SUBPIXEL_HEAD) {
+            // the decomposition holds for the exact x2 case only (PyTorch's nearest index at any other ratio does not
+            // split into phases): decided per input size
+            const bool exact = p->precision != CPN_PRECISION_F32 && o.src1 >= 0 && o.up1 &&
+                               sp.th[o.src0] == 2 * sp.th[o.src1] && sp.tw[o.src0] == 2 * sp.tw[o.src1];
+            sp.skip[oi] = exact;
+            sp.skip[oi + 1] = sp.skip[oi + 2] = !exact;
+        }
         switch (o.op) {
             case CPN_OP_INPUT: sp.th[o.dst] = H; sp.tw[o.dst] = W; break;
             case CPN_OP_MAXPOOL:
@@ -87,6 +98,15 @@ static void propagate_dims(const cpn_plan *p, int H, int W, ShapePlan &sp) {
             case CPN_OP_CONV_DEFERRED: {
                 int hv, wv;
                 if (o.up0 && o.up1) { bad("conv: both sources resized"); break; }
+                if (o.subpixel == CPN_SUBPIXEL_PHASE) {  // 2 x 2 taps per output phase: the output keeps the source's size
+                    sp.th[o.dst] = sp.th[o.src0]; sp.tw[o.dst] = sp.tw[o.src0];
+                    break;
+                }
+                if (o.subpixel == CPN_SUBPIXEL_SCATTER) {  // conv over the x2-upsampled source (scale_factor = 2)
+                    if (o.dst < 0) { bad("conv: a sub-pixel scatter conv needs a tensor destination"); break; }
+                    sp.th[o.dst] = 2 * sp.th[o.src0]; sp.tw[o.dst] = 2 * sp.tw[o.src0];
+                    break;
+                }
                 if (o.up0 == 2) { hv = H; wv = W; }  // bilinear resize of the source to the INPUT size (cpn.py:277-278)
                 else if (o.up1) { hv = sp.th[o.src0]; wv = sp.tw[o.src0]; }
                 else if (o.up0 && o.src1 >= 0) { hv = sp.th[o.src1]; wv = sp.tw[o.src1]; }
@@ -98,6 +118,7 @@ static void propagate_dims(const cpn_plan *p, int H, int W, ShapePlan &sp) {
                 if (hv + 2 * o.pad < o.kh || wv + 2 * o.pad < o.kw) { bad("input too small for a convolution of the graph"); break; }
                 const int ho = (hv + 2 * o.pad - o.kh) / o.stride + 1, wo = (wv + 2 * o.pad - o.kw) / o.stride + 1;
                 if (o.res >= 0 && !o.res_up && (sp.th[o.res] != ho || sp.tw[o.res] != wo)) { bad("conv: residual size mismatch"); break; }
+                if (o.res >= 0 && o.res_up == 2 && !sp.skip[oi] && (2 * sp.th[o.res] != ho || 2 * sp.tw[o.res] != wo)) { bad("conv: phase tensor size mismatch"); break; }
                 if (o.dst >= 0) { sp.th[o.dst] = ho; sp.tw[o.dst] = wo; }
                 else if (o.out_index >= 0 && o.out_index < CPN_NUM_OUTPUTS) { sp.out_h[o.out_index] = ho; sp.out_w[o.out_index] = wo; }
                 break;
@@ -129,6 +150,7 @@ static const ShapePlan &get_shape_plan(cpn_plan *p, int N, int H, int W) {
     std::vector<int> def(nt, -1), last(nt, -1);
     for (int i = 0; i < (int) p->ops.size(); ++i) {
         const cpn_op_desc &o = p->ops[i];
+        if (sp.skip[i]) continue;  // (the alternative of a sub-pixel triple that does not run at this size)
         if (o.dst >= 0 && def[root[o.dst]] < 0) def[root[o.dst]] = i;
         // (the sources of a deferred conv are read after the run, cpn_sparse_heads: they stay live to the end)
         const int use = o.op == CPN_OP_CONV_DEFERRED ? (int) p->ops.size() : i;
@@ -191,12 +213,23 @@ static int build_conv_args(const cpn_plan *p, const cpn_op_desc &o, int N, ConvA
     a.KH = o.kh; a.KW = o.kw; a.stride = o.stride; a.pad = o.pad;
     a.Hout = (Hin + 2 * o.pad - o.kh) / o.stride + 1;
     a.Wout = (Win + 2 * o.pad - o.kw) / o.stride + 1;
+    a.phase = o.subpixel == CPN_SUBPIXEL_PHASE ? 1 : (o.subpixel == CPN_SUBPIXEL_SCATTER ? 2 : 0);
+    if (a.phase) {  // four 2 x 2 convs (one per output phase, padding (1 - py, 1 - px)) on the low-resolution map
+        if (o.kh != 2 || o.kw != 2 || o.pad != 1 || o.stride != 1 || o.bundles != 4 || s1 || o.up0 || res)
+            return fail(CPN_E_INVALID, "conv: a sub-pixel phase conv is 2x2, pad 1, stride 1, 4 bundles, one plain source");
+        a.Hout = Hin; a.Wout = Win;
+    }
     a.bundles = o.bundles; a.cin_b = o.cin_b; a.cout_b = o.cout_b;
     a.weights = p ? p->weights + o.weight_offset : nullptr;
     a.bias = (p && o.bias_offset >= 0) ? p->bias + o.bias_offset : nullptr;
     a.res = res; a.res_stride = rs; a.res_up = o.res_up;
     a.Hr = (src_dims && o.res_up) ? src_dims[4] : (o.res_up ? a.Hout >> 1 : a.Hout);
     a.Wr = (src_dims && o.res_up) ? src_dims[5] : (o.res_up ? a.Wout >> 1 : a.Wout);
+    if (o.res_up == 2) {
+        if (!res || rs % 4 || 2 * a.Hr != a.Hout || 2 * a.Wr != a.Wout)
+            return fail(CPN_E_INVALID, "conv: a pixel-shuffled residual is a [H/2, W/2, 4 * C] phase tensor");
+        a.res_cph = rs / 4;
+    }
     if (res && (a.Hr <= 0 || a.Wr <= 0)) return fail(CPN_E_INVALID, "conv: empty residual");
     a.ry = (float) a.Hr / (float) a.Hout; a.rx = (float) a.Wr / (float) a.Wout;
     a.act = o.act; a.act_scale = o.act_scale;
@@ -217,13 +250,13 @@ static int build_conv_args(const cpn_plan *p, const cpn_op_desc &o, int N, ConvA
         a.out_inv_scale = o.dst >= 0 ? 1.f / p->tensors[o.dst].scale : 0.f;
     }
     if (o.bundles > 1 && s1) return fail(CPN_E_INVALID, "conv: grouped conv with two sources");
-    if (!s1 && o.c0_used < o.bundles * o.cin_b) return fail(CPN_E_INVALID, "conv: c0_used smaller than input channels");
+    if (!s1 && o.c0_used < (a.phase ? 1 : o.bundles) * o.cin_b) return fail(CPN_E_INVALID, "conv: c0_used smaller than input channels");
     // sources are read through raw buffer descriptors whose out-of-range sentinel is byte offset 2^31 (conv_igemm.hip):
     // a source tensor may hold at most 2^31 BYTES (fp32 verification path: 2^31 elements); destinations are addressed
     // with 32-bit element offsets
     const int64_t src_limit = (p && p->precision == CPN_PRECISION_F32) ? (1ll << 31) : (1ll << 31) / (kc == 64 ? 1 : 2);
     if ((int64_t) N * a.Hs0 * a.Ws0 * c0s >= src_limit || (s1 && (int64_t) N * a.Hs1 * a.Ws1 * c1s >= src_limit) ||
-        (int64_t) N * a.Hout * a.Wout * std::max(ds, 1) >= (1ll << 31))
+        (int64_t) N * a.Hout * a.Wout * (a.phase == 2 ? 4 : 1) * std::max(ds, 1) >= (1ll << 31))
         return fail(CPN_E_UNSUPPORTED, "conv: tensor too large for one launch (sources: 2^31 bytes, destination: 2^31 "
                                        "elements); split the batch");
     // plain 1x1 convs are GEMMs over the flattened pixel axis: re-tile as [1, M/32, 32] so that narrow images
@@ -274,6 +307,21 @@ int cpn_plan_create(cpn_plan **plan, const cpn_tensor_desc *tensors, int32_t n_t
                 delete p;
                 return fail(CPN_E_INVALID, "cpn_plan_create: tensor id out of range");
             }
+        const size_t oi_ = (size_t) (&o - p->ops.data());
+        if (o.subpixel == CPN_SUBPIXEL_HEAD &&
+            (o.op != CPN_OP_CONV || precision == CPN_PRECISION_F32 || oi_ + 2 >= p->ops.size() || p->ops[oi_ + 1].subpixel != CPN_SUBPIXEL_PHASE ||
+             p->ops[oi_ + 2].subpixel != CPN_SUBPIXEL_LATERAL || p->ops[oi_ + 1].op != CPN_OP_CONV ||
+             p->ops[oi_ + 2].op != CPN_OP_CONV || p->ops[oi_ + 2].dst != o.dst || p->ops[oi_ + 2].res != p->ops[oi_ + 1].dst ||
+             p->ops[oi_ + 2].res_up != 2 || p->ops[oi_ + 1].src0 != o.src1 || p->ops[oi_ + 2].src0 != o.src0 || !o.up1 ||
+             o.src1 < 0 || o.dst < 0 || p->ops[oi_ + 1].dst < 0)) {
+            delete p;
+            return fail(CPN_E_INVALID, "cpn_plan_create: malformed sub-pixel triple (HEAD, PHASE, LATERAL)");
+        }
+        if ((o.subpixel == CPN_SUBPIXEL_PHASE && (oi_ < 1 || p->ops[oi_ - 1].subpixel != CPN_SUBPIXEL_HEAD)) ||
+            (o.subpixel == CPN_SUBPIXEL_LATERAL && (oi_ < 2 || p->ops[oi_ - 2].subpixel != CPN_SUBPIXEL_HEAD))) {
+            delete p;
+            return fail(CPN_E_INVALID, "cpn_plan_create: sub-pixel PHASE / LATERAL ops must follow their HEAD op");
+        }
         if (o.op == CPN_OP_CONV_DEFERRED && (precision != CPN_PRECISION_BF16 || o.fuse_cout <= 0 || o.dst >= 0)) {
             delete p;
             return fail(CPN_E_INVALID, "cpn_plan_create: a deferred conv must be a fused ReadOut head of a bf16 plan");
@@ -371,6 +419,7 @@ static int run_or_count(cpn_plan *plan, const void *input, int32_t in_dtype, int
         const cpn_op_desc &o = plan->ops[i];
         int rc = 0;
         if (events) (void) hipEventRecord(events[i], st);
+        if (sp.skip[i]) continue;
         switch (o.op) {
             case CPN_OP_INPUT: {
                 if (flops) break;
@@ -415,7 +464,8 @@ static int run_or_count(cpn_plan *plan, const void *input, int32_t in_dtype, int
                 if (rc) return rc;
                 if (o.dst >= 0) {
                     const int64_t M = (int64_t) N * sp.th[o.dst] * sp.tw[o.dst];
-                    if ((int64_t) a.N * a.Hout * a.Wout != M) return fail(CPN_E_INVALID, "cpn_plan_run: conv output size mismatch");
+                    if ((int64_t) a.N * a.Hout * a.Wout * (a.phase == 2 ? 4 : 1) != M)
+                        return fail(CPN_E_INVALID, "cpn_plan_run: conv output size mismatch");
                 }
                 if (op_flops) op_flops[i] = conv_executed_flops(a);
                 if (flops) { *flops += conv_executed_flops(a); break; }

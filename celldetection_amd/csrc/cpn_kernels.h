@@ -30,8 +30,14 @@ struct ConvArgs {
     const void *weights;        // [bundle][cin_b/32 x KH*KW items (+1 zero item if odd)][cout_b][32] bf16
     const float *bias;          // [bundles*cout_b] fp32 (BN folded) or nullptr
     // epilogue
+    int phase;                  // sub-pixel phase conv (CPN_SUBPIXEL_PHASE): the `bundles` = 4 output phases (py, px) =
+                                // (g >> 1, g & 1) read the SAME cin_b input channels with padding (pad - py, pad - px);
+                                // 2 (CPN_SUBPIXEL_SCATTER): additionally phase g writes channels [0, cout_b) of pixel
+                                // (2 oy + py, 2 ox + px) of a [2 Hout][2 Wout] destination and all phases share one bias
     const void *res;            // residual NHWC bf16 (added before activation) or nullptr
-    int res_stride, res_up;     // res_up: stored at Hr x Wr, nearest-resized to Hout x Wout (FPN top-down path)
+    int res_stride, res_up;     // res_up 1: stored at Hr x Wr, nearest-resized to Hout x Wout (FPN top-down path)
+                                // res_up 2: phase tensor [Hout/2][Wout/2][4 * res_cph], read pixel-shuffled
+    int res_cph;                // res_up 2: channels per phase
     int Hr, Wr;
     float ry, rx;               // float(Hr) / Hout, float(Wr) / Wout
     int act;

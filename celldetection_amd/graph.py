@@ -44,13 +44,18 @@ class Plan:
                          (prefix + 'num_batches_tracked', (), 'long')]
 
     # ---- IR
-    def tensor(self, c, down):
-        self.tensors.append(dict(c=int(c), down=int(down)))
+    def tensor(self, c, down, phases=1):
+        """``phases`` = 4: sub-pixel phase tensor, channel layout [phase (py, px)][padded c] (see ``conv(sub='phase')``)."""
+        self.tensors.append(dict(c=int(c), down=int(down), phases=int(phases)))
         return len(self.tensors) - 1
 
     def conv(self, src0, cout, k, *, w, bn=None, bias=False, stride=1, pad=None, groups=1, act='none', act_scale=0.,
-             src1=None, up0=False, up1=False, res=None, res_up=False, out_index=None, fuse=None, deferred=False):
-        """Adds conv(+BN)(+residual)(+act); returns the destination tensor id (None for external outputs)."""
+             src1=None, up0=False, up1=False, res=None, res_up=False, out_index=None, fuse=None, deferred=False,
+             sub=None, dst=None):
+        """Adds conv(+BN)(+residual)(+act); returns the destination tensor id (None for external outputs).
+        ``sub``: member of a sub-pixel triple (``_subpixel_pair``): 'head' = the conv as the reference states it, ('phase',
+        c0) / ('lateral', c0) = its decomposition (they share the head's state-dict entries and add none); ``dst``: write
+        into an existing tensor (the lateral op writes the head's destination)."""
         pad = k // 2 if pad is None else pad
         t0 = self.tensors[src0]
         if up0 == 'bilinear':  # source read through a bilinear resize to the input size (nominal down factor 1)
@@ -63,15 +68,22 @@ class Plan:
         if src1 is not None and not up1:  # (a resized second source takes the size of the first one: any ratio)
             assert self.tensors[src1]['down'] == down_in
         down_out = down_in * stride
-        dst = self.tensor(cout, down_out) if out_index is None else None
-        self.conv_keys(w, cout, cin // groups, k, bias)
-        if bn is not None:
-            self.bn_keys(bn, cout)
-        if fuse is not None:  # fused ReadOut tail: final 1x1 conv (bias) applied to this conv's activated output
-            self.conv_keys(fuse['w'], fuse['cout'], cout, 1, True)
+        scatter = isinstance(sub, tuple) and sub[0] == 'scatter'  # stands for a 3x3 conv over the x2-upsampled source
+        if scatter:
+            assert t0['down'] % 2 == 0 and src1 is None and not up0 and k == 2
+            down_out = t0['down'] // 2
+        member = isinstance(sub, tuple) and not scatter  # phase / lateral op of a triple: no state-dict entries of its own
+        if dst is None:
+            dst = self.tensor(cout, down_out, phases=4 if (member and sub[0] == 'phase') else 1) if out_index is None else None
+        if not member:
+            self.conv_keys(w, cout, cin // groups, 3 if scatter else k, bias)
+            if bn is not None:
+                self.bn_keys(bn, cout)
+            if fuse is not None:  # fused ReadOut tail: final 1x1 conv (bias) applied to this conv's activated output
+                self.conv_keys(fuse['w'], fuse['cout'], cout, 1, True)
         self.ops.append(dict(op='conv', src0=src0, src1=src1, res=res, dst=dst, up0=up0, up1=up1, res_up=res_up, k=k,
                              stride=stride, pad=pad, groups=groups, cin=cin, cout=cout, w=w, bn=bn, bias=bias, act=act,
-                             act_scale=act_scale, out_index=out_index, fuse=fuse, deferred=bool(deferred)))
+                             act_scale=act_scale, out_index=out_index, fuse=fuse, deferred=bool(deferred), sub=sub))
         return dst
 
     def maxpool(self, src, k, stride, pad):
@@ -97,9 +109,26 @@ class Plan:
 # encoders
 # ---------------------------------------------------------------------------------------------------------------------
 
-def _two_conv_norm_relu(P, x, cout, prefix, bias=True, src1=None, up0=False, up1=False):
-    """TwoConvNormRelu (commons.py:120-149): Sequential(conv, bn, relu, conv, bn, relu) -> indices 0,1,3,4."""
-    x = P.conv(x, cout, 3, w=prefix + '0.', bn=prefix + '1.', bias=bias, act='relu', src1=src1, up0=up0, up1=up1)
+def _two_conv_norm_relu(P, x, cout, prefix, bias=True, src1=None, up0=False, up1=False, subpixel=False):
+    """TwoConvNormRelu (commons.py:120-149): Sequential(conv, bn, relu, conv, bn, relu) -> indices 0,1,3,4.
+    ``subpixel``: the first conv reads cat(x, nearest-upsampled src1) -- emit it as a sub-pixel triple (see
+    include/cpn_hip.h, CPN_SUBPIXEL_*): the conv itself (runs at sizes where the upsampling is not an exact x2), then
+    its decomposition into four 2 x 2 phase convs on the low-resolution map + the lateral conv with the pixel-shuffled
+    partial sums as residual (4/9 of the multiply-accumulates on the upsampled channels)."""
+    if subpixel and src1 is None and up0 is True:
+        # bridge level: the conv's ONLY source is the x2-upsampled map (scale_factor=2: always exact) -> one op, the four
+        # 2 x 2 phase convs + bias + ReLU scattered to their pixels (CPN_SUBPIXEL_SCATTER)
+        x = P.conv(x, cout, 2, w=prefix + '0.', bn=prefix + '1.', bias=bias, act='relu', pad=1, sub=('scatter', 0))
+        return P.conv(x, cout, 3, w=prefix + '3.', bn=prefix + '4.', bias=bias, act='relu')
+    lat = x
+    sub = bool(subpixel) and src1 is not None and up1 and not up0
+    x = P.conv(lat, cout, 3, w=prefix + '0.', bn=prefix + '1.', bias=bias, act='relu', src1=src1, up0=up0, up1=up1,
+               sub='head' if sub else None)
+    if sub:
+        c0 = P.tensors[lat]['c']
+        ph = P.conv(src1, cout, 2, w=prefix + '0.', bn=prefix + '1.', bias=bias, pad=1, sub=('phase', c0))
+        P.conv(lat, cout, 3, w=prefix + '0.', bn=prefix + '1.', bias=bias, act='relu', res=ph, res_up='shuffle',
+               sub=('lateral', c0), dst=x)
     return P.conv(x, cout, 3, w=prefix + '3.', bn=prefix + '4.', bias=bias, act='relu')
 
 
@@ -215,7 +244,7 @@ def _resnet(P, x, in_channels, prefix, kind, base_channel=64, **unused):
 # decoders
 # ---------------------------------------------------------------------------------------------------------------------
 
-def _generalized_unet(P, feats, channels, strides, prefix):
+def _generalized_unet(P, feats, channels, strides, prefix, subpixel=False):
     """GeneralizedUNet (unet.py:62-249), default kwargs: nearest interpolation, cat_order 0, TwoConvNormRelu blocks,
     bridge blocks (bias=False) for the log2(first stride) missing levels.  The 1x1 ``inner`` conv is applied BEFORE
     the nearest upsample (bit-identical per pixel, 4x fewer MACs); the upsample itself and the channel concat are
@@ -246,9 +275,10 @@ def _generalized_unet(P, feats, channels, strides, prefix):
         del P.entries[mark:]
         ouc = out_list[i]
         if lat is not None:
-            last = _two_conv_norm_relu(P, lat, ouc, f'{prefix}layer_blocks.{i}.', bias=True, src1=top, up1=True)
+            last = _two_conv_norm_relu(P, lat, ouc, f'{prefix}layer_blocks.{i}.', bias=True, src1=top, up1=True,
+                                       subpixel=subpixel)
         else:
-            last = _two_conv_norm_relu(P, top, ouc, f'{prefix}layer_blocks.{i}.', bias=False, up0=True)
+            last = _two_conv_norm_relu(P, top, ouc, f'{prefix}layer_blocks.{i}.', bias=False, up0=True, subpixel=subpixel)
         entries_layer[i] = P.entries[mark:]
         del P.entries[mark:]
         results[i] = last
@@ -319,7 +349,8 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
                backbone_kwargs: dict = None, fuse_readout: bool = True, uncertainty_head: bool = False,
                contour_head_channels: int = None, refinement_head_channels: int = None,
                kernel_sizes: dict = None, fuse_bilinear: bool = True, contour_head_stride: int = 1,
-               refinement_head_stride: int = 1, features: dict = None, sparse_heads: bool = False) -> Plan:
+               refinement_head_stride: int = 1, features: dict = None, sparse_heads: bool = False,
+               subpixel: bool = False) -> Plan:
     """Plan of ``Cpn<backbone>`` (celldetection/models/cpn.py:287-439,771-2061; heads: CPNCore.__init__
     cpn.py:125-236).  ``kernel_sizes``: optional {'score'|'location'|'fourier'|'uncertainty'|'refinement': k}
     (the reference's ``kernel_size_<head>`` kwargs, default 7).  ``contour_head_stride`` / ``refinement_head_stride``: stride
@@ -330,7 +361,9 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
     ``sparse_heads``: score-gated location / Fourier heads -- CPN.forward reads their maps at the proposal pixels only
     (cpn.py:613-637), so the two convs are packed but not executed by the graph (``deferred`` ops) and evaluated at the
     proposals by ``ops.sparse_heads``; needs both heads fused, on the same plain feature, stride 1, same kernel size
-    and a hidden width of 128 or 256 (``Plan.meta['sparse_heads']`` = None when the plan does not qualify)."""
+    and a hidden width of 128 or 256 (``Plan.meta['sparse_heads']`` = None when the plan does not qualify).
+    ``subpixel`` (bf16 plans): the first conv of every UNet decoder level (models/unet.py:213-224) additionally carries its
+    sub-pixel decomposition; the executor picks it wherever the top-down map is upsampled by exactly 2."""
     if contour_head_stride not in (1, 2) or refinement_head_stride not in (1, 2):
         raise NotImplementedError('head strides other than 1 and 2 are not supported by the HIP conv kernel')
     feats_cfg = dict(score='1', location='1', contour='1', uncertainty='1', refinement='0')
@@ -360,7 +393,7 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
     wanted = {k for name, v in feats_cfg.items() for k in _keys(v)
               if (name != 'uncertainty' or uncertainty_head) and (name != 'refinement' or refinement)}
     if family == 'unet':
-        results, out_list = _generalized_unet(P, feats, channels, strides, bp + 'unet.')
+        results, out_list = _generalized_unet(P, feats, channels, strides, bp + 'unet.', subpixel=subpixel)
         level = {str(i): (results[i], out_list[i]) for i in results}
         level.update({f'encoder.{i}': (feats[i], channels[i]) for i in range(len(feats))})
     else:
@@ -498,7 +531,7 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=Non
     mparts, op_scales = [], []
     tens = (_lib.TensorDesc * len(plan.tensors))()
     for i, t in enumerate(plan.tensors):
-        tens[i].channels, tens[i].down = _pad(t['c']), t['down']
+        tens[i].channels, tens[i].down = _pad(t['c']) * t.get('phases', 1), t['down']
         tens[i].scale = float(act_scales[i]) if fp8 else 0.
     ops = (_lib.OpDesc * len(plan.ops))()
     wparts, bparts = [], []
@@ -522,6 +555,15 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=Non
         # conv
         w, b = _fold(state_dict, op)
         k, groups, cin, cout = op['k'], op['groups'], op['cin'], op['cout']
+        sub = op.get('sub')
+        if sub is not None and (f32 or fp8):
+            raise ValueError('sub-pixel conv triples are a bf16-plan feature')
+        if isinstance(sub, tuple) and sub[0] == 'lateral':  # the lateral's share of the head conv's weights (+ its bias)
+            w = w[:, :sub[1]]
+        phase = isinstance(sub, tuple) and sub[0] in ('phase', 'scatter')
+        if phase:  # four 2 x 2 kernels on the low-resolution map (tap sums in float64, rounded to bf16 once)
+            from .subpixel import collapse_upsampled_taps
+            w = collapse_upsampled_taps(w[:, sub[1]:]).reshape(4, cout, cin, 2, 2)
         c0 = plan.tensors[op['src0']]['c']
         c0p = _pad(c0)
         c1 = plan.tensors[op['src1']]['c'] if op['src1'] is not None else 0
@@ -535,7 +577,16 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=Non
             else:
                 w *= act_scales[op['src0']]
         geo = _bundle_geometry(cin, cout, groups, KC)
-        if geo is None:
+        if phase:
+            bundles, cin_b, cout_b = 4, cinp, coutp
+            dense = torch.zeros(4, coutp, cinp, 2, 2, dtype=torch.float64)
+            dense[:, :cout, :cin] = w
+            packed = dense.reshape(4, coutp, cinp // KC, KC, 4).permute(0, 2, 4, 1, 3)
+            bias = None  # (partial sums; the lateral op of the triple adds the bias)
+            if sub[0] == 'scatter':  # one bias shared by the four phases
+                bias = torch.zeros(coutp, dtype=torch.float64)
+                bias[:cout] = b
+        elif geo is None:
             dense = torch.zeros(coutp, cinp, k, k, dtype=torch.float64)
             if groups == 1:
                 dense[:cout, :c0] = w[:, :c0]
@@ -597,25 +648,30 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=Non
             if packed.shape[1] % 2:
                 packed = torch.cat((packed, torch.zeros_like(packed[:, :1])), 1)
             wparts.append(packed.contiguous().reshape(-1).to(wdt))
-        bparts.append(bias.to(torch.float32))
+        if bias is not None:
+            bparts.append(bias.to(torch.float32))
         d.op = _lib.OP_CONV_DEFERRED if op.get('deferred') else _lib.OP_CONV
+        d.subpixel = {None: _lib.SUBPIXEL_NONE, 'head': _lib.SUBPIXEL_HEAD, 'phase': _lib.SUBPIXEL_PHASE,
+                      'lateral': _lib.SUBPIXEL_LATERAL, 'scatter': _lib.SUBPIXEL_SCATTER}[sub[0] if isinstance(sub, tuple) else sub]
         d.src0 = op['src0']
         d.src1 = -1 if op['src1'] is None else op['src1']
         d.res = -1 if op['res'] is None else op['res']
         d.dst = -1 if op['dst'] is None else op['dst']
-        d.up0, d.up1, d.res_up = (2 if op['up0'] == 'bilinear' else int(op['up0'])), int(op['up1']), int(op['res_up'])
+        d.up0, d.up1 = (2 if op['up0'] == 'bilinear' else int(op['up0'])), int(op['up1'])
+        d.res_up = 2 if op['res_up'] == 'shuffle' else int(op['res_up'])
         d.c0_used = c0p if op['src1'] is not None else cinp
         d.kh = d.kw = k
         d.stride, d.pad = op['stride'], op['pad']
         d.bundles, d.cin_b, d.cout_b = bundles, cin_b, cout_b
-        d.weight_offset, d.bias_offset = woff, boff
+        d.weight_offset, d.bias_offset = woff, (boff if bias is not None else -1)
         d.act, d.act_scale = _ACT[op['act']], float(op['act_scale'])
         d.out_index = -1 if op['out_index'] is None else op['out_index']
         d.cout_real = cout
         d.fuse_weight_offset = d.fuse_bias_offset = -1
         d.fuse_cout = 0
         woff += wparts[-1].numel() * wsz
-        boff += bparts[-1].numel()
+        if bias is not None:
+            boff += bparts[-1].numel()
         # keep blob offsets 16-byte aligned
         padw = (-wparts[-1].numel()) % (16 if fp8 else 8)
         if padw:
@@ -655,12 +711,14 @@ def reference_flops(plan: Plan, H, W):
     """2*MAC FLOPs of the reference graph per input (convs only, batch 1)."""
     total = 0.
     for op in plan.ops:
-        if op['op'] != 'conv':
+        sub = op.get('sub')
+        if op['op'] != 'conv' or (isinstance(sub, tuple) and sub[0] != 'scatter'):  # (phase / lateral ops restate their head)
             continue
         t0 = plan.tensors[op['src0']]
-        down_in = 1 if op['up0'] == 'bilinear' else t0['down'] // (2 if op['up0'] else 1)
+        scatter = isinstance(sub, tuple)  # stands for the reference's 3x3 conv over the x2-upsampled source
+        down_in = 1 if op['up0'] == 'bilinear' else t0['down'] // (2 if (op['up0'] or scatter) else 1)
         ho, wo = H // (down_in * op['stride']), W // (down_in * op['stride'])
-        f = 2. * ho * wo * op['cout'] * (op['cin'] // op['groups']) * op['k'] ** 2
+        f = 2. * ho * wo * op['cout'] * (op['cin'] // op['groups']) * (3 if scatter else op['k']) ** 2
         # the reference runs the UNet inner 1x1 after the upsample (4x the pixels), unet.py:213-218
         if 'inner_blocks' in op['w'] and '.unet.' in op['w']:
             f *= 4

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CPN_ABI_VERSION 7
+#define CPN_ABI_VERSION 8
 
 #define CPN_E_INVALID (-1)
 #define CPN_E_UNSUPPORTED (-2)
@@ -52,6 +52,26 @@ typedef struct {
  * intact in the workspace until the end of the run (cpn_plan_tensor_info locates it). */
 enum { CPN_OP_INPUT = 0, CPN_OP_CONV = 1, CPN_OP_MAXPOOL = 2, CPN_OP_BILINEAR = 3, CPN_OP_CONV_DEFERRED = 4 };
 enum { CPN_ACT_NONE = 0, CPN_ACT_RELU = 1, CPN_ACT_SIGMOID = 2, CPN_ACT_TANH_SCALED = 3 };
+/* Sub-pixel decomposition of a k = 3 conv over cat(lateral, nearest-x2-upsampled top-down map) -- the first conv of every
+ * GeneralizedUNet decoder level (celldetection/models/unet.py:213-224).  Output pixel (2i+py, 2j+px) sees the upsampled
+ * map through 2 x 2 distinct low-resolution pixels only, so that part of the conv is FOUR 2 x 2 convs on the
+ * low-resolution map (4/9 of the multiply-accumulates, tap sums rounded to bf16 once).  In a plan such a conv is a
+ * triple of consecutive ops:
+ *   CPN_SUBPIXEL_HEAD     the conv as the reference states it (virtual concat + nearest resize in the loader)
+ *   CPN_SUBPIXEL_PHASE    src0 = top-down map, kh = kw = 2, `bundles` = 4 output phases (py, px) that all read the SAME
+ *                         cin_b input channels with padding (pad - py, pad - px); dst = [h/2, w/2, 4 * cout_b] partial
+ *                         sums (no bias, no activation), phase-major channels
+ *   CPN_SUBPIXEL_LATERAL  src0 = lateral, res = the phase tensor read pixel-shuffled (res_up = 2), bias + activation,
+ *                         dst = the HEAD op's dst
+ * The executor runs PHASE + LATERAL when the lateral is exactly twice the top-down map's size and HEAD otherwise
+ * (any other ratio: PyTorch's nearest index does not decompose).
+ *   CPN_SUBPIXEL_SCATTER  a k = 3 conv whose ONLY source is a x2-upsampled map (`scale_factor=2`: always exact; the
+ *                         bridge levels of GeneralizedUNet, unet.py:100-107,213-217) as a single op: the four 2 x 2 phase
+ *                         convs (kh = kw = 2, bundles = 4 sharing cin_b input channels and ONE bias of cout_b entries)
+ *                         + bias + activation, each phase written to its pixels (2i+py, 2j+px) of the [2h, 2w, cout_b]
+ *                         destination.  Replaces the conv it restates (no HEAD op). */
+enum { CPN_SUBPIXEL_NONE = 0, CPN_SUBPIXEL_HEAD = 1, CPN_SUBPIXEL_PHASE = 2, CPN_SUBPIXEL_LATERAL = 3,
+       CPN_SUBPIXEL_SCATTER = 4 };
 enum { CPN_OUT_SCORES = 0, CPN_OUT_LOCATIONS = 1, CPN_OUT_FOURIER = 2, CPN_OUT_REFINEMENT = 3, CPN_OUT_UNCERTAINTY = 4,
        CPN_NUM_OUTPUTS = 5 };
 
@@ -61,6 +81,8 @@ typedef struct {
     int32_t dst;              /* tensor id, or -1 when the op writes an external fp32 NCHW output             */
     int32_t up0, up1, res_up; /* 1: source / residual is nearest-resized (PyTorch 'nearest': floor(dst*in/out)) to the
                                * size of the other concat source / of the output; a lone up0 source: exact x2.
+                               * res_up == 2: the residual is a CPN_SUBPIXEL_PHASE tensor [h/2, w/2, 4 * C] read
+                               * pixel-shuffled: out(y, x, c) += res(y >> 1, x >> 1, ((y & 1) * 2 + (x & 1)) * C + c).
                                * up0 == 2: src0 is read through a BILINEAR resize (align_corners=False) to the input
                                * size H x W (cpn.py:277-278; k x k stride-1 single-source convs of bf16 / fp8 plans) */
     int32_t c0_used;          /* channels of the concat taken from src0 (multiple of 32)                      */
@@ -83,6 +105,7 @@ typedef struct {
     float fuse_act_scale;
     int32_t mult_offset;      /* CPN_PRECISION_FP8: float offset into the bias blob of the per-output-channel
                                * multipliers (weight scales), -1 = none; unused by the other precisions        */
+    int32_t subpixel;         /* CPN_SUBPIXEL_* (bf16 plans)                                                    */
 } cpn_op_desc;
 
 typedef struct cpn_plan cpn_plan;

@@ -197,6 +197,145 @@ def test_conv_register_weight_loop(dev, name, monkeypatch):
     assert (rw - ref).abs().max().item() < 5e-2 * scale
 
 
+SUBPIXEL_CASES = {
+    'sp_64_128_64': dict(n=2, h=32, w=32, c0=64, c1=128, cout=64),
+    'sp_padded_channels': dict(n=1, h=64, w=64, c0=8, c1=16, cout=16),
+    'sp_partial_tiles': dict(n=2, h=40, w=48, c0=32, c1=64, cout=96, seed=3),
+    'sp_flagship_tile': dict(n=8, h=128, w=128, c0=32, c1=64, cout=256, seed=5),
+    'sp_two_cout_blocks': dict(n=4, h=64, w=64, c0=64, c1=64, cout=512, seed=7),
+    'sp_no_bias': dict(n=1, h=32, w=64, c0=32, c1=32, cout=32, bias=False, seed=9),
+}
+
+
+@pytest.mark.parametrize('name', list(SUBPIXEL_CASES))
+def test_subpixel_decoder_conv(dev, name):
+    """Sub-pixel triple of a UNet decoder conv over cat(lateral, nearest-x2-upsampled top-down map)
+    (models/unet.py:213-224): PHASE (four 2x2 convs on the low-resolution map) + LATERAL (3x3 on the lateral, pixel-
+    shuffled partial sums as residual) against (a) an fp32 emulation of exactly that arithmetic on the same bf16-rounded
+    operands -- tap sums rounded to bf16 ONCE, partial sums rounded to bf16 -- and (b) the HEAD conv = the reference's
+    statement of the layer (both approximate the fp32 conv; they differ by the rounding of the tap sums and partials)."""
+    from celldetection_amd import _lib, graph
+    from celldetection_amd.subpixel import collapse_upsampled_taps, phase_padding
+    c = dict(bias=True, seed=0)
+    c.update(SUBPIXEL_CASES[name])
+    n, h, w, c0, c1, cout = (c[k] for k in ('n', 'h', 'w', 'c0', 'c1', 'cout'))
+    g = torch.Generator().manual_seed(c['seed'])
+    P = graph.Plan()
+    lat, top = P.tensor(c0, 1), P.tensor(c1, 2)
+    kw = dict(w='c.', bn='b.', bias=c['bias'])
+    x = P.conv(lat, cout, 3, act='relu', src1=top, up1=True, sub='head', **kw)
+    ph = P.conv(top, cout, 2, pad=1, sub=('phase', c0), **kw)
+    P.conv(lat, cout, 3, act='relu', res=ph, res_up='shuffle', sub=('lateral', c0), dst=x, **kw)
+    sd = {}
+    for key, shape, kind in P.entries:
+        if key.endswith('running_var'):
+            sd[key] = torch.rand(shape, generator=g) + .5
+        elif key.endswith('num_batches_tracked'):
+            sd[key] = torch.zeros((), dtype=torch.long)
+        elif len(shape) == 4:
+            sd[key] = torch.randn(shape, generator=g) / np.sqrt(np.prod(shape[1:]))
+        else:
+            sd[key] = torch.randn(shape, generator=g) * .5 + (1. if key.endswith('b.weight') else 0.)
+    tens, ops, wblob, bblob = graph.pack(P, sd, dev)
+    assert [o.subpixel for o in ops] == [_lib.SUBPIXEL_HEAD, _lib.SUBPIXEL_PHASE, _lib.SUBPIXEL_LATERAL]
+    assert tens[ph].channels == 4 * _pad32(cout)
+    xl = torch.randn(n, c0, h, w, generator=g).to(torch.bfloat16).float()
+    xt = torch.randn(n, c1, h // 2, w // 2, generator=g).to(torch.bfloat16).float()
+    dl, dt = to_nhwc_bf16(xl.to(dev)), to_nhwc_bf16(xt.to(dev))
+    cp = _pad32(cout)
+    lib = _lib.load()
+    nan = float('nan')
+    head = torch.full((n, h, w, cp), nan, dtype=torch.bfloat16, device=dev)
+    part = torch.full((n, h // 2, w // 2, 4 * cp), nan, dtype=torch.bfloat16, device=dev)
+    pair = torch.full((n, h, w, cp), nan, dtype=torch.bfloat16, device=dev)
+    args = (_lib.ptr(wblob), _lib.ptr(bblob), _lib.stream_ptr())
+    _lib.check(lib.cpn_conv2d(ops[0], _lib.ptr(dl), dl.shape[-1], _lib.ptr(dt), dt.shape[-1], _lib.ptr(None), 0,
+                              _lib.ptr(head), cp, n, h, w, *args), 'head')
+    _lib.check(lib.cpn_conv2d(ops[1], _lib.ptr(dt), dt.shape[-1], _lib.ptr(None), 0, _lib.ptr(None), 0,
+                              _lib.ptr(part), 4 * cp, n, h // 2, w // 2, *args), 'phase')
+    _lib.check(lib.cpn_conv2d(ops[2], _lib.ptr(dl), dl.shape[-1], _lib.ptr(None), 0, _lib.ptr(part), 4 * cp,
+                              _lib.ptr(pair), cp, n, h, w, *args), 'lateral')
+    torch.cuda.synchronize()
+    assert torch.isfinite(part.float()).all() and torch.isfinite(pair.float()).all()
+    got, got_head = from_nhwc(pair.cpu(), cout), from_nhwc(head.cpu(), cout)
+    wf, bf = graph._fold(sd, P.ops[0])
+    wc = collapse_upsampled_taps(wf[:, c0:]).float().to(torch.bfloat16).float()  # [py, px, cout, c1, 2, 2]
+    psum = torch.zeros(n, cout, h, w)
+    for py in (0, 1):
+        for px in (0, 1):
+            pt, pl = phase_padding(py), phase_padding(px)
+            psum[:, :, py::2, px::2] = F.conv2d(F.pad(xt, (pl, 1 - pl, pt, 1 - pt)), wc[py, px])
+    got_part = part.cpu().float().reshape(n, h // 2, w // 2, 2, 2, cp)[..., :cout]  # [n, Y, X, py, px, c]
+    got_part = got_part.permute(0, 5, 1, 3, 2, 4).reshape(n, cout, h, w)
+    scale_p = max(psum.abs().max().item(), 1.)
+    assert (got_part - psum).abs().max().item() < 1e-2 * scale_p, 'phase partial sums'
+    ref = F.relu(F.conv2d(xl, wf[:, :c0].float().to(torch.bfloat16).float(), bf.float(), 1, 1)
+                 + psum.to(torch.bfloat16).float())
+    err = (got - ref).abs()
+    scale = max(ref.abs().max().item(), 1.)
+    # the kernel adds ITS bf16-rounded partial sum, which may sit one bf16 ulp (2^-8 relative) from the emulation's
+    bad = (err > 1e-2 * scale + 8e-3 * ref.abs() + 2 ** -7 * psum.abs()).sum().item()
+    print(f'{name}: vs emulation max abs err {err.max().item():.3e} (ref max {scale:.3e}); '
+          f'vs head conv max {(got - got_head).abs().max().item():.3e}')
+    assert bad == 0, f'{name}: {bad} / {err.numel()} elements off the emulated arithmetic'
+    # (b) the decomposition against the reference's statement of the layer: same function, different bf16 roundings
+    full = F.relu(F.conv2d(torch.cat((xl, F.interpolate(xt, scale_factor=2, mode='nearest')), 1), wf.float(), bf.float(), 1, 1))
+    rel_pair = ((got - full).norm() / full.norm()).item()
+    rel_head = ((got_head - full).norm() / full.norm()).item()
+    print(f'{name}: rel L2 vs the fp32 conv: sub-pixel pair {rel_pair:.2e}, head conv {rel_head:.2e}')
+    assert rel_pair < 1e-2 and rel_pair < 2.5 * rel_head + 1e-3
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout,bias', [(2, 32, 32, 64, 64, False), (1, 40, 72, 16, 24, True),
+                                                  (4, 256, 256, 64, 64, False), (2, 64, 64, 32, 256, True)])
+def test_subpixel_bridge_conv(dev, n, h, w, cin, cout, bias):
+    """CPN_SUBPIXEL_SCATTER: the 3x3 conv of a GeneralizedUNet bridge level, whose only source is the x2-upsampled map
+    (models/unet.py:100-107,213-217), as four 2x2 phase convs + bias + ReLU scattered to their output pixels; vs the fp32
+    emulation of that arithmetic (tap sums rounded to bf16 once) and vs the fp32 conv over the upsampled map."""
+    from celldetection_amd import _lib, graph
+    from celldetection_amd.subpixel import collapse_upsampled_taps, phase_padding
+    g = torch.Generator().manual_seed(n * 100 + cout)
+    P = graph.Plan()
+    top = P.tensor(cin, 2)
+    dst = P.conv(top, cout, 2, w='c.', bn='b.', bias=bias, act='relu', pad=1, sub=('scatter', 0))
+    assert P.tensors[dst]['down'] == 1 and [e[1] for e in P.entries if e[0] == 'c.weight'] == [(cout, cin, 3, 3)]
+    sd = {}
+    for key, shape, kind in P.entries:
+        if key.endswith('running_var'):
+            sd[key] = torch.rand(shape, generator=g) + .5
+        elif key.endswith('num_batches_tracked'):
+            sd[key] = torch.zeros((), dtype=torch.long)
+        elif len(shape) == 4:
+            sd[key] = torch.randn(shape, generator=g) / np.sqrt(np.prod(shape[1:]))
+        else:
+            sd[key] = torch.randn(shape, generator=g) * .5 + (1. if key.endswith('b.weight') else 0.)
+    tens, ops, wblob, bblob = graph.pack(P, sd, dev)
+    assert ops[0].subpixel == _lib.SUBPIXEL_SCATTER and ops[0].bundles == 4 and ops[0].kh == 2
+    xt = torch.randn(n, cin, h // 2, w // 2, generator=g).to(torch.bfloat16).float()
+    dt = to_nhwc_bf16(xt.to(dev))
+    cp = _pad32(cout)
+    out = torch.full((n, h, w, cp), float('nan'), dtype=torch.bfloat16, device=dev)
+    _lib.check(_lib.load().cpn_conv2d(ops[0], _lib.ptr(dt), dt.shape[-1], _lib.ptr(None), 0, _lib.ptr(None), 0, _lib.ptr(out),
+                                      cp, n, h // 2, w // 2, _lib.ptr(wblob), _lib.ptr(bblob), _lib.stream_ptr()), 'scatter')
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    got = from_nhwc(out.cpu(), cout)
+    wf, bf = graph._fold(sd, P.ops[0])
+    wc = collapse_upsampled_taps(wf).float().to(torch.bfloat16).float()
+    ref = torch.zeros(n, cout, h, w)
+    for py in (0, 1):
+        for px in (0, 1):
+            pt, pl = phase_padding(py), phase_padding(px)
+            ref[:, :, py::2, px::2] = F.conv2d(F.pad(xt, (pl, 1 - pl, pt, 1 - pt)), wc[py, px], bf.float())
+    ref = F.relu(ref)
+    err = (got - ref).abs()
+    scale = max(ref.abs().max().item(), 1.)
+    bad = (err > 1e-2 * scale + 8e-3 * ref.abs()).sum().item()
+    assert bad == 0, f'{bad} / {err.numel()} elements off; max abs err {err.max().item():.3e}'
+    full = F.relu(F.conv2d(F.interpolate(xt, scale_factor=2, mode='nearest'), wf.float(), bf.float(), 1, 1))
+    assert ((got - full).norm() / full.norm()).item() < 1e-2
+
+
 def test_maxpool_bilinear_input(dev):
     from celldetection_amd import _lib
     lib = _lib.load()

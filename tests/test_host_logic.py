@@ -222,3 +222,86 @@ def test_subpixel_decomposition_is_exact(n, cin, cout, h, w):
     assert got.shape == ref.shape
     torch.testing.assert_close(got, ref, rtol=1e-12, atol=1e-12)
     assert subpixel.collapse_upsampled_taps(wt).shape == (2, 2, cout, cin, 2, 2)
+
+
+def test_subpixel_triple_packing_matches_the_kernel_indexing():
+    """CPU emulation of what conv_igemm does with the packed PHASE / LATERAL ops of a sub-pixel triple (bundle g = phase
+    (g >> 1, g & 1) with padding (1 - py, 1 - px), K items chunk-major / tap-minor, residual read pixel-shuffled) against
+    the reference's statement of the layer: conv3x3(cat(lateral, nearest_x2(top))) (models/unet.py:213-224)."""
+    import torch.nn.functional as F
+    from celldetection_amd import _lib, graph
+    g = torch.Generator().manual_seed(0)
+    n, h, w, c0, c1, cout = 1, 8, 12, 8, 40, 24
+    P = graph.Plan()
+    lat, top = P.tensor(c0, 1), P.tensor(c1, 2)
+    kw = dict(w='c.', bn='b.', bias=True)
+    x = P.conv(lat, cout, 3, act='relu', src1=top, up1=True, sub='head', **kw)
+    ph = P.conv(top, cout, 2, pad=1, sub=('phase', c0), **kw)
+    P.conv(lat, cout, 3, act='relu', res=ph, res_up='shuffle', sub=('lateral', c0), dst=x, **kw)
+    assert len(P.entries) == 7  # one conv + one BN: the member ops add no state-dict entries
+    sd = {}
+    for key, shape, kind in P.entries:
+        sd[key] = torch.zeros((), dtype=torch.long) if kind == 'long' else (
+            torch.rand(shape, generator=g) + .5 if key.endswith('running_var') else torch.randn(shape, generator=g) * .3)
+    tens, ops, wblob, bblob = graph.pack(P, sd, 'cpu')
+    assert (ops[1].kh, ops[1].pad, ops[1].bundles, ops[1].bias_offset, ops[1].subpixel) == (2, 1, 4, -1, _lib.SUBPIXEL_PHASE)
+    assert (ops[2].res_up, ops[2].res, ops[2].dst, ops[2].subpixel) == (2, ph, x, _lib.SUBPIXEL_LATERAL)
+    assert tens[ph].channels == 4 * 32 and ops[0].dst == x and ops[0].subpixel == _lib.SUBPIXEL_HEAD
+    xl, xt = torch.randn(n, c0, h, w, generator=g), torch.randn(n, c1, h // 2, w // 2, generator=g)
+
+    def slab(op, k):  # [bundle][chunk][tap][cout_b][32] float
+        items = (op.cin_b // 32) * k * k
+        cnt = op.bundles * (items + (items & 1)) * op.cout_b * 32
+        wv = wblob[op.weight_offset // 2: op.weight_offset // 2 + cnt].float()
+        return wv.reshape(op.bundles, items + (items & 1), op.cout_b, 32)[:, :items].reshape(op.bundles, op.cin_b // 32, k * k, op.cout_b, 32)
+
+    # PHASE: out[g][co][Y][X] = sum_{chunk, (ky, kx), c} W[g][chunk][ky*2+kx][co][c] * top[chunk*32+c][Y+ky-(1-py)][X+kx-(1-px)]
+    wp = slab(ops[1], 2)
+    xt_p = torch.zeros(n, ops[1].cin_b, h // 2, w // 2)
+    xt_p[:, :c1] = xt
+    part = torch.zeros(n, 4, ops[1].cout_b, h // 2, w // 2)
+    for gph in range(4):
+        py, px = gph >> 1, gph & 1
+        xp = F.pad(xt_p, (1 - px, px, 1 - py, py))  # taps at offsets -(1-p), -(1-p)+1
+        wk = wp[gph].permute(2, 0, 3, 1).reshape(ops[1].cout_b, ops[1].cin_b, 2, 2)  # [co][chunk*32+c][ky][kx]
+        part[:, gph] = F.conv2d(xp, wk)
+    # LATERAL: 3x3 on the lateral + bias + part(y >> 1, x >> 1, phase (y & 1, x & 1)) -> relu
+    wl = slab(ops[2], 3)[0].permute(2, 0, 3, 1).reshape(ops[2].cout_b, ops[2].cin_b, 3, 3)
+    xl_p = torch.zeros(n, ops[2].cin_b, h, w)
+    xl_p[:, :c0] = xl
+    out = F.conv2d(xl_p, wl, bblob[ops[2].bias_offset: ops[2].bias_offset + ops[2].cout_b], padding=1)
+    shuf = part.reshape(n, 2, 2, ops[1].cout_b, h // 2, w // 2).permute(0, 3, 4, 1, 5, 2).reshape(n, ops[1].cout_b, h, w)
+    out = F.relu(out + shuf)[:, :cout]
+    wf, bf = graph._fold(sd, P.ops[0])
+    ref = F.relu(F.conv2d(torch.cat((xl, F.interpolate(xt, scale_factor=2, mode='nearest')), 1), wf.float(), bf.float(), padding=1))
+    assert (out - ref).abs().max().item() < 3e-2 * max(ref.abs().max().item(), 1.)  # bf16 weights vs fp32 weights
+    assert ((out - ref).norm() / ref.norm()).item() < 5e-3
+
+
+def test_subpixel_plans_keep_entries_and_flops_and_switch_per_size():
+    import celldetection_amd as cda
+    from celldetection_amd import _lib, graph
+    from ctypes import c_void_p
+    from celldetection_amd.synth import synth_state_dict
+    m = cda.models.CpnU22(3, backbone_kwargs={'backbone_kwargs': {'base_channels': 32}})
+    assert m.subpixel and sum(1 for op in m._plan.ops if op.get('sub') == 'head') == 4
+    plain = graph.build_plan(**m._plan_kwargs)
+    assert plain.entries == m._plan.entries and all(op.get('sub') is None for op in plain.ops)
+    assert graph.reference_flops(plain, 256, 256) == graph.reference_flops(m._plan, 256, 256)
+    assert all(op.get('sub') is None for p_ in ('fp8', 'fp32') for op in m.plan_for(p_).ops)
+    m.subpixel = False
+    assert all(op.get('sub') is None for op in m.plan_for('bf16').ops)
+    m.subpixel = True
+    sd = synth_state_dict(m.state_dict(), seed=0)
+    lib = _lib.load()
+    fl = {}
+    for name, plan in (('sub', m._plan), ('plain', plain)):
+        tens, ops, wblob, bblob = graph.pack(plan, sd, 'cpu')
+        hdl = c_void_p()
+        _lib.check(lib.cpn_plan_create(hdl, tens, len(tens), ops, len(ops), c_void_p(wblob.data_ptr()), wblob.numel() * 2,
+                                       c_void_p(bblob.data_ptr()), bblob.numel(), _lib.PRECISION_BF16), 'create')
+        fl[name] = {hw: lib.cpn_plan_executed_flops(hdl, 1, *hw) for hw in ((64, 96), (75, 101))}
+        assert lib.cpn_plan_workspace_bytes(hdl, 2, 64, 96) > 0 and lib.cpn_plan_workspace_bytes(hdl, 2, 75, 101) > 0
+        lib.cpn_plan_destroy(hdl)
+    assert fl['sub'][(64, 96)] < .96 * fl['plain'][(64, 96)]      # exact x2 everywhere: the decomposition runs
+    assert fl['sub'][(75, 101)] == fl['plain'][(75, 101)]        # odd sizes: every level falls back to the head conv
