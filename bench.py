@@ -158,11 +158,86 @@ def load_traffic(model, batch, tile, precision):
     return float(e['traffic_bytes_per_graph']), e.get('source')
 
 
+def dry_run_slide(args, world, rank):
+    """--dry-run --workload slide: the slide loop of the product (inference.tiled_inference: tiling, strided tile -> rank
+    sharding, batching, packed variable-length all-gather, redundant global NMS) on CPU ranks with a synthetic per-tile
+    forward (a deterministic function of the tile offset; some tiles yield NO detections) and pure-torch stand-ins for the
+    border rule / NMS kernels.  Ranks may own no tile at all (slide smaller than world x crop).  Every rank checks that
+    its final result equals rank 0's bit for bit.  NOT a measurement."""
+    import hashlib
+    import torch.distributed as td
+    from celldetection_amd import inference
+    S_, O_ = 8, 3
+
+    def forward(tiles, offsets, **kw):
+        out = {k: [] for k in inference.KEYS}
+        for n in range(tiles.shape[0]):
+            ox, oy = int(offsets[n, 0]), int(offsets[n, 1])
+            g = torch.Generator().manual_seed(ox * 7919 + oy + 1)
+            k = ((ox // max(args.stride, 1)) + (oy // max(args.stride, 1))) % 3 * 4  # 0, 4 or 8 detections
+            ctr = torch.rand(k, 1, 2, generator=g) * tiles.shape[-1]
+            con = ctr + torch.rand(k, S_, 2, generator=g) * 12 - 6 + torch.tensor([ox, oy], dtype=torch.float32)
+            out['contours'].append(con)
+            out['contour_proposals'].append(con + 1)
+            out['boxes'].append(torch.cat((con.min(1).values, con.max(1).values), 1))
+            out['scores'].append(torch.rand(k, generator=g))
+            out['classes'].append(torch.ones(k, dtype=torch.int64))
+            out['locations'].append(ctr[:, 0] + torch.tensor([ox, oy], dtype=torch.float32))
+            out['fourier'].append(torch.randn(k, O_, 4, generator=g))
+        return out
+
+    def nms(boxes, scores, thr):  # greedy box NMS, O(K^2), descending score (stable)
+        order = torch.argsort(scores, descending=True, stable=True).tolist()
+        area = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+        keep = []
+        for i in order:
+            ok = True
+            for j in keep:
+                lt, rb = torch.maximum(boxes[i, :2], boxes[j, :2]), torch.minimum(boxes[i, 2:], boxes[j, 2:])
+                inter = (rb - lt).clamp(min=0).prod()
+                if float(inter / (area[i] + area[j] - inter)) > thr:
+                    ok = False
+                    break
+            if ok:
+                keep.append(i)
+        return torch.tensor(keep, dtype=torch.int64)
+
+    class Model:
+        nms_thresh, samples, order = .3, S_, O_
+
+        class core:
+            order = O_
+
+    keep_all = lambda contours, image_index, sides, offsets, size, pad: torch.ones(contours.shape[0], dtype=torch.bool)
+    img = torch.zeros(3, args.slide, args.slide, dtype=torch.uint8)
+    t = {}
+    res = inference.tiled_inference(Model(), img, crop_size=(args.tile, args.tile), strides=(args.stride, args.stride),
+                                    batch_size=args.batch, forward_fn=forward,
+                                    ops_fns=(keep_all, inference.stitch_rule_batched, nms), timings=t)
+    digest = hashlib.sha256(b''.join(res[k].contiguous().numpy().tobytes() for k in inference.KEYS)).digest()[:8]
+    mine = torch.tensor([int.from_bytes(digest, 'little') >> 1, t['tiles_local'], t['detections_local']], dtype=torch.int64)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        td.all_gather(allr, mine)
+        td.barrier()
+    else:
+        allr = [mine]
+    assert all(int(a[0]) == int(allr[0][0]) for a in allr), 'ranks disagree on the final detections'
+    if rank == 0:
+        print(json.dumps({'dry_run': True, 'workload': 'slide', 'n_gpus': world, 'world_size_seen': world,
+                          'backend': args.backend, 'tiles_per_rank': [int(a[1]) for a in allr],
+                          'detections_per_rank': [int(a[2]) for a in allr],
+                          'gathered_detections': t['detections_gathered'], 'final_detections': t['detections_final'],
+                          'identical_on_all_ranks': True}), file=_JSON_OUT, flush=True)
+
+
 def dry_run(args, world, rank):
     """CPU exercise of the launch / rendezvous / sharding / packed all-gather plumbing (no GPU, no kernels): used by
     tests/test_bench_launch.py with --backend gloo.  Prints a JSON line marked dry_run; NOT a measurement."""
     import torch.distributed as td
     from celldetection_amd import inference, util
+    if args.workload == 'slide':
+        return dry_run_slide(args, world, rank)
     S, O = 8, 3
     n_tiles = len(list(util.get_tiling_slices((2048, 2048), (512, 512), (384, 384))[0]))
     mine = inference.shard_tiles(n_tiles, rank, world)
@@ -247,6 +322,8 @@ def main():
         raise SystemExit('bench.py: measurements run on RCCL (--backend nccl); gloo is for --dry-run only')
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
+    if world > 1:  # N ranks on one host: no N-fold oversubscription of the cores while the weights are synthesised
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     if dist:
         import torch.distributed as td
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -324,30 +401,39 @@ def main():
     backbone = None
     dominant = None
     prof = None
+    prof_batch = args.batch
     if rank == 0:
-        try:
-            prof = eng.profile(x, model.core.order, True)
-        except (ValueError, NotImplementedError):  # the engine splits this batch (32-bit addressing limit), or the plan has
-            # score-gated heads: no per-op timing
-            prof = None
+        from celldetection_amd.graph import reference_flops
+        peng = eng
+        if eng.sparse:  # per-op timing needs a plan whose heads all run inside the graph: profile the dense plan's ops
+            model.sparse_heads = False
+            peng = model.engine(dev)
+        prof_batch = peng.max_batch(args.batch, args.tile, args.tile)  # (the engine splits larger batches: 2^31-byte tensors)
+        prof = peng.profile(x[:prof_batch], model.core.order, True)
+        if eng.sparse:
+            model.sparse_heads = True
+            model._engine = eng
     if prof is not None:
         tot = sum(p['ms'] for p in prof)
         bb_ms = sum(p['ms'] for p in prof if p['op'] != 'conv' or 'backbone' in p['name'])
         bb_gf = BACKBONE_GFLOP_PER_TILE.get(args.model) if args.tile == 512 else None
+        if bb_gf is None:
+            bb_gf = reference_flops(model._plan, args.tile, args.tile, only=lambda op: 'backbone' in op['w']) / 1e9
         if bb_gf:
-            backbone = {'ms': bb_ms, 'achieved': bb_gf * args.batch / bb_ms,
-                        'frac': bb_gf * args.batch / bb_ms / (PEAK_BF16_TFLOPS * (2 if args.precision == 'fp8' else 1)),
-                        'algorithmic_gflop': bb_gf * args.batch,
-                        'note': 'backbone conv stack (body + unet incl. input/maxpool helpers) of one per-op-timed graph '
-                                'execution outside the timed region'}
+            backbone = {'ms': bb_ms, 'achieved': bb_gf * prof_batch / bb_ms,
+                        'frac': bb_gf * prof_batch / bb_ms / (PEAK_BF16_TFLOPS * (2 if args.precision == 'fp8' else 1)),
+                        'algorithmic_gflop': bb_gf * prof_batch, 'batch': prof_batch,
+                        'note': 'backbone conv stack (encoder + decoder incl. input/maxpool helpers) of one per-op-timed graph '
+                                'execution outside the timed region; algorithmic FLOPs of the reference graph'}
         # the dominant kernel instantiation, conv_igemm_kernel<8,256,4,2,1>: dense k x k stride-1 convs with >= 256 output
         # channels (8 decoder 3x3 + 3 head 7x7 convs of CpnResNeXt101UNet), from the same per-op timing
         dom = [p for p in prof if p['op'] == 'conv' and (p['k'] or 0) > 1 and p['groups'] == 1 and p['stride'] == 1
-               and (p['cout'] or 0) >= 256 and (p['cin'] or 0) >= 64]
+               and (p['cout'] or 0) >= 256 and (p['cin'] or 0) >= 64 and p['ms'] > 0.02]
         if dom:
             d_ms, d_gf = sum(p['ms'] for p in dom), sum(p['gflop'] for p in dom)
             dominant = {'kernel': 'conv_igemm_kernel<8,256,4,2,1>' if args.precision == 'bf16' else 'cpn_fp8::conv_igemm_kernel<8,256,4,2,1>',
                         'launches_per_graph': len(dom), 'avg_launch_us': 1e3 * d_ms / len(dom), 'gflop_per_graph': d_gf,
+                        'batch': prof_batch,
                         'achieved': d_gf / d_ms, 'frac': d_gf / d_ms / (PEAK_BF16_TFLOPS * (2 if args.precision == 'fp8' else 1)),
                         'share_of_graph_time': d_ms / tot}
         if args.profile_layers:
@@ -372,7 +458,21 @@ def main():
         executed = eng.executed_flops(args.batch, args.tile, args.tile) / 1e9
         traffic, traffic_src = load_traffic(args.model, args.batch, args.tile, args.precision)
         ndet = sum(len(s) for s in y['scores'])
-        n_launch = sum(1 for op in eng.plan.ops if op['op'] == 'conv' and not op.get('deferred'))
+        # conv launches of one graph execution (sub-pixel triples run either their head or their two member ops: per-op
+        # executed FLOPs of the profiled run tell which)
+        n_launch = sum(1 for p in prof if p['op'] == 'conv' and p['gflop'] > 0) - (2 if args.sparse_heads and eng.sparse else 0)
+        rccl_world = td.get_world_size() if dist else None  # None: no process group exists (one rank, RCCL never initialised)
+        gated = None
+        if args.sparse_heads and eng.sparse:
+            # score-gated line: the roofline fraction counts EXECUTED FLOPs (conv graph without the two deferred heads + the
+            # gathered kernel's work on the proposals, padded to its 128-proposal workgroups) over the whole step
+            sc = model.core_forward(x)[0]
+            n_prop = int((sc > model.score_thresh).sum().item())
+            head_px = sc.shape[0] * sc.shape[-2] * sc.shape[-1]
+            per_prop = sum(2. * op['cout'] * op['cin'] * op['k'] ** 2 + 2. * op['fuse']['cout'] * op['cout']
+                           for op in eng.plan.ops if op.get('deferred'))
+            sparse_gf = per_prop * ((n_prop + 127) // 128 * 128) / 1e9
+            gated = dict(proposals=n_prop, head_pixels=head_px, density=n_prop / head_px, sparse_kernel_gflop=sparse_gf)
         out = {
             'metric': f'tiles/sec (3x{args.tile}x{args.tile}) {args.model}', 'value': value, 'unit': 'tiles/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
@@ -382,20 +482,32 @@ def main():
                                       == ('CpnResNeXt101UNet', 16, 512, 'bf16') else '')
                                    + ', synthetic weights of the reference shapes',
                        'tiles_per_gpu_per_step': args.batch, 'detections_last_step': ndet,
-                       'world_size_seen_by_rccl': world,
+                       'world_size_seen_by_rccl': rccl_world,
                        'parallelism': f'tile-sharded x{world}, one process per GPU, no data-path collective',
                        'step_mode': 'forward() per step' if not args.pipeline else
                        'forward_pipelined(): post-processing of step i overlaps the conv graph of step i+1',
                        'heads': 'score-gated location / Fourier heads (exact; evaluated at the proposals only, outside the '
                                 'HIP-event bracket of the conv graph)' if args.sparse_heads else 'dense (reference graph)'},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                         'traffic': traffic, 'traffic_source': traffic_src,
+                         'traffic': traffic if not (args.sparse_heads or args.no_subpixel) else None, 'traffic_source': traffic_src,
                          'kernel': f'conv_igemm_kernel: one conv-graph execution = {n_launch} launches of the kernel family '
                                    '(+ input/maxpool helpers), timed with HIP events on the launch stream',
                          'launch_ms': conv_ms, 'algorithmic_gflop_per_launch': gf * args.batch,
                          'executed_gflop_per_launch': executed, 'executed_frac': executed / conv_ms / peak,
                          'backbone_stack': backbone, 'dominant_kernel': dominant},
         }
+        if gated is not None:
+            step_ms = 1e3 * dt / args.steps
+            ex = executed + gated['sparse_kernel_gflop']
+            out['config']['proposal_density'] = gated['density']
+            out['config']['proposals_per_step'] = gated['proposals']
+            out['roofline'].update({
+                'achieved': ex / step_ms, 'frac': ex / step_ms / peak,
+                'frac_basis': 'EXECUTED FLOPs (conv graph without the two deferred heads + the gathered head kernel on the '
+                              'proposals) / whole step time: the gathered kernel runs in the post-processing, outside the '
+                              'HIP-event bracket of the conv graph',
+                'executed_gflop_per_step': ex, 'sparse_kernel_gflop_per_step': gated['sparse_kernel_gflop'],
+                'algorithmic_frac': gf * args.batch / step_ms / peak})
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(sd, args.tile)
         print(json.dumps(out), file=_JSON_OUT, flush=True)
@@ -448,7 +560,7 @@ def slide_workload(args, model, dev, world, rank, dist):
             'config': {'workload': f'{args.model} tiled inference over a synthetic 1x3x{S}x{S} uint8 slide, {ntiles} tiles '
                                    f'{args.tile}/{args.stride}, batch {args.batch}, tile-shard + RCCL gather + global NMS'
                                    + (' (BASELINE.json configs[3])' if (S, args.tile, args.stride) == (16384, 512, 384) else ''),
-                       'tiles_total': ntiles, 'world_size_seen_by_rccl': world,
+                       'tiles_total': ntiles, 'world_size_seen_by_rccl': td.get_world_size() if dist else None,
                        'parallelism': f'tile i -> rank i mod {world}; one packed all-gather of the detections; global NMS on every rank',
                        'tile_loop_ms': 1e3 * t_tiles / args.steps, 'gather_ms': 1e3 * t_gather / args.steps,
                        'global_nms_ms': 1e3 * t_nms / args.steps,

@@ -707,11 +707,14 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=Non
     return tens, ops, wblob, bblob
 
 
-def reference_flops(plan: Plan, H, W):
-    """2*MAC FLOPs of the reference graph per input (convs only, batch 1)."""
+def reference_flops(plan: Plan, H, W, only=None):
+    """2*MAC FLOPs of the reference graph per input (convs only, batch 1).  ``only``: optional
+    predicate on the op dict (e.g. the backbone stack: ``lambda op: 'backbone' in op['w']``)."""
     total = 0.
     for op in plan.ops:
         sub = op.get('sub')
+        if only is not None and op['op'] == 'conv' and not only(op):
+            continue
         if op['op'] != 'conv' or (isinstance(sub, tuple) and sub[0] != 'scatter'):  # (phase / lateral ops restate their head)
             continue
         t0 = plan.tensors[op['src0']]

@@ -25,13 +25,19 @@ def dict2model(conf, updated_kwargs=True, **kwargs):
         key, = conf.keys()
         if key not in ('model', 'lightning_model') and getattr(src, key, None) is not None:
             return getattr(src, key)(**conf[key])
-    kw = conf.get('kwargs', conf.get('kw', {}))
+
+    def field(*names, default=None):  # first spelling of a field that the config holds (long form, short form)
+        return next((conf[n] for n in names if n in conf), default)
+
+    # precedence (lowest to highest): stored constructor kwargs < attributes changed after construction < caller's kwargs
+    kw = dict(field('kwargs', 'kw', default={}))
     if updated_kwargs:
-        kw = {**kw, **conf.get('updated_kwargs', {})}
-    kw = {**kw, **kwargs}
-    name = conf.get('lightning_model', conf.get('model'))
-    assert name is not None, 'Config should define either ``lightning_model`` or ``model``.'
-    args = conf.get('args', conf.get('a', ()))
+        kw.update(conf.get('updated_kwargs', {}))
+    kw.update(kwargs)
+    name = field('lightning_model', 'model')
+    if name is None:
+        raise AssertionError("the model config needs a 'model' (or 'lightning_model') entry")
+    args = field('args', 'a', default=())
     if isfile(name):
         return load_model(name, **kw)
     if hasattr(src, name):

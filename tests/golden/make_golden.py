@@ -226,7 +226,14 @@ def flat_outputs(prefix, y, out):
             out[f'{prefix}.{k}.{i}'] = npy(t)
 
 
-MODEL_CALIBRATION = {'CpnU22_classes4': dict(score_shift=-3.5)}  # per-spec calibrate_heads arguments
+# per-spec calibrate_heads arguments.  The head-option / odd-size models have coarse head grids (stride 4: 16 x 24 pixels):
+# denser scores and smaller contours so that >= 30 detections per image survive the NMS (with 1..8 kept
+# detections the keep-index part of those fixtures pinned almost nothing)
+MODEL_CALIBRATION = {'CpnU22_classes4': dict(score_shift=-3.5),
+                     'CpnU22_strided': dict(score_shift=0., fourier_std=.12, location_std=.3),
+                     'CpnU22_odd': dict(score_shift=-1.5, fourier_std=.25, location_std=.4),
+                     'CpnResNet50UNet_feats': dict(score_shift=-.3, fourier_std=.25, location_std=.4),
+                     'CpnResNet18FPN_fuse': dict(score_shift=-.5, fourier_std=.4, location_std=.4)}
 
 
 def gen_model(name, seed=0):
@@ -358,8 +365,27 @@ def gen_stitch_dups():
     save('stitch_dups.npz', **out)
 
 
+def gen_checkpoint():
+    """G9: a model file written by the reference's OWN ``save_fetchable_model`` (util/util.py:545-560) -- tiny CpnU22 with one
+    attribute changed after construction (-> ``updated_kwargs``) -- plus the reference's outputs for one input.  The file
+    holds only builtins and tensors ({'cd.__version__', 'cd.models': {model, kwargs, updated_kwargs}, 'state_dict'})."""
+    model, _, shape = build_ref_model('CpnU22', 0, score_shift=-1.5, fourier_std=.4, location_std=.4)
+    model.score_thresh = .85
+    model.samples = 24
+    path = os.path.join(HERE, 'ref_checkpoint_CpnU22.pt')
+    cd.save_fetchable_model(model, path, append_hash=False)
+    x = torch.rand(1, *shape[1:], generator=torch.Generator().manual_seed(11))
+    out = {'x': npy(x)}
+    with torch.no_grad():
+        flat_outputs('nms', model(x), out)
+    print('checkpoint:', os.path.getsize(path) // 1024, 'KiB; detections', [len(t) for t in model(x)['scores']])
+    save('ref_checkpoint_CpnU22_outputs.npz', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['ops', 'tiling', 'models', 'stitch']
+    which = sys.argv[1:] or ['ops', 'tiling', 'models', 'stitch', 'checkpoint']
+    if 'checkpoint' in which:
+        gen_checkpoint()
     if 'ops' in which:
         gen_ops()
     if 'tiling' in which:

@@ -43,3 +43,17 @@ def test_single_rank_dry_run():
 def test_world_size_mismatch_fails():
     r = _run(['--gpus', '2', '--dry-run'], env=dict(WORLD_SIZE='1', RANK='0', LOCAL_RANK='0'))
     assert r.returncode != 0 and 'WORLD_SIZE=1' in (r.stderr + r.stdout)
+
+
+@pytest.mark.parametrize('slide,tiles', [(900, [3, 2, 2, 2]), (600, [1, 1, 1, 1]), (512, [1, 0, 0, 0])])
+def test_four_rank_slide_dry_run_ragged_counts(slide, tiles):
+    """the slide workload's loop (tiling, sharding, batching, packed variable-length all-gather,
+    redundant global NMS) on 4 gloo ranks with ragged per-rank counts -- tiles without detections, ranks without
+    detections, ranks without a single tile -- must give the identical result on every rank."""
+    r = _run(['--gpus', '4', '--backend', 'gloo', '--dry-run', '--workload', 'slide', '--slide', str(slide), '--batch', '2'])
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert d['identical_on_all_ranks'] and d['n_gpus'] == 4 and d['tiles_per_rank'] == tiles
+    assert d['gathered_detections'] == sum(d['detections_per_rank']) and d['final_detections'] <= d['gathered_detections']
+    if slide == 900:
+        assert 0 in d['detections_per_rank'] or min(d['detections_per_rank']) < max(d['detections_per_rank'])

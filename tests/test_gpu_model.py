@@ -173,6 +173,26 @@ def test_fetchable_model_roundtrip(dev, tmp_path):
         assert torch.equal(p, q)
 
 
+def test_checkpoint_written_by_the_reference_loads_and_reproduces_its_outputs(dev):
+    """tests/golden/ref_checkpoint_CpnU22.pt was written by the REFERENCE's own ``save_fetchable_model``
+    (util/util.py:545-560; generator: make_golden.py gen_checkpoint) with two attributes changed after construction
+    (``updated_kwargs``): ``cda.load_model`` must build the same model, and the fp32 path must reproduce the reference's
+    detections for the recorded input (index sets exact, coordinates within 1e-4)."""
+    import celldetection_amd as cda
+    from model_specs import G
+    model = cda.load_model(os.path.join(G, 'ref_checkpoint_CpnU22.pt'), map_location=dev)
+    assert type(model).__name__ == 'CpnU22' and model.score_thresh == .85 and model.samples == 24
+    g = np.load(os.path.join(G, 'ref_checkpoint_CpnU22_outputs.npz'))
+    x = torch.as_tensor(g['x']).to(dev)
+    model.precision = 'fp32'
+    assert len(g['nms.scores.0']) >= 20
+    check_exact('nms', model(x), g, 1, raw_atol=5e-4)
+    model.precision = 'bf16'
+    y = model(x)
+    rate = _iou_match_rate(y['boxes'][0].cpu().numpy(), g['nms.boxes.0'])
+    assert rate > .9, rate
+
+
 def test_tiled_inference_stitching(dev):
     """Slide-level loop (tiling -> forward(offsets) -> border removal -> global NMS) on the GPU:
     (1) exact agreement with the oracle's stitching applied to the SAME per-tile GPU detections,

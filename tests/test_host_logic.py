@@ -305,3 +305,23 @@ def test_subpixel_plans_keep_entries_and_flops_and_switch_per_size():
         lib.cpn_plan_destroy(hdl)
     assert fl['sub'][(64, 96)] < .96 * fl['plain'][(64, 96)]      # exact x2 everywhere: the decomposition runs
     assert fl['sub'][(75, 101)] == fl['plain'][(75, 101)]        # odd sizes: every level falls back to the head conv
+
+
+def test_reference_written_checkpoint_loads_on_the_host():
+    """The model-file format is the reference's (util/util.py:545-560): a file written by the reference's own
+    save_fetchable_model (fixture generated by make_golden.py gen_checkpoint) builds the same class with the constructor
+    kwargs overridden by the attributes that were changed after construction, and every tensor of its state dict."""
+    import os
+    import celldetection_amd as cda
+    from model_specs import G
+    path = os.path.join(G, 'ref_checkpoint_CpnU22.pt')
+    raw = torch.load(path, weights_only=True)  # builtins + tensors only: nothing of the reference is pickled
+    assert set(raw) == {'cd.__version__', 'cd.models', 'state_dict'}
+    model = cda.load_model(path)
+    assert type(model).__name__ == raw['cd.models']['model'] == 'CpnU22'
+    assert raw['cd.models']['updated_kwargs'] == {'score_thresh': .85, 'samples': 24}
+    assert (model.score_thresh, model.samples, model.nms_thresh) == (.85, 24, raw['cd.models']['kwargs']['nms_thresh'])
+    sd = model.state_dict()
+    assert list(sd) == list(raw['state_dict']) and all(torch.equal(sd[k], v) for k, v in raw['state_dict'].items())
+    d = cda.util.model2dict(model)  # and back: the description this build writes for that model
+    assert d['model'] == 'CpnU22' and d['kwargs']['backbone_kwargs'] == raw['cd.models']['kwargs']['backbone_kwargs']
