@@ -353,7 +353,7 @@ def main():
         # steps run this same function so that the caching allocator is in steady state (no hipMalloc while timing)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        state['maps'] = model.core_forward(x)
+        state['maps'] = model.core_forward(x, _static_ok=True)  # (consumed right below, before the slot is re-used)
         e1.record()
         events.append((e0, e1))
         state['y'] = model.postprocess(*state['maps'], (args.tile, args.tile), flag=model._last_flag,

@@ -82,6 +82,7 @@ class _Engine:
         self.sparse = plan.meta.get('sparse_heads') if precision == 'bf16' else None  # dict(ops=(i, j), src=tensor id)
         self._ws_ring, self._ws_turn = [None, None], 0
         self.last_sparse = None
+        self._graphs, self._graph_seen, self._graph_broken = {}, {}, False  # hipGraph slots per run shape (see run())
 
     def __del__(self):
         handle, self.handle = getattr(self, 'handle', None), None
@@ -151,38 +152,31 @@ class _Engine:
         self.run(x, order_total, refinement, _absmax=absmax)
         return absmax.cpu()
 
-    def run(self, x: torch.Tensor, order_total: int, refinement: bool, _timed=None, _absmax=None):
-        """x: [N,C,H,W] float32 in [0,1] (or uint8) on self.device -> (scores, locations, refinement, fourier, flag)."""
-        lib = _lib.load()
-        n, _, h, w = x.shape
-        if x.dtype == torch.uint8:
-            dt = 1
-        else:
-            dt = 0
-            if x.dtype != torch.float32:
-                x = x.float()
-        x = x.contiguous()
+    # ---- hipGraph replay of the conv graph -------------------------------------------------------------------------
+    # One conv-graph execution is ~120 dependent launches, most of them tens of microseconds long: replaying them as ONE
+    # hipGraph removes the host-side launch gaps (profiles/r03_graph_probe.txt: 29.68 -> 29.29 ms for the BASELINE
+    # configs[2] batch).  A shape is captured the second time it is seen, into GRAPH_SLOTS instances that are used in turn:
+    # each owns its input copy, arena, head maps and range flag, so the post-processing of run i (second stream of
+    # forward_pipelined) can still read slot i while run i+1 replays another slot.  CPN_HIP_GRAPH=0 disables it.
+    GRAPH_SLOTS = 3
+    GRAPH_SHAPES = 4  # captured shapes kept (least recently used evicted)
+
+    def _alloc_outputs(self, n, h, w, order_total, refinement, gated):
         f32 = dict(dtype=torch.float32, device=self.device)
         meta = self.plan.meta
         # head grids: any H x W (sizes propagated by the executor; heads may read different features / use a stride)
         scores = torch.empty((n, meta.get('score_channels', 1)) + self.output_size(h, w, _lib.OUT_SCORES), **f32)
-        gated = bool(self.sparse) and _timed is None and _absmax is None
-        if self.sparse and not gated:
-            raise NotImplementedError('per-op profiling / calibration runs need a plan without score-gated heads')
         locations = None if gated else torch.empty((n, 2) + self.output_size(h, w, _lib.OUT_LOCATIONS), **f32)
         fourier = None if gated else torch.empty((n, 4 * order_total) + self.output_size(h, w, _lib.OUT_FOURIER), **f32)
         ref = torch.empty((n, 2 * meta.get('refinement_buckets', 1)) + self.output_size(h, w, _lib.OUT_REFINEMENT),
                           **f32) if refinement else None
-        self.last_uncertainty = torch.empty((n, 4) + self.output_size(h, w, _lib.OUT_UNCERTAINTY), **f32) \
+        unc = torch.empty((n, 4) + self.output_size(h, w, _lib.OUT_UNCERTAINTY), **f32) \
             if meta.get('uncertainty_head') else None
-        flag = torch.zeros(1, dtype=torch.int32, device=self.device)
-        nb = self.max_batch(n, h, w)
-        if _timed is not None and nb < n:
-            raise ValueError('per-op profiling needs a batch whose tensors stay below 2^31 elements')
-        if gated and nb < n:  # (CPN.core_forward routes such batches to the dense plan)
-            raise NotImplementedError('score-gated heads need the whole batch in one graph run (tensors below 2^31 bytes)')
-        ws, need = self.workspace(nb, h, w)
-        outputs = (scores, locations, fourier, ref, self.last_uncertainty)
+        return scores, locations, fourier, ref, unc
+
+    def _launch(self, x, dt, h, w, ws, need, outputs, flag, nb, _timed=None, _absmax=None):
+        lib = _lib.load()
+        n = x.shape[0]
         for i0 in range(0, n, nb):
             m = min(nb, n - i0)
             xi = x[i0:i0 + m]
@@ -198,6 +192,96 @@ class _Engine:
             else:
                 _lib.check(lib.cpn_plan_run(self.handle, _lib.ptr(xi), dt, m, h, w, _lib.ptr(ws), need, outs,
                                             _lib.ptr(flag), _lib.stream_ptr()), 'plan_run')
+
+    def _graph_slot(self, key, x, dt, order_total, refinement, gated):
+        """The hipGraph instance to replay for this run, or None (shape seen for the first time / graphs disabled)."""
+        import os
+        if os.environ.get('CPN_HIP_GRAPH', '1') == '0' or self._graph_broken:
+            return None
+        st = self._graphs.get(key)
+        if st is None:
+            self._graph_seen[key] = self._graph_seen.get(key, 0) + 1
+            if self._graph_seen[key] < 2:
+                return None
+            while len(self._graphs) >= self.GRAPH_SHAPES:  # evict the least recently used shape (frees its arenas)
+                self._graphs.pop(next(iter(self._graphs)))
+            st = self._graphs[key] = dict(slots=[], turn=0)
+        else:
+            self._graphs[key] = self._graphs.pop(key)  # most recently used last
+        if len(st['slots']) < self.GRAPH_SLOTS:
+            n, _, h, w = x.shape
+            need = int(_lib.load().cpn_plan_workspace_bytes(self.handle, n, h, w))
+            slot = dict(x=torch.empty_like(x), ws=torch.empty(max(need, 1), dtype=torch.uint8, device=self.device),
+                        need=need, outputs=self._alloc_outputs(n, h, w, order_total, refinement, gated),
+                        flag=torch.zeros(1, dtype=torch.int32, device=self.device))
+            cur = torch.cuda.current_stream(self.device)
+            side = torch.cuda.Stream(self.device)
+            side.wait_stream(cur)
+            try:
+                with torch.cuda.stream(side):
+                    slot['x'].copy_(x)
+                    # eager run on the capture stream first: per-device function attributes (dynamic LDS limit) are set on
+                    # the first launch of every kernel instantiation, which must not happen inside a capture
+                    self._launch(slot['x'], dt, h, w, slot['ws'], need, slot['outputs'], slot['flag'], n)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=side, capture_error_mode='relaxed'):
+                        slot['flag'].zero_()
+                        self._launch(slot['x'], dt, h, w, slot['ws'], need, slot['outputs'], slot['flag'], n)
+                slot['graph'] = g
+            except Exception as e:  # capture is an optimisation: fall back to eager launches, loudly
+                import warnings
+                warnings.warn(f'hipGraph capture of the conv graph failed ({type(e).__name__}: {e}); using eager launches',
+                              RuntimeWarning)
+                self._graph_broken = True
+                self._graphs.pop(key, None)
+                return None
+            finally:
+                cur.wait_stream(side)
+            st['slots'].append(slot)
+            st['turn'] = len(st['slots']) % self.GRAPH_SLOTS
+            return slot
+        slot = st['slots'][st['turn']]
+        st['turn'] = (st['turn'] + 1) % self.GRAPH_SLOTS
+        return slot
+
+    def run(self, x: torch.Tensor, order_total: int, refinement: bool, _timed=None, _absmax=None, static_ok=False):
+        """x: [N,C,H,W] float32 in [0,1] (or uint8) on self.device -> (scores, locations, refinement, fourier, flag).
+        ``static_ok``: the caller consumes the outputs before this engine runs GRAPH_SLOTS more times (the forward paths
+        do); otherwise outputs that live in a hipGraph slot are cloned."""
+        lib = _lib.load()
+        n, _, h, w = x.shape
+        if x.dtype == torch.uint8:
+            dt = 1
+        else:
+            dt = 0
+            if x.dtype != torch.float32:
+                x = x.float()
+        x = x.contiguous()
+        gated = bool(self.sparse) and _timed is None and _absmax is None
+        if self.sparse and not gated:
+            raise NotImplementedError('per-op profiling / calibration runs need a plan without score-gated heads')
+        nb = self.max_batch(n, h, w)
+        if _timed is not None and nb < n:
+            raise ValueError('per-op profiling needs a batch whose tensors stay below 2^31 elements')
+        if gated and nb < n:  # (CPN.core_forward routes such batches to the dense plan)
+            raise NotImplementedError('score-gated heads need the whole batch in one graph run (tensors below 2^31 bytes)')
+        slot = None
+        if _timed is None and _absmax is None and nb == n and self.precision != 'fp32':
+            slot = self._graph_slot((n, h, w, dt, order_total, bool(refinement)), x, dt, order_total, refinement, gated)
+        if slot is not None and 'graph' in slot:
+            slot['x'].copy_(x, non_blocking=True)
+            slot['graph'].replay()
+            scores, locations, fourier, ref, self.last_uncertainty = slot['outputs']
+            flag, ws = slot['flag'], slot['ws']
+            if not static_ok:
+                scores, locations, fourier, ref, self.last_uncertainty, flag = (
+                    None if t is None else t.clone() for t in (scores, locations, fourier, ref, self.last_uncertainty, flag))
+        else:
+            scores, locations, fourier, ref, self.last_uncertainty = self._alloc_outputs(n, h, w, order_total, refinement, gated)
+            flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+            ws, need = self.workspace(nb, h, w)
+            self._launch(x, dt, h, w, ws, need, (scores, locations, fourier, ref, self.last_uncertainty), flag, nb,
+                         _timed=_timed, _absmax=_absmax)
         if ref is not None and tuple(ref.shape[2:]) != (h, w):  # strided refinement head: `_equal_size(.., inputs)`, cpn.py:279
             ref = _equal_size(ref, x)
         self.last_sparse = None
@@ -388,8 +472,9 @@ class CPN(nn.Module):
 
     # ---- forward --------------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def core_forward(self, inputs: torch.Tensor):
-        """CPNCore.forward (cpn.py:238-283) -> (scores(sigmoid applied), locations, refinement, fourier)."""
+    def core_forward(self, inputs: torch.Tensor, _static_ok: bool = False):
+        """CPNCore.forward (cpn.py:238-283) -> (scores(sigmoid applied), locations, refinement, fourier).
+        (``_static_ok``: internal -- the forward paths consume the maps before the engine re-uses their hipGraph slot.)"""
         eng = self.engine(inputs.device, calibration_input=inputs)
         if eng.sparse and eng.max_batch(inputs.shape[0], *inputs.shape[-2:]) < inputs.shape[0]:
             # the engine has to split this batch (2^31-byte tensors), but the gathered heads read the heads' source of the
@@ -401,7 +486,8 @@ class CPN(nn.Module):
                 finally:
                     self.sparse_heads = sh
             eng = self._engine_dense
-        scores, locations, refinement, fourier, flag = eng.run(inputs, self.core.order, self.refinement)
+        scores, locations, refinement, fourier, flag = eng.run(inputs, self.core.order, self.refinement,
+                                                               static_ok=_static_ok)
         self._last_flag = flag
         self._last_uncertainty = eng.last_uncertainty  # fifth CPNCore output (cpn.py:283), [N,4,h,w] or None
         self._last_sparse = eng.last_sparse  # score-gated heads: locations / fourier are None, evaluated in postprocess
@@ -414,7 +500,7 @@ class CPN(nn.Module):
         if not inputs.is_cuda:
             raise RuntimeError('celldetection_amd.CPN.forward needs GPU inputs (no CPU fallback).')
         original_size = tuple(inputs.shape[-2:])
-        scores, locations, refinement, fourier = self.core_forward(inputs)
+        scores, locations, refinement, fourier = self.core_forward(inputs, _static_ok=True)
         return self.postprocess(scores, locations, refinement, fourier, original_size, nms=nms, flag=self._last_flag,
                                 uncertainty=self._last_uncertainty, sparse=self._last_sparse, **kwargs)
 
@@ -464,7 +550,7 @@ class CPN(nn.Module):
                 if _events is not None:  # (start, end) HIP events around the conv graph, on its launch stream
                     e0 = torch.cuda.Event(enable_timing=True)
                     e0.record(s_conv)
-                maps = self.core_forward(x)
+                maps = self.core_forward(x, _static_ok=True)
                 ev = torch.cuda.Event(enable_timing=_events is not None)
                 ev.record(s_conv)
                 if _events is not None:

@@ -68,6 +68,11 @@ def _lib():
             fn.restype, fn.argtypes = res, args
         if lib.H5open() < 0:
             raise RuntimeError('H5open failed')
+        # hid_t is a 64-bit integer since HDF5 1.10 (a 32-bit int before): this binding declares it as int64
+        maj, mnr, rel = c_uint(0), c_uint(0), c_uint(0)
+        lib.H5get_libversion.argtypes = [POINTER(c_uint)] * 3
+        if lib.H5get_libversion(maj, mnr, rel) < 0 or (maj.value, mnr.value) < (1, 10):
+            raise RuntimeError(f'libhdf5 {maj.value}.{mnr.value}.{rel.value} is too old: HDF5 >= 1.10 (64-bit hid_t) is required')
         lib.H5Eset_auto2(0, None, None)  # no error stack printing: failures are raised as Python exceptions
         _H = lib
     return _H
@@ -110,7 +115,20 @@ def to_h5(filename, mode='w', chunks=None, compression=None, overwrite=False, dr
     lib = _lib()
     attributes = attributes or {}
     fn = os.fsencode(filename)
-    if mode in ('w', 'w-', 'x') or not os.path.isfile(filename):
+    # h5py.File mode semantics: 'w' create / truncate; 'w-' and 'x' create, fail if the file exists; 'r+' read/write, the
+    # file must exist; 'a' read/write if it exists, create otherwise
+    exists = os.path.isfile(filename)
+    if mode not in ('w', 'w-', 'x', 'r+', 'a'):
+        raise ValueError(f"to_h5: mode must be one of 'w', 'w-', 'x', 'r+', 'a' (got {mode!r})")
+    if mode in ('w-', 'x') and exists:
+        raise FileExistsError(f'to_h5: {filename} exists (mode {mode!r})')
+    if mode == 'r+' and not exists:
+        raise FileNotFoundError(f'to_h5: {filename} does not exist (mode {mode!r})')
+    if chunks is not None or compression is not None or driver is not None or create_dataset_kw:
+        import warnings
+        warnings.warn('to_h5: chunks / compression / driver / create_dataset_kw are not supported by the libhdf5 binding: '
+                      'datasets are written contiguous and uncompressed', RuntimeWarning, stacklevel=2)
+    if mode in ('w', 'w-', 'x') or not exists:
         f = _check(lib.H5Fcreate(fn, _F_TRUNC, 0, 0), f'create {filename}')
     else:
         f = _check(lib.H5Fopen(fn, _F_RDWR, 0), f'open {filename}')

@@ -102,6 +102,45 @@ def _lists_to_flat(y, device):
     return flat, counts
 
 
+COMPACT_EVERY = 8  # batches whose pre-filter detections are kept alive before the kept rows are selected (one host sync)
+
+
+def _compact(pending, keys):
+    """[(flat dict, keep mask, *extra per-row tensors)] -> ONE entry holding only the kept rows (bounds the memory of the
+    slide loop: without it every pre-filter detection of the slide stays alive until the end)."""
+    if not pending:
+        return []
+    sel = torch.cat([p[1] for p in pending]).nonzero().squeeze(1)  # the host sync of this group of batches
+    flat = {k: torch.cat([p[0][k] for p in pending]).index_select(0, sel) for k in keys}
+    extra = tuple(torch.cat([p[i] for p in pending]).index_select(0, sel) for i in range(2, len(pending[0])))
+    return [(flat, torch.ones(sel.shape[0], dtype=torch.bool, device=sel.device)) + extra]
+
+
+_warned_double_offset = [False]
+
+
+def _undo_double_offset(model, flat, offs, dev):
+    """Without refinement (``refinement_iterations == 0``) the reference's ``contours`` IS its ``contour_proposals``
+    tensor, so the two in-place ``+= offsets`` of CPN.forward hit it twice (models/cpn.py:655-656,697-699) while boxes and
+    locations receive the offset once.  ``CPN.forward`` reproduces that on purpose (golden ``noref_offs.*``); in the TILE
+    LOOPS the doubled offset would displace every contour by its tile origin and make the border / stitching rules test
+    shifted coordinates, so here one offset is taken back (documented divergence from the reference script, which returns
+    the displaced contours for such models)."""
+    if getattr(model, 'refinement', True) and getattr(model, 'refinement_iterations', 1) > 0:
+        return flat
+    if not _warned_double_offset[0]:
+        import warnings
+        warnings.warn('CPN without refinement in a tile loop: the reference adds the tile offset to the contours twice '
+                      '(models/cpn.py:655-699); celldetection_amd corrects this in tiled_inference / forward_tiled.',
+                      RuntimeWarning, stacklevel=3)
+        _warned_double_offset[0] = True
+    d = offs.to(torch.float32).to(dev)[flat['b'].long()][:, None]
+    flat = dict(flat)
+    flat['contours'] = flat['contours'] - d
+    flat['contour_proposals'] = flat['contour_proposals'] - d
+    return flat
+
+
 def _sync(dev):
     if dev.type == 'cuda':
         torch.cuda.synchronize(dev)
@@ -203,6 +242,8 @@ def tiled_inference(model, img: torch.Tensor, crop_size=(1024, 1024), strides=(7
         samples, order = flat['contours'].shape[1], flat['fourier'].shape[1]
         if flat['scores'].shape[0] == 0:
             continue
+        if forward_fn is None:
+            flat = _undo_double_offset(model, flat, offs, dev)
         sides = []
         for i in idxs:  # sides that have a neighbouring tile (cpn_inference.py:372-380)
             h_i, w_i = np.unravel_index(i, shape)
@@ -216,15 +257,15 @@ def tiled_inference(model, img: torch.Tensor, crop_size=(1024, 1024), strides=(7
             stops = (torch.tensor([size[1], size[0]], dtype=torch.float32) - ov).to(dev, non_blocking=True)
             keep = keep & stitch_fn(flat['contours'], flat['b'], stops, neg)
         pending.append((flat, keep))
+        if len(pending) >= COMPACT_EVERY:
+            pending = _compact(pending, KEYS)
     if samples is None:  # this rank had no tiles: shapes from the model
         samples, order = model.samples, min(model.order, model.core.order)
     local = OrderedDict()
     shapes = dict(contours=(0, samples, 2), boxes=(0, 4), scores=(0,), classes=(0,), locations=(0, 2),
                   fourier=(0, order, 4), contour_proposals=(0, samples, 2))
     if pending:
-        sel = torch.cat([k for _, k in pending]).nonzero().squeeze(1)  # the one host sync of the filter
-        for k in KEYS:
-            local[k] = torch.cat([f[k] for f, _ in pending]).index_select(0, sel)
+        local.update(_compact(pending, KEYS)[0][0])  # (one host sync per COMPACT_EVERY batches)
     else:
         for k in KEYS:
             local[k] = torch.zeros(shapes[k], device=dev)
@@ -310,6 +351,7 @@ def forward_tiled(model, inputs: torch.Tensor, crop_size=1024, stride=512, borde
         chunk, offs, size = meta.pop(0)
         if flat['scores'].shape[0] == 0:
             continue
+        flat = _undo_double_offset(model, flat, offs, dev)
         sides = []
         for _, i in chunk:
             h_i, w_i = np.unravel_index(i, shape)
@@ -321,21 +363,26 @@ def forward_tiled(model, inputs: torch.Tensor, crop_size=1024, stride=512, borde
         keep = ((boxes[:, 2] - boxes[:, 0]) >= min_box_size) & ((boxes[:, 3] - boxes[:, 1]) >= min_box_size)
         keep &= ops.remove_border_contours_batched(flat['contours'], flat['b'], sides_t, neg, size, border_removal).bool()
         img = torch.tensor([j for j, _ in chunk], dtype=torch.int64).to(dev, non_blocking=True)[flat['b'].long()]
-        pending.append((flat, keep, img))
-    coll = [dict(contours=[], scores=[], boxes=[]) for _ in range(n_img)]
+        pending.append(({k: flat[k] for k in ('contours', 'scores', 'boxes')}, keep, img))
+        if len(pending) >= COMPACT_EVERY:
+            pending = _compact(pending, ('contours', 'scores', 'boxes'))
+    coll = [None] * n_img
     if pending:
-        keep_all = torch.cat([k for _, k, _ in pending])
-        img_all = torch.cat([m for _, _, m in pending])
-        cat = {k: torch.cat([f[k] for f, _, _ in pending]) for k in ('contours', 'scores', 'boxes')}
+        (cat, _, img_all), = _compact(pending, ('contours', 'scores', 'boxes'))
+        # group the kept rows by image with ONE stable sort (tile order within an image is preserved) and one count
+        # read-back, instead of a mask + nonzero (= a host sync) per image
+        order_ = torch.sort(img_all, stable=True).indices
+        counts = torch.bincount(img_all, minlength=n_img).tolist()
+        o = 0
         for j in range(n_img):
-            sel = (keep_all & (img_all == j)).nonzero().squeeze(1)
-            if sel.numel():
-                for k in cat:
-                    coll[j][k].append(cat[k].index_select(0, sel))
+            if counts[j]:
+                sel = order_[o:o + counts[j]]
+                coll[j] = {k: cat[k].index_select(0, sel) for k in cat}
+            o += counts[j]
     final = OrderedDict(contours=[], scores=[], boxes=[])
     for j in range(n_img):
-        if coll[j]['scores']:
-            con, sco, box = (torch.cat(coll[j][k]) for k in ('contours', 'scores', 'boxes'))
+        if coll[j] is not None:
+            con, sco, box = (coll[j][k] for k in ('contours', 'scores', 'boxes'))
             keep = ops.nms(box, sco, nms_thresh)
             con, sco, box = con[keep], sco[keep], box[keep]
         else:

@@ -249,6 +249,29 @@ def test_fp32_path_end_to_end_parity(dev, name):
     check_exact('offs', model(x, offsets=torch.as_tensor(g['offsets'])), g, n, raw_atol=5e-4)
 
 
+def test_tile_loops_without_refinement_take_one_offset_back(dev):
+    """with ``refinement_iterations == 0`` CPN.forward adds the tile offset to the contours twice (the reference's
+    aliasing, models/cpn.py:655-699, reproduced on purpose); the tile loops correct it, so that contours, boxes and the
+    border rule agree again: every contour's bounding box must be its box (boxes receive the offset once)."""
+    import warnings
+    from celldetection_amd import inference
+    model, g = build('CpnU22', dev, fixture='stitch.npz')
+    model.refinement_iterations = 0
+    img = torch.as_tensor(g['img']).to(dev)
+    crop, stride = tuple(int(i) for i in g['crop']), tuple(int(i) for i in g['stride'])
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', RuntimeWarning)
+        res = inference.tiled_inference(model, img, crop, stride, batch_size=4, border_removal=int(g['border']))
+        til = model.forward_tiled(img[None], crop_size=crop, stride=stride)
+    assert res['scores'].shape[0] > 5
+    for con, box in ((res['contours'], res['boxes']), (til['contours'][0], til['boxes'][0])):
+        H, W = img.shape[-2:]
+        assert con[..., 0].min() >= -1 and con[..., 0].max() <= W and con[..., 1].max() <= H
+        assert torch.allclose(con.min(1).values, box[:, :2], atol=1e-3) and torch.allclose(con.max(1).values, box[:, 2:], atol=1e-3)
+    y = model(img[None, :, :crop[0], :crop[1]], offsets=torch.tensor([[100, 50]]))  # CPN.forward itself stays bug-compatible
+    assert not torch.allclose(y['contours'][0].min(1).values, y['boxes'][0][:, :2], atol=1.)
+
+
 def test_forward_tiled_and_mask(dev):
     """In-model tiling (LitCpn.forward_tiled semantics) and mask handling of the slide loop."""
     import cpn_oracle as orc
@@ -382,6 +405,44 @@ def test_ensemble_inference_and_inference_wrapper(dev):
     assert isinstance(out['contours'][0], np.ndarray) and out['box_uncertainties'] is None
     y = m0(img)
     np.testing.assert_array_equal(out['boxes'][0], y['boxes'][0].cpu().numpy())
+
+
+def test_hip_graph_replay_equals_eager_launches(dev, monkeypatch):
+    """The conv graph of a shape that is seen repeatedly is replayed as ONE hipGraph from a ring of GRAPH_SLOTS captured
+    instances (cpn._Engine.run): every output must be bit-identical to the eager launches, results handed out by the public
+    ``core_forward`` must survive later runs (they are cloned out of the slot), and the pipelined tile loop -- which reads
+    the slots from a second stream -- must equal per-batch ``forward``."""
+    model, g = build('CpnU22_wide', dev)
+    xs = [torch.rand(2, 3, 96, 128, generator=torch.Generator().manual_seed(s)).to(dev) for s in range(7)]
+    monkeypatch.setenv('CPN_HIP_GRAPH', '0')
+    eager = [model(x) for x in xs]
+    eager_maps = [tuple(t.clone() for t in model.core_forward(x)) for x in xs[:2]]
+    assert not model.engine(dev)._graphs
+    monkeypatch.setenv('CPN_HIP_GRAPH', '1')
+    held = model.core_forward(xs[0])          # first sighting of the shape: eager
+    held2 = model.core_forward(xs[1])         # second: captured into slot 0 and cloned out
+    replay = [model(x) for x in xs]           # slots 1, 2 captured, then pure replays
+    eng = model.engine(dev)
+    assert len(eng._graphs) == 1 and len(next(iter(eng._graphs.values()))['slots']) == eng.GRAPH_SLOTS and not eng._graph_broken
+    for a, b in zip(eager, replay):
+        for k in a:
+            if a[k] is not None:
+                for p, q in zip(a[k], b[k]):
+                    assert torch.equal(p, q), k
+    for got, want in ((held, eager_maps[0]), (held2, eager_maps[1])):
+        for p, q in zip(got, want):
+            assert torch.equal(p, q)
+    pipe = list(model.forward_pipelined(iter(xs)))
+    for a, b in zip(eager, pipe):
+        for k in a:
+            if a[k] is not None:
+                for p, q in zip(a[k], b[k]):
+                    assert torch.equal(p, q), k
+    bad = xs[0].clone()
+    bad[0, 0, 0, 0] = 2.                      # the range flag lives in the slot and is re-armed by every replay
+    with pytest.raises(AssertionError):
+        model(bad)
+    model(xs[0])
 
 
 def test_forward_pipelined_equals_forward(dev):

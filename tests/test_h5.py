@@ -31,3 +31,25 @@ def test_result_file_roundtrip(tmp_path):
     h5.to_h5(f, mode='a', scores=np.zeros((0,), np.float32), contours=np.zeros((0, s, 2), np.float32))
     sc, con, boxes = h5.from_h5(f, 'scores', 'contours', 'boxes')
     assert sc.shape == (0,) and con.shape == (0, s, 2) and boxes.shape == (k, 4)
+
+
+@pytest.mark.skipif(not h5.hdf5_available(), reason='libhdf5 not present')
+def test_file_modes_follow_h5py(tmp_path):
+    """'w-' / 'x' must not truncate an existing file, 'r+' needs an existing one, unsupported dataset options
+    are announced instead of being ignored silently."""
+    f = str(tmp_path / 'm.h5')
+    with pytest.raises(FileNotFoundError):
+        h5.to_h5(f, mode='r+', a=np.arange(3))
+    h5.to_h5(f, mode='x', a=np.arange(3))
+    for mode in ('x', 'w-'):
+        with pytest.raises(FileExistsError):
+            h5.to_h5(f, mode=mode, a=np.arange(5))
+    assert h5.from_h5(f, 'a').shape == (3,)  # untouched
+    h5.to_h5(f, mode='r+', b=np.ones((2, 2), np.float32))
+    h5.to_h5(f, mode='a', c=np.zeros(1, np.uint8))
+    assert h5.from_h5(f, 'a').shape == (3,) and h5.from_h5(f, 'b').shape == (2, 2) and h5.from_h5(f, 'c').shape == (1,)
+    with pytest.warns(RuntimeWarning):
+        h5.to_h5(f, mode='w', compression='gzip', a=np.arange(4))
+    assert h5.from_h5(f, 'a').shape == (4,)
+    with pytest.raises(ValueError):
+        h5.to_h5(f, mode='q', a=np.arange(4))
