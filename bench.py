@@ -409,6 +409,7 @@ def main():
             model.sparse_heads = False
             peng = model.engine(dev)
         prof_batch = peng.max_batch(args.batch, args.tile, args.tile)  # (the engine splits larger batches: 2^31-byte tensors)
+        peng.profile(x[:prof_batch], model.core.order, True)  # (warm: a fresh engine's first run pays one-time set-up)
         prof = peng.profile(x[:prof_batch], model.core.order, True)
         if eng.sparse:
             model.sparse_heads = True

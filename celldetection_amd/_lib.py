@@ -14,7 +14,7 @@ ABI_VERSION = 8
 PRECISION_BF16, PRECISION_F32, PRECISION_FP8 = 0, 1, 2
 E_INVALID, E_UNSUPPORTED, E_WORKSPACE = -1, -2, -3
 
-OP_INPUT, OP_CONV, OP_MAXPOOL, OP_BILINEAR, OP_CONV_DEFERRED = 0, 1, 2, 3, 4
+OP_INPUT, OP_CONV, OP_MAXPOOL, OP_BILINEAR, OP_CONV_DEFERRED, OP_INPUT_STEM, OP_STEM7 = 0, 1, 2, 3, 4, 5, 6
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH_SCALED = 0, 1, 2, 3
 SUBPIXEL_NONE, SUBPIXEL_HEAD, SUBPIXEL_PHASE, SUBPIXEL_LATERAL, SUBPIXEL_SCATTER = 0, 1, 2, 3, 4
 OUT_SCORES, OUT_LOCATIONS, OUT_FOURIER, OUT_REFINEMENT, OUT_UNCERTAINTY = 0, 1, 2, 3, 4
@@ -34,7 +34,7 @@ class OpDesc(Structure):
                 ('act', c_int32), ('act_scale', c_float), ('out_index', c_int32), ('cout_real', c_int32),
                 ('dst_coff', c_int32), ('in_channels', c_int32),
                 ('fuse_weight_offset', c_int64), ('fuse_bias_offset', c_int64), ('fuse_cout', c_int32),
-                ('fuse_act', c_int32), ('fuse_act_scale', c_float), ('mult_offset', c_int32), ('subpixel', c_int32)]
+                ('fuse_act', c_int32), ('fuse_act_scale', c_float), ('mult_offset', c_int32), ('subpixel', c_int32), ('alt', c_int32)]
 
 
 # every symbol include/cpn_hip.h declares: (name, restype, argtypes)
@@ -60,6 +60,10 @@ _SIGNATURES = [
     ('cpn_conv2d_fp8', ctypes.c_int, [POINTER(OpDesc), c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p,
                                       c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                       c_void_p]),
+    ('cpn_convert_input_stem', ctypes.c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                              c_void_p]),
+    ('cpn_stem7', ctypes.c_int, [POINTER(OpDesc), c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                                 c_void_p]),
     ('cpn_maxpool2d', ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                      c_int32, c_void_p]),
     ('cpn_resize_bilinear', ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,

@@ -26,6 +26,7 @@ SOURCES = {
     'nms_binned.hip': ['-ffp-contract=off'],
     'labels.hip': [],
     'sparse_heads.hip': [],
+    'stem.hip': [],
     'cpn_abi.hip': [],
 }
 HEADERS = ['cpn_kernels.h', 'cpn_error.h', 'conv_igemm.hip', os.path.join('..', '..', 'include', 'cpn_hip.h')]

@@ -370,7 +370,7 @@ class CPN(nn.Module):
         # 4/9 of the MACs on the upsampled channels, taken wherever the upsampling is an exact x2.  A run-time switch.
         self.subpixel = True
         # bf16: fused ReadOut tails + fused bilinear head source + sub-pixel decoder convs
-        self._plan = graph.build_plan(**self._plan_kwargs, subpixel=True)
+        self._plan = graph.build_plan(**self._plan_kwargs, subpixel=True, stem_fast=True)
         self._alt_plans = {}
         for key, shape, kind in self._plan.entries:
             _register(self, key, shape, kind)
@@ -420,7 +420,8 @@ class CPN(nn.Module):
             if key == (False, True):
                 return self._plan
             if key not in self._alt_plans:
-                self._alt_plans[key] = graph.build_plan(**self._plan_kwargs, sparse_heads=key[0], subpixel=key[1])
+                self._alt_plans[key] = graph.build_plan(**self._plan_kwargs, sparse_heads=key[0], subpixel=key[1],
+                                                        stem_fast=True)
             return self._alt_plans[key]
         if precision not in self._alt_plans:
             extra = dict(fuse_bilinear=False) if precision == 'fp8' else dict(fuse_readout=False, fuse_bilinear=False)

@@ -1149,6 +1149,14 @@ static TileChoice choose_tile(const ConvArgs &a) {
     if (blocks(TH, BN) < MIN_BLOCKS && BN > 128) BN = 128;
     if (blocks(TH, BN) < MIN_BLOCKS && BN > 64) BN = 64;
     while (lds_bytes(a, TH, BN) > LDS_MAX && BN > 32) BN >>= 1;
+    // experiment (read per call): grouped-conv bundles hold ONE 32-channel chunk, so a workgroup cannot overlap its halo
+    // DMA with its own MFMA work -- only other resident workgroups of the CU can.
+    //  CPN_GS2=1: stride-2 bundles (87 KB halo at 8 rows = one workgroup per CU, DMA and compute strictly serial) on
+    //             4-row tiles (46 KB: three workgroups per CU)
+    if (a.bundles > 1 && a.cin_b == CH && BN == 32) {
+        const char *e2 = getenv("CPN_GS2");
+        if (a.stride == 2 && TH == 8 && e2 && atoi(e2) != 0) TH = 4;
+    }
     // narrow-channel layers at high resolution (64 -> 64 @ 512^2): 16-row tiles keep 8 waves per CU busy
     if (BN == 64 && TH == 8 && a.Hout >= 16 && lds_bytes(a, 16, 64) <= LDS_MAX && blocks(16, 64) >= 2 * MIN_BLOCKS) TH = 16;
     return TileChoice{TH, BN};

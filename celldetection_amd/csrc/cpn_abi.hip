@@ -86,8 +86,24 @@ static void propagate_dims(const cpn_plan *p, int H, int W, ShapePlan &sp) {
             sp.skip[oi] = exact;
             sp.skip[oi + 1] = sp.skip[oi + 2] = !exact;
         }
+        if (o.alt == 1 || o.alt == 2) {
+            // stem alternatives: the fast pair (padded 4-channel input layout inside the input tensor's storage + the
+            // dedicated 7x7 stride-2 kernel) wherever that layout fits, the generic pair otherwise
+            int tin = -1;
+            for (const cpn_op_desc &q : p->ops)
+                if (q.op == CPN_OP_INPUT) { tin = q.dst; break; }
+            const bool fast = p->precision == CPN_PRECISION_BF16 && tin >= 0 &&
+                              (int64_t) (H + STEM_PAD_ROWS) * (W + STEM_PAD_COLS) * 4 <= (int64_t) H * W * p->tensors[tin].channels;
+            sp.skip[oi] = (o.alt == 2) != fast;
+        }
         switch (o.op) {
-            case CPN_OP_INPUT: sp.th[o.dst] = H; sp.tw[o.dst] = W; break;
+            case CPN_OP_INPUT:
+            case CPN_OP_INPUT_STEM: sp.th[o.dst] = H; sp.tw[o.dst] = W; break;
+            case CPN_OP_STEM7:
+                if (o.dst < 0 || o.src0 < 0) { bad("stem conv: missing tensors"); break; }
+                sp.th[o.dst] = (sp.th[o.src0] - 1) / 2 + 1;  // floor((in + 6 - 7) / 2) + 1
+                sp.tw[o.dst] = (sp.tw[o.src0] - 1) / 2 + 1;
+                break;
             case CPN_OP_MAXPOOL:
                 sp.th[o.dst] = (sp.th[o.src0] + 2 * o.pad - o.kh) / o.stride + 1;
                 sp.tw[o.dst] = (sp.tw[o.src0] + 2 * o.pad - o.kw) / o.stride + 1;
@@ -322,6 +338,20 @@ int cpn_plan_create(cpn_plan **plan, const cpn_tensor_desc *tensors, int32_t n_t
             delete p;
             return fail(CPN_E_INVALID, "cpn_plan_create: sub-pixel PHASE / LATERAL ops must follow their HEAD op");
         }
+        if ((o.op == CPN_OP_INPUT_STEM || o.op == CPN_OP_STEM7) &&
+            (precision != CPN_PRECISION_BF16 || o.alt != 2 || o.dst < 0 ||
+             (o.op == CPN_OP_INPUT_STEM && (o.in_channels < 1 || o.in_channels > 4)) ||
+             (o.op == CPN_OP_STEM7 && ((o.cout_b != 32 && o.cout_b != 64) || o.src0 < 0 || o.weight_offset < 0 ||
+                                       (size_t) o.weight_offset + (size_t) 7 * o.cout_b * 64 > weight_bytes ||
+                                       (o.bias_offset >= 0 && (size_t) o.bias_offset + o.cout_b > bias_count))))) {
+            delete p;
+            return fail(CPN_E_INVALID, "cpn_plan_create: malformed stem fast-path op (bf16 plans, alt = 2, <= 4 input "
+                                       "channels, 32 | 64 output channels)");
+        }
+        if (o.alt < 0 || o.alt > 2) {
+            delete p;
+            return fail(CPN_E_INVALID, "cpn_plan_create: alt must be 0, 1 or 2");
+        }
         if (o.op == CPN_OP_CONV_DEFERRED && (precision != CPN_PRECISION_BF16 || o.fuse_cout <= 0 || o.dst >= 0)) {
             delete p;
             return fail(CPN_E_INVALID, "cpn_plan_create: a deferred conv must be a fused ReadOut head of a bf16 plan");
@@ -427,6 +457,22 @@ static int run_or_count(cpn_plan *plan, const void *input, int32_t in_dtype, int
                 rc = check_hip((hipError_t) (f32 ? launch_input_f32(a, st)
                                                  : fp8 ? launch_input_fp8(a, 1.f / plan->tensors[o.dst].scale, st)
                                                        : launch_input(a, st)), "input kernel");
+                break;
+            }
+            case CPN_OP_INPUT_STEM: {
+                if (flops) break;
+                InputArgs a{input, tptr(o.dst), N, o.in_channels, H, W, 4, in_dtype, range_flag};
+                rc = check_hip((hipError_t) launch_input_stem(a, st), "stem input kernel");
+                break;
+            }
+            case CPN_OP_STEM7: {
+                StemArgs a{tptr(o.src0), tptr(o.dst), plan->weights + o.weight_offset,
+                           o.bias_offset >= 0 ? plan->bias + o.bias_offset : nullptr, N, sp.th[o.src0], sp.tw[o.src0],
+                           sp.th[o.dst], sp.tw[o.dst], o.cout_b, tch(o.dst)};
+                const double fl = 2.0 * N * a.Hout * a.Wout * (double) o.cout_b * 7 * 32;
+                if (op_flops) op_flops[i] = fl;
+                if (flops) { *flops += fl; break; }
+                rc = check_hip((hipError_t) launch_stem7(a, st), "stem conv kernel");
                 break;
             }
             case CPN_OP_MAXPOOL: {
@@ -565,6 +611,25 @@ int cpn_conv2d_fp8(const cpn_op_desc *op, const void *src0, int32_t c0_stride, c
         a.fuse_b = (bias && op->fuse_bias_offset >= 0) ? bias + op->fuse_bias_offset : nullptr;
     }
     return check_hip((hipError_t) launch_conv_fp8(a, (hipStream_t) stream), "cpn_conv2d_fp8");
+}
+
+int cpn_convert_input_stem(const void *src, int32_t in_dtype, void *dst, int32_t N, int32_t C, int32_t H, int32_t W,
+                           int32_t *range_flag, void *stream) {
+    if (!src || !dst || N <= 0 || H <= 0 || W <= 0 || C < 1 || C > 4 || (in_dtype != 0 && in_dtype != 1))
+        return fail(CPN_E_INVALID, "cpn_convert_input_stem: bad arguments (1..4 channels, dtype 0 = f32 | 1 = u8)");
+    InputArgs a{src, dst, N, C, H, W, 4, in_dtype, range_flag};
+    return check_hip((hipError_t) launch_input_stem(a, (hipStream_t) stream), "cpn_convert_input_stem");
+}
+
+int cpn_stem7(const cpn_op_desc *op, const void *src, void *dst, int32_t dst_stride, int32_t N, int32_t H, int32_t W,
+              const void *weights, const float *bias, void *stream) {
+    if (!op || !src || !dst || !weights || N <= 0 || H <= 0 || W <= 0) return fail(CPN_E_INVALID, "cpn_stem7: bad arguments");
+    if (op->op != CPN_OP_STEM7 || (op->cout_b != 32 && op->cout_b != 64) || dst_stride < op->cout_b || dst_stride % 8)
+        return fail(CPN_E_INVALID, "cpn_stem7: needs a CPN_OP_STEM7 descriptor with 32 | 64 output channels");
+    StemArgs a{src, dst, (const unsigned char *) weights + op->weight_offset,
+               (bias && op->bias_offset >= 0) ? bias + op->bias_offset : nullptr, N, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1,
+               op->cout_b, dst_stride};
+    return check_hip((hipError_t) launch_stem7(a, (hipStream_t) stream), "cpn_stem7");
 }
 
 int cpn_maxpool2d(const void *src, void *dst, int32_t N, int32_t Hin, int32_t Win, int32_t C, int32_t k, int32_t stride,

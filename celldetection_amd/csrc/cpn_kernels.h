@@ -92,6 +92,19 @@ struct InputArgs {
 };
 int launch_input(const InputArgs &a, hipStream_t stream);
 
+// ResNet stem fast path (csrc/stem.hip): the input as bf16 [N][H + STEM_PAD_ROWS][W + STEM_PAD_COLS][4] with a zero border
+// (3 rows / columns in front), and conv 7x7 stride 2 pad 3 (+ folded BN + ReLU) straight from that layout
+constexpr int STEM_PAD_ROWS = 6, STEM_PAD_COLS = 8;
+struct StemArgs {
+    const void *src;       // padded 4-channel input (launch_input_stem)
+    void *dst;             // bf16 NHWC [N][Hout][Wout][dst_stride]
+    const void *weights;   // [7][coutp][32] bf16: filter row ky, output channel, (kx 0..7, c 0..3) -- kx = 7 and c >= C zero
+    const float *bias;     // [coutp] or nullptr
+    int N, H, W, Hout, Wout, coutp, dst_stride;
+};
+int launch_input_stem(const InputArgs &a, hipStream_t stream);
+int launch_stem7(const StemArgs &a, hipStream_t stream);
+
 // fp32 verification path (csrc/conv_f32.hip): same argument structs, fp32 NHWC activations, weights
 // [bundle][kh*kw][cin_b][cout_b] fp32
 int launch_conv_f32(const ConvArgs &a, hipStream_t stream);

@@ -104,6 +104,21 @@ class Plan:
         self.ops.append(dict(op='input', dst=dst, in_channels=in_channels))
         return dst
 
+    def stem_fast_path(self, conv_index):
+        """Marks the plan's input op + the conv op ``conv_index`` (a 7x7 stride-2 pad-3 stem conv on the input tensor,
+        ResNet ``body.0``, models/resnet.py:274-284) as the GENERIC alternative (alt = 1) and adds the fast alternative
+        (alt = 2; csrc/stem.hip): the input converted into a padded 4-channel layout inside the same tensor's storage and
+        the dedicated stem kernel writing the same destination.  The executor picks per input size.  No new state-dict
+        entries: the fast conv packs the same weights differently."""
+        conv = self.ops[conv_index]
+        inp_i = next(i for i, o in enumerate(self.ops) if o['op'] == 'input')
+        inp = self.ops[inp_i]
+        assert conv['op'] == 'conv' and conv['src0'] == inp['dst'] and (conv['k'], conv['stride'], conv['pad']) == (7, 2, 3)
+        inp['alt'], conv['alt'] = 1, 1
+        self.ops.insert(inp_i + 1, dict(op='input_stem', dst=inp['dst'], in_channels=inp['in_channels'], alt=2))
+        fast = dict(conv, op='stem7', alt=2)
+        self.ops.insert(self.ops.index(conv) + 1, fast)
+
 
 # ---------------------------------------------------------------------------------------------------------------------
 # encoders
@@ -188,13 +203,16 @@ _RESNETS = {
 }
 
 
-def _resnet(P, x, in_channels, prefix, kind, base_channel=64, **unused):
+def _resnet(P, x, in_channels, prefix, kind, base_channel=64, stem_fast=False, **unused):
     """ResNet(fused_initial=False) (resnet.py:265-297): body.0 = conv7x7 s2 + BN + ReLU (feature '0'),
     body.1 = Sequential(MaxPool(3,2,1), layer1), body.2..4 = layer2..4; blocks per torchvision forward."""
     _check_kwargs(unused, (), kind)
     block, layers, groups, base_width = _RESNETS[kind]
     bc = base_channel
+    xin = x
     x = P.conv(x, bc, 7, w=prefix + '0.0.', bn=prefix + '0.1.', stride=2, pad=3, act='relu')
+    if stem_fast and P.tensors[xin]['c'] <= 4 and _pad32(bc) in (32, 64) and P.ops[-2]['op'] == 'input':
+        P.stem_fast_path(len(P.ops) - 1)
     feats, channels = [x], [bc]
     x = P.maxpool(x, 3, 2, 1)
     inplanes = bc
@@ -350,7 +368,7 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
                contour_head_channels: int = None, refinement_head_channels: int = None,
                kernel_sizes: dict = None, fuse_bilinear: bool = True, contour_head_stride: int = 1,
                refinement_head_stride: int = 1, features: dict = None, sparse_heads: bool = False,
-               subpixel: bool = False) -> Plan:
+               subpixel: bool = False, stem_fast: bool = False) -> Plan:
     """Plan of ``Cpn<backbone>`` (celldetection/models/cpn.py:287-439,771-2061; heads: CPNCore.__init__
     cpn.py:125-236).  ``kernel_sizes``: optional {'score'|'location'|'fourier'|'uncertainty'|'refinement': k}
     (the reference's ``kernel_size_<head>`` kwargs, default 7).  ``contour_head_stride`` / ``refinement_head_stride``: stride
@@ -363,7 +381,9 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
     proposals by ``ops.sparse_heads``; needs both heads fused, on the same plain feature, stride 1, same kernel size
     and a hidden width of 128 or 256 (``Plan.meta['sparse_heads']`` = None when the plan does not qualify).
     ``subpixel`` (bf16 plans): the first conv of every UNet decoder level (models/unet.py:213-224) additionally carries its
-    sub-pixel decomposition; the executor picks it wherever the top-down map is upsampled by exactly 2."""
+    sub-pixel decomposition; the executor picks it wherever the top-down map is upsampled by exactly 2.
+    ``stem_fast`` (bf16 plans, ResNet-family encoders with <= 4 input channels): the 7x7 stride-2 stem additionally carries
+    its dedicated kernel on a padded 4-channel input layout (``Plan.stem_fast_path``)."""
     if contour_head_stride not in (1, 2) or refinement_head_stride not in (1, 2):
         raise NotImplementedError('head strides other than 1 and 2 are not supported by the HIP conv kernel')
     feats_cfg = dict(score='1', location='1', contour='1', uncertainty='1', refinement='0')
@@ -386,7 +406,7 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
         feats, channels, strides = _unet_encoder(P, x, in_channels, bp + 'body.', **ekw)
     else:
         ekw = dict(bkw.get('backbone_kwargs') or {})
-        feats, channels, strides = _resnet(P, x, in_channels, bp + 'body.', enc, **ekw)
+        feats, channels, strides = _resnet(P, x, in_channels, bp + 'body.', enc, stem_fast=bool(stem_fast), **ekw)
     def _keys(v):
         return [str(k) for k in v] if isinstance(v, (list, tuple)) else [str(v)]
 
@@ -541,8 +561,32 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=Non
         d.src0 = d.src1 = d.res = d.dst = -1
         d.bias_offset = d.mult_offset = -1
         op_scales.append((0., 0.))
-        if op['op'] == 'input':
-            d.op, d.dst, d.in_channels = _lib.OP_INPUT, op['dst'], op['in_channels']
+        d.alt = int(op.get('alt', 0))
+        if d.alt and (f32 or fp8):
+            raise ValueError('the stem fast path is a bf16-plan feature')
+        if op['op'] in ('input', 'input_stem'):
+            d.op, d.dst, d.in_channels = (_lib.OP_INPUT if op['op'] == 'input' else _lib.OP_INPUT_STEM), op['dst'], op['in_channels']
+            continue
+        if op['op'] == 'stem7':
+            # weights [7][cout_b][32] bf16: filter row ky, output channel, (kx 0..7, c 0..3) -- the 7 taps of a filter row
+            # over a 4-channel NHWC input are 28 contiguous values; kx = 7 and c >= in_channels meet zeros
+            w, b = _fold(state_dict, op)
+            cout, cin = op['cout'], op['cin']
+            coutp = _pad32(cout)
+            wk = torch.zeros(7, coutp, 8, 4, dtype=torch.float64)
+            wk[:, :cout, :7, :cin] = w.permute(2, 0, 3, 1)  # [cout, cin, ky, kx] -> [ky, cout, kx, cin]
+            bias = torch.zeros(coutp, dtype=torch.float64)
+            bias[:cout] = b
+            wparts.append(wk.reshape(-1).to(torch.bfloat16))
+            bparts.append(bias.to(torch.float32))
+            d.op, d.src0, d.dst = _lib.OP_STEM7, op['src0'], op['dst']
+            d.kh = d.kw = 7
+            d.stride, d.pad, d.bundles, d.cin_b, d.cout_b = 2, 3, 1, 32, coutp
+            d.weight_offset, d.bias_offset = woff, boff
+            d.act, d.cout_real, d.out_index = _lib.ACT_RELU, cout, -1
+            d.fuse_weight_offset = d.fuse_bias_offset = -1
+            woff += wparts[-1].numel() * 2
+            boff += bparts[-1].numel()
             continue
         if op['op'] == 'maxpool':
             d.op, d.src0, d.dst = _lib.OP_MAXPOOL, op['src0'], op['dst']

@@ -50,7 +50,15 @@ typedef struct {
 /* CPN_OP_CONV_DEFERRED (score-gated heads, cpn_sparse_heads below): a fused ReadOut head conv that cpn_plan_run does NOT
  * execute -- its weights are packed and its output size is reported like a CPN_OP_CONV's, and its source tensor stays
  * intact in the workspace until the end of the run (cpn_plan_tensor_info locates it). */
-enum { CPN_OP_INPUT = 0, CPN_OP_CONV = 1, CPN_OP_MAXPOOL = 2, CPN_OP_BILINEAR = 3, CPN_OP_CONV_DEFERRED = 4 };
+/* CPN_OP_INPUT_STEM / CPN_OP_STEM7 (bf16 plans; csrc/stem.hip): the ResNet stem `body.0` = Conv2d(in_channels <= 4 -> 32 | 64
+ * output channels after padding, 7x7, stride 2, pad 3) + BN + ReLU (celldetection/models/resnet.py:274-284) on a dedicated
+ * layout: CPN_OP_INPUT_STEM converts the input to bf16 [N][H + 6][W + 8][4] with a zero border inside the storage of its
+ * dst tensor (which needs (H + 6) * (W + 8) * 4 <= H * W * channels elements), CPN_OP_STEM7 reads it with weights
+ * [7][cout_b][32] bf16 at weight_offset (filter row, output channel, (kx 0..7, c 0..3); kx = 7 and c >= in_channels zero).
+ * Both carry `alt` = 2 and stand next to the generic CPN_OP_INPUT / CPN_OP_CONV pair (`alt` = 1): the executor runs the
+ * fast pair at every input size the layout fits into the tensor, the generic pair otherwise. */
+enum { CPN_OP_INPUT = 0, CPN_OP_CONV = 1, CPN_OP_MAXPOOL = 2, CPN_OP_BILINEAR = 3, CPN_OP_CONV_DEFERRED = 4,
+       CPN_OP_INPUT_STEM = 5, CPN_OP_STEM7 = 6 };
 enum { CPN_ACT_NONE = 0, CPN_ACT_RELU = 1, CPN_ACT_SIGMOID = 2, CPN_ACT_TANH_SCALED = 3 };
 /* Sub-pixel decomposition of a k = 3 conv over cat(lateral, nearest-x2-upsampled top-down map) -- the first conv of every
  * GeneralizedUNet decoder level (celldetection/models/unet.py:213-224).  Output pixel (2i+py, 2j+px) sees the upsampled
@@ -106,6 +114,7 @@ typedef struct {
     int32_t mult_offset;      /* CPN_PRECISION_FP8: float offset into the bias blob of the per-output-channel
                                * multipliers (weight scales), -1 = none; unused by the other precisions        */
     int32_t subpixel;         /* CPN_SUBPIXEL_* (bf16 plans)                                                    */
+    int32_t alt;              /* 0: always runs; 1 / 2: generic / fast member of the stem alternatives (see above)  */
 } cpn_op_desc;
 
 typedef struct cpn_plan cpn_plan;
@@ -180,6 +189,13 @@ int cpn_conv2d_fp8(const cpn_op_desc *op, const void *src0, int32_t c0_stride, c
                    const void *res, int32_t res_stride, void *dst, int32_t dst_stride, int32_t N, int32_t Hin,
                    int32_t Win, const void *weights, const float *bias, const float *mult, float res_scale,
                    float out_inv_scale, void *stream);
+/* ResNet stem fast path (see CPN_OP_INPUT_STEM / CPN_OP_STEM7): input conversion into the padded 4-channel layout
+ * (dst: (H + 6) * (W + 8) * 4 bf16 per image) and the 7x7 stride-2 conv + bias + ReLU from it (`op`: a CPN_OP_STEM7
+ * descriptor; dst NHWC bf16 [N][(H - 1) / 2 + 1][(W - 1) / 2 + 1][dst_stride]). */
+int cpn_convert_input_stem(const void *src, int32_t in_dtype, void *dst, int32_t N, int32_t C, int32_t H, int32_t W,
+                           int32_t *range_flag, void *stream);
+int cpn_stem7(const cpn_op_desc *op, const void *src, void *dst, int32_t dst_stride, int32_t N, int32_t H, int32_t W,
+              const void *weights, const float *bias, void *stream);
 int cpn_maxpool2d(const void *src, void *dst, int32_t N, int32_t Hin, int32_t Win, int32_t C, int32_t k, int32_t stride,
                   int32_t pad, void *stream);
 int cpn_resize_bilinear(const void *src, void *dst, int32_t N, int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout,

@@ -336,6 +336,69 @@ def test_subpixel_bridge_conv(dev, n, h, w, cin, cout, bias):
     assert ((got - full).norm() / full.norm()).item() < 1e-2
 
 
+@pytest.mark.parametrize('n,h,w,cin,cout,dtype', [(2, 64, 96, 3, 64, 0), (1, 75, 101, 3, 64, 0), (3, 33, 47, 1, 8, 1),
+                                                   (2, 64, 64, 4, 32, 0), (16, 128, 128, 3, 64, 1), (1, 7, 9, 3, 64, 0)])
+def test_stem_fast_path(dev, n, h, w, cin, cout, dtype):
+    """csrc/stem.hip: ResNet stem conv 7x7 stride 2 pad 3 + BN + ReLU (models/resnet.py:274-284) from the padded 4-channel
+    input layout, against an fp32 conv on the same bf16-rounded operands; the input conversion itself must be exact."""
+    from celldetection_amd import _lib, graph
+    g = torch.Generator().manual_seed(h * 1000 + w)
+    P = graph.Plan()
+    x = P.input(cin)
+    P.conv(x, cout, 7, w='c.', bn='b.', stride=2, pad=3, act='relu')
+    P.stem_fast_path(len(P.ops) - 1)
+    assert [o['op'] for o in P.ops] == ['input', 'input_stem', 'conv', 'stem7'] and [o['alt'] for o in P.ops] == [1, 2, 1, 2]
+    sd = {}
+    for key, shape, kind in P.entries:
+        if key.endswith('running_var'):
+            sd[key] = torch.rand(shape, generator=g) + .5
+        elif key.endswith('num_batches_tracked'):
+            sd[key] = torch.zeros((), dtype=torch.long)
+        elif len(shape) == 4:
+            sd[key] = torch.randn(shape, generator=g) / np.sqrt(np.prod(shape[1:]))
+        else:
+            sd[key] = torch.randn(shape, generator=g) * .5 + (1. if key.endswith('b.weight') else 0.)
+    tens, ops, wblob, bblob = graph.pack(P, sd, dev)
+    lib = _lib.load()
+    xin = torch.rand(n, cin, h, w, generator=g)
+    src = xin.to(dev) if dtype == 0 else (xin * 255).to(torch.uint8).to(dev)
+    xq = xin if dtype == 0 else (xin * 255).to(torch.uint8).float() / 255
+    pad = torch.full((n, h + 6, w + 8, 4), 7., dtype=torch.bfloat16, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(lib.cpn_convert_input_stem(_lib.ptr(src.contiguous()), dtype, _lib.ptr(pad), n, cin, h, w, _lib.ptr(flag),
+                                          _lib.stream_ptr()), 'input_stem')
+    torch.cuda.synchronize()
+    exp = torch.zeros(n, h + 6, w + 8, 4)
+    exp[:, 3:3 + h, 3:3 + w, :cin] = xq.to(torch.bfloat16).float().permute(0, 2, 3, 1)
+    assert torch.equal(pad.cpu().float(), exp) and flag.item() == 0
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    cp = _pad32(cout)
+    out = torch.full((n, ho, wo, cp), float('nan'), dtype=torch.bfloat16, device=dev)
+    _lib.check(lib.cpn_stem7(ops[3], _lib.ptr(pad), _lib.ptr(out), cp, n, h, w, _lib.ptr(wblob), _lib.ptr(bblob),
+                             _lib.stream_ptr()), 'stem7')
+    # the generic kernel on the 32-channel input, same weights: both approximate the same fp32 conv
+    gen_in = to_nhwc_bf16(xq.to(dev))
+    gen = torch.full((n, ho, wo, cp), float('nan'), dtype=torch.bfloat16, device=dev)
+    _lib.check(lib.cpn_conv2d(ops[2], _lib.ptr(gen_in), gen_in.shape[-1], _lib.ptr(None), 0, _lib.ptr(None), 0, _lib.ptr(gen),
+                              cp, n, h, w, _lib.ptr(wblob), _lib.ptr(bblob), _lib.stream_ptr()), 'generic stem')
+    torch.cuda.synchronize()
+    got = from_nhwc(out.cpu(), cout)
+    assert torch.isfinite(out.float()).all() and out[..., cout:].abs().max().item() == 0
+    wf, bf = graph._fold(sd, P.ops[2])
+    ref = F.relu(F.conv2d(xq.to(torch.bfloat16).float(), wf.float().to(torch.bfloat16).float(), bf.float(), 2, 3))
+    err = (got - ref).abs()
+    scale = max(ref.abs().max().item(), 1.)
+    bad = (err > 1e-2 * scale + 8e-3 * ref.abs()).sum().item()
+    assert bad == 0, f'{bad} / {err.numel()} elements off; max abs err {err.max().item():.3e}'
+    assert (from_nhwc(gen.cpu(), cout) - got).abs().max().item() < 2e-2 * scale
+    bad_in = xin.clone()
+    bad_in[0, 0, 1, 1] = 1.5
+    if dtype == 0:  # the range flag of the reference's Normalize assert (models/commons.py:694-697)
+        _lib.check(lib.cpn_convert_input_stem(_lib.ptr(bad_in.to(dev)), 0, _lib.ptr(pad), n, cin, h, w, _lib.ptr(flag),
+                                              _lib.stream_ptr()), 'input_stem')
+        assert flag.item() == 1
+
+
 def test_maxpool_bilinear_input(dev):
     from celldetection_amd import _lib
     lib = _lib.load()

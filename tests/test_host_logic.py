@@ -325,3 +325,41 @@ def test_reference_written_checkpoint_loads_on_the_host():
     assert list(sd) == list(raw['state_dict']) and all(torch.equal(sd[k], v) for k, v in raw['state_dict'].items())
     d = cda.util.model2dict(model)  # and back: the description this build writes for that model
     assert d['model'] == 'CpnU22' and d['kwargs']['backbone_kwargs'] == raw['cd.models']['kwargs']['backbone_kwargs']
+
+
+def test_stem_fast_path_plan_and_packing():
+    """ResNet-family bf16 plans carry the stem alternatives (generic pair alt = 1, fast pair alt = 2; csrc/stem.hip); the
+    fast conv packs the SAME state-dict weights as [ky][cout][kx 0..7][c 0..3]; the executor takes the fast pair at sizes
+    where the padded 4-channel layout fits into the input tensor and reports fewer executed FLOPs there."""
+    import celldetection_amd as cda
+    from ctypes import c_void_p
+    from celldetection_amd import _lib, graph
+    from celldetection_amd.synth import synth_state_dict
+    m = cda.models.CpnResNet18FPN(3, backbone_kwargs={'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}})
+    assert [(o['op'], o.get('alt')) for o in m._plan.ops[:4]] == [('input', 1), ('input_stem', 2), ('conv', 1), ('stem7', 2)]
+    generic = graph.build_plan(**m._plan_kwargs, subpixel=True)
+    assert generic.entries == m._plan.entries
+    assert all(not o.get('alt') for p_ in ('fp8', 'fp32') for o in m.plan_for(p_).ops)
+    assert not any(o.get('alt') for o in cda.models.CpnU22(3).plan_for('bf16').ops)  # (3x3 stride-1 first conv: no stem)
+    sd = synth_state_dict(m.state_dict(), seed=0)
+    tens, ops, wblob, bblob = graph.pack(m._plan, sd, 'cpu')
+    st = ops[3]
+    assert (st.op, st.alt, st.cout_b, ops[1].op, ops[1].in_channels) == (_lib.OP_STEM7, 2, 32, _lib.OP_INPUT_STEM, 3)
+    wk = wblob[st.weight_offset // 2: st.weight_offset // 2 + 7 * 32 * 32].float().reshape(7, 32, 8, 4)
+    wf, bf = graph._fold(sd, m._plan.ops[2])
+    want = torch.zeros(7, 32, 8, 4)
+    want[:, :8, :7, :3] = wf.permute(2, 0, 3, 1).float().to(torch.bfloat16).float()
+    assert torch.equal(wk, want)
+    assert torch.equal(bblob[st.bias_offset: st.bias_offset + 8], bf.float())
+    lib = _lib.load()
+    fl = {}
+    for name, plan in (('fast', m._plan), ('generic', generic)):
+        t_, o_, w_, b_ = graph.pack(plan, sd, 'cpu')
+        hdl = c_void_p()
+        _lib.check(lib.cpn_plan_create(hdl, t_, len(t_), o_, len(o_), c_void_p(w_.data_ptr()), w_.numel() * 2,
+                                       c_void_p(b_.data_ptr()), b_.numel(), _lib.PRECISION_BF16), 'create')
+        fl[name] = lib.cpn_plan_executed_flops(hdl, 1, 64, 96)
+        assert lib.cpn_plan_workspace_bytes(hdl, 2, 64, 96) > 0
+        lib.cpn_plan_destroy(hdl)
+    stem_generic = 2. * 32 * 48 * 32 * 32 * 49
+    assert abs((fl['generic'] - fl['fast']) - stem_generic * (1 - 7 / 49.)) < 1.
