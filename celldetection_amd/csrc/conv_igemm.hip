@@ -1149,14 +1149,6 @@ static TileChoice choose_tile(const ConvArgs &a) {
     if (blocks(TH, BN) < MIN_BLOCKS && BN > 128) BN = 128;
     if (blocks(TH, BN) < MIN_BLOCKS && BN > 64) BN = 64;
     while (lds_bytes(a, TH, BN) > LDS_MAX && BN > 32) BN >>= 1;
-    // experiment (read per call): grouped-conv bundles hold ONE 32-channel chunk, so a workgroup cannot overlap its halo
-    // DMA with its own MFMA work -- only other resident workgroups of the CU can.
-    //  CPN_GS2=1: stride-2 bundles (87 KB halo at 8 rows = one workgroup per CU, DMA and compute strictly serial) on
-    //             4-row tiles (46 KB: three workgroups per CU)
-    if (a.bundles > 1 && a.cin_b == CH && BN == 32) {
-        const char *e2 = getenv("CPN_GS2");
-        if (a.stride == 2 && TH == 8 && e2 && atoi(e2) != 0) TH = 4;
-    }
     // narrow-channel layers at high resolution (64 -> 64 @ 512^2): 16-row tiles keep 8 waves per CU busy
     if (BN == 64 && TH == 8 && a.Hout >= 16 && lds_bytes(a, 16, 64) <= LDS_MAX && blocks(16, 64) >= 2 * MIN_BLOCKS) TH = 16;
     return TileChoice{TH, BN};
@@ -1176,13 +1168,7 @@ int launch_conv(const ConvArgs &a, hipStream_t stream) {
         c.TH = (a.cout_b == 64 && c.TH == 16) ? 16 : 8;
     }
     if (lds_bytes(a, c.TH, c.BN) > LDS_MAX) return (int) hipErrorInvalidValue;
-    if (c.TH == 16) {
-        // CPN_T64=1 (experiment, read per call): four waves of 4 rows x 32 px x 64 cout (8 MFMAs per 6 fragment reads, like
-        // the flagship tile) instead of eight waves of 2 rows (4 MFMAs per 4 reads: LDS-read bound)
-        const char *e = getenv("CPN_T64");
-        if (e && atoi(e) != 0) return launch_cfg<16, 64, 4, 2>(a, stream);
-        return launch_cfg<16, 64, 2, 2>(a, stream);
-    }
+    if (c.TH == 16) return launch_cfg<16, 64, 2, 2>(a, stream);
     if (c.TH == 8) {
         switch (c.BN) {
             case 256: return launch_cfg<8, 256, 4, 2>(a, stream);

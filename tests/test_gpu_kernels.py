@@ -147,6 +147,8 @@ CONV_CASES = {
     '3x3_256_flagship_tile': dict(n=8, h=128, w=128, cin=64, cout=256, k=3),
     '3x3_256_flagship_concat_up': dict(n=8, h=128, w=128, cin=32, cout=256, k=3, cin1=64, up1=True, seed=7),
     'fused_head_256_flagship_tile': dict(n=8, h=128, w=128, cin=96, cout=256, k=7, fuse_cout=20, fuse_act='none', seed=9),
+    '1x1_flagship_tile': dict(n=16, h=32, w=32, cin=96, cout=1024, k=1, seed=11),
+    '1x1_flagship_tile_res': dict(n=16, h=32, w=32, cin=64, cout=1024, k=1, res=True, seed=13),
     'fused_head_256': dict(n=1, h=32, w=64, cin=64, cout=256, k=7, fuse_cout=20, fuse_act='none'),
     'fused_head_128_sigmoid': dict(n=2, h=32, w=32, cin=32, cout=128, k=3, fuse_cout=1, fuse_act='sigmoid'),
     'fused_head_64_tanh_th16': dict(n=4, h=256, w=256, cin=64, cout=64, k=7, fuse_cout=2, fuse_act='tanh_scaled', seed=5),
@@ -383,7 +385,7 @@ def test_stem_fast_path(dev, n, h, w, cin, cout, dtype):
                               cp, n, h, w, _lib.ptr(wblob), _lib.ptr(bblob), _lib.stream_ptr()), 'generic stem')
     torch.cuda.synchronize()
     got = from_nhwc(out.cpu(), cout)
-    assert torch.isfinite(out.float()).all() and out[..., cout:].abs().max().item() == 0
+    assert torch.isfinite(out.float()).all() and (cout == cp or out[..., cout:].abs().max().item() == 0)
     wf, bf = graph._fold(sd, P.ops[2])
     ref = F.relu(F.conv2d(xq.to(torch.bfloat16).float(), wf.float().to(torch.bfloat16).float(), bf.float(), 2, 3))
     err = (got - ref).abs()
@@ -397,6 +399,19 @@ def test_stem_fast_path(dev, n, h, w, cin, cout, dtype):
         _lib.check(lib.cpn_convert_input_stem(_lib.ptr(bad_in.to(dev)), 0, _lib.ptr(pad), n, cin, h, w, _lib.ptr(flag),
                                               _lib.stream_ptr()), 'input_stem')
         assert flag.item() == 1
+
+
+@pytest.mark.parametrize('name', ['1x1_flagship_tile', '1x1_flagship_tile_res'])
+def test_conv_pointwise_register_weight_loop(dev, name, monkeypatch):
+    """CPN_PWR=1 selects MODE_PWR (the 1x1 convs' weight fragments from L2 straight into registers, 8x256 tile; round-3
+    experiment, neutral on the MI355X: profiles/r03_kernel_experiments.txt).  Same K order and MFMA sequence as MODE_PW:
+    bit-identical outputs."""
+    monkeypatch.setenv('CPN_PWR', '0')
+    lds, ref, _ = run_conv(dev, **CONV_CASES[name])
+    monkeypatch.setenv('CPN_PWR', '1')
+    rw, _, _ = run_conv(dev, **CONV_CASES[name])
+    assert torch.equal(rw, lds), f'max abs {(rw - lds).abs().max().item():.3e}'
+    assert (rw - ref).abs().max().item() < 5e-2 * max(ref.abs().max().item(), 1.)
 
 
 def test_maxpool_bilinear_input(dev):
