@@ -144,12 +144,16 @@ __device__ __forceinline__ void bdma16(rsrc_t rsrc, unsigned lane_off, unsigned 
 // MODE_S1R = MODE_S1 with the weight operand loaded from L2 straight into registers (dense KxK, >= 9 taps, 8x256 tile)
 // MODE_PWR = MODE_PW with the register-weight loop of MODE_S1R (1x1 convs stream BOTH operands once per output tile: the
 // LDS-DMA issue path is their bottleneck, and the weight half of it moves to plain buffer loads)
-enum Mode : int { MODE_PW = 0, MODE_S1 = 1, MODE_S2 = 2, MODE_BL = 3, MODE_S1R = 4, MODE_PWR = 5 };
+// MODE_N = MODE_S1 for outputs that are exactly 16 pixels wide (the deepest encoder / decoder level of a 512^2 tile): an
+// MFMA pixel fragment is TWO output rows x 16 columns instead of one row x 32, so no half of the 32-pixel tile is empty.
+// [N][H][16] IS [N][H/2][32] in memory, hence the launcher passes the output (and a same-size residual) with those
+// virtual dimensions and the epilogue is unchanged; only the halo geometry and the fragment addresses know about it.
+enum Mode : int { MODE_PW = 0, MODE_S1 = 1, MODE_S2 = 2, MODE_BL = 3, MODE_S1R = 4, MODE_PWR = 5, MODE_N = 6 };
 
 template <int MODE>
 struct ModeCfg {
     static constexpr int S = MODE == MODE_S2 ? 2 : 1;                              // conv stride
-    static constexpr int PITCH = (MODE == MODE_PW || MODE == MODE_PWR) ? 32 : (MODE == MODE_S2 ? 80 : 48);  // halo row pitch (pixels)
+    static constexpr int PITCH = (MODE == MODE_PW || MODE == MODE_PWR || MODE == MODE_N) ? 32 : (MODE == MODE_S2 ? 80 : 48);  // halo row pitch (pixels)
 };
 
 template <int TH, int BN, int WM, int WN>
@@ -347,6 +351,8 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     constexpr bool PW = MODE == MODE_PW || MODE == MODE_PWR;
     constexpr bool BL = MODE == MODE_BL;
     constexpr bool RW = MODE == MODE_S1R || MODE == MODE_PWR;  // weights: global -> registers (no weight tiles in LDS)
+    constexpr bool NR = MODE == MODE_N;  // narrow output: fragment = 2 rows x 16 px; a.Hout / a.Wout are the virtual [H/2][32]
+    constexpr int RPF = NR ? 2 : 1;      // output rows per pixel fragment
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -369,7 +375,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
 
     const int KW = PW ? 1 : a.KW;
     const int KH = PW ? 1 : a.KH;
-    const int HH = (TH - 1) * S + KH;                 // halo rows
+    const int HH = (RPF * TH - 1) * S + KH;           // halo rows
     const int hinstr = (HH * PITCH * 4 + 63) >> 6;    // 1-KiB DMA instructions per halo tile
     const int halo_buf = hinstr << 10;
     const int nchunks = a.cin_b / CH;
@@ -395,12 +401,12 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
 
     HaloGeo G;
     G.sub = PW ? a.stride : 1;
-    G.n = n; G.iy0 = oy0 * (PW ? a.stride : S) - pad_y; G.ix0 = ox0 * (PW ? a.stride : S) - pad_x;
+    G.n = n; G.iy0 = RPF * oy0 * (PW ? a.stride : S) - pad_y; G.ix0 = ox0 * (PW ? a.stride : S) - pad_x;
     G.Hin = a.Hin; G.Win = a.Win;
     G.up0 = a.up0; G.up1 = a.up1;
     G.Hs0 = a.Hs0; G.Ws0 = a.Ws0; G.Hs1 = a.Hs1; G.Ws1 = a.Ws1;
     G.sy0 = a.sy0; G.sx0 = a.sx0; G.sy1 = a.sy1; G.sx1 = a.sx1;
-    G.c0_stride = a.c0_stride; G.c1_stride = a.c1_stride; G.HH = HH; G.HWreal = (TW - 1) * S + KW;
+    G.c0_stride = a.c0_stride; G.c1_stride = a.c1_stride; G.HH = HH; G.HWreal = ((NR ? 16 : TW) - 1) * S + KW;
 
     // halo DMA instruction q (0..hinstr) is issued by wave q % NWAVES; the source offsets are recomputed per issue
     // (a few VALU per 1-KiB DMA; keeping them in registers cost 10 VGPRs of a kernel that sits at the 256 limit)
@@ -512,9 +518,10 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     // an XOR 32 on the byte address (records are 64-B aligned, the swizzled part index lives in bits 4-5)
     constexpr int PSEL = CPN_FP8 ? 2 : 1;  // first 16-byte part of lane half lhi: lhi (bf16 k-half 0) | 2*lhi (fp8)
     const unsigned w_lane = (unsigned) ((wave_n * WN * 32 + l31) * REC + (((PSEL * lhi) ^ ((l31 >> 2) & 3)) << 4));
-    const int x_lane = l31 * S;                            // halo column of this lane's pixel for tap column 0
-    const int row_wave = wave_m * WM * S;                  // halo row of fragment 0 for tap row 0
-    constexpr int FRAG_STRIDE = S * PITCH * REC;           // bytes between the halo rows of consecutive fragments
+    const int x_lane = (NR ? (l31 & 15) : l31) * S;        // halo column of this lane's pixel for tap column 0
+    const int row_wave = wave_m * WM * RPF * S;            // halo row of fragment 0 for tap row 0
+    constexpr int FRAG_STRIDE = RPF * S * PITCH * REC;     // bytes between the halo rows of consecutive fragments
+    const unsigned nr_lane = NR ? (unsigned) ((l31 >> 4) * S * PITCH * REC) : 0u;  // narrow: lanes 16..31 = the fragment's 2nd row
 
     // ---- software-pipelined main loop -------------------------------------------------------------------------
     // A step has up to four MFMA groups (item x k-half), each WN + WM fragments and WN*WM MFMAs.  Two fragment
@@ -544,7 +551,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     // byte address (within smem) of this lane's k-half-0 pixel / weight fragment of an item
 #define ITEM_PADDR(C_, KY_, KX_)                                                                               \
     ((unsigned) ((min((C_), nchunks - 1) & nhb_mask) * halo_buf + (row_wave + (KY_)) * (PITCH * REC)) +        \
-     (unsigned) ((x_lane + (KX_)) * REC) + (unsigned) (((PSEL * lhi) ^ (((x_lane + (KX_)) >> 2) & 3)) << 4))
+     (unsigned) ((x_lane + (KX_)) * REC) + (unsigned) (((PSEL * lhi) ^ (((x_lane + (KX_)) >> 2) & 3)) << 4) + nr_lane)
     const unsigned lds0 = (unsigned) (size_t) (__attribute__((address_space(3))) unsigned char *) smem;
 #define LOAD_GROUP(WF, PF, PADDR, WADDR) load_frags<WN, WM, FRAG_STRIDE>(WF, PF, lds0 + (PADDR), lds0 + (WADDR))
     // MFMAs of a group whose reads were followed by PENDING younger ds_reads (the next group's prefetch)
@@ -1061,7 +1068,15 @@ struct TileChoice {
     int TH, BN;
 };
 
+// narrow outputs (see MODE_N): exactly 16 columns, an even number of rows, stride-1 k x k conv whose epilogue addresses nothing
+// but the output and a same-size residual
+static bool narrow_ok(const ConvArgs &a) {
+    return !CPN_FP8 && a.Wout == 16 && a.Hout % 2 == 0 && a.stride == 1 && !(a.KH == 1 && a.KW == 1 && a.pad == 0) &&
+           a.up0 != 2 && a.res_up == 0 && a.phase != 2 && a.KW <= 17;
+}
+
 static int conv_mode(const ConvArgs &a) {
+    if (a.narrow) return MODE_N;
     if (a.KH == 1 && a.KW == 1 && a.pad == 0) {  // incl. strided 1x1: the tile gathers only its outputs
         const char *e = getenv("CPN_PWR");  // opt-in experiment (read per call): register-weight loop, 8x256 tile only
         return (!CPN_FP8 && e && atoi(e) != 0) ? MODE_PWR : MODE_PW;
@@ -1077,8 +1092,8 @@ static int conv_mode(const ConvArgs &a) {
 static size_t lds_bytes(const ConvArgs &a, int TH, int BN) {
     const int mode = conv_mode(a);
     const int S = mode == MODE_S2 ? 2 : 1;
-    const int pitch = (mode == MODE_PW || mode == MODE_PWR) ? 32 : (mode == MODE_S2 ? 80 : 48);
-    const int HH = (TH - 1) * S + a.KH;
+    const int pitch = (mode == MODE_PW || mode == MODE_PWR || mode == MODE_N) ? 32 : (mode == MODE_S2 ? 80 : 48);
+    const int HH = ((mode == MODE_N ? 2 : 1) * TH - 1) * S + a.KH;
     const int nchunks = a.cin_b / 32;
     const size_t halo_buf = (size_t) ((HH * pitch * 4 + 63) / 64) * 1024;
     const int nhb = (a.KH * a.KW == 1) ? 4 : (nchunks > 1 ? 2 : 1);
@@ -1122,6 +1137,9 @@ static int launch_cfg(const ConvArgs &a, hipStream_t stream) {
 #endif
             return launch_mode<TH, BN, WM, WN, MODE_PW>(a, stream);
         case MODE_PW: return launch_mode<TH, BN, WM, WN, MODE_PW>(a, stream);
+#if !CPN_FP8
+        case MODE_N: return launch_mode<TH, BN, WM, WN, MODE_N>(a, stream);
+#endif
         case MODE_S1: return launch_mode<TH, BN, WM, WN, MODE_S1>(a, stream);
         case MODE_S1R:
 #if !CPN_FP8
@@ -1154,7 +1172,13 @@ static TileChoice choose_tile(const ConvArgs &a) {
     return TileChoice{TH, BN};
 }
 
-int launch_conv(const ConvArgs &a, hipStream_t stream) {
+int launch_conv(const ConvArgs &a_in, hipStream_t stream) {
+    ConvArgs a = a_in;
+    if (narrow_ok(a)) {  // [N][H][16] viewed as [N][H/2][32]: same memory, full 32-pixel fragments (MODE_N)
+        a.narrow = 1;
+        a.Hout /= 2;
+        a.Wout = 32;
+    }
     if (a.cin_b % CH || a.cout_b % 32 || a.c0_used % CH) return (int) hipErrorInvalidValue;
     if (a.stride != 1 && a.stride != 2) return (int) hipErrorInvalidValue;
     if (a.up0 == 2 && (CPN_FP8 || a.stride != 1 || a.src1 || a.up1 || (a.KH == 1 && a.KW == 1)))

@@ -34,6 +34,7 @@ struct ConvArgs {
                                 // (g >> 1, g & 1) read the SAME cin_b input channels with padding (pad - py, pad - px);
                                 // 2 (CPN_SUBPIXEL_SCATTER): additionally phase g writes channels [0, cout_b) of pixel
                                 // (2 oy + py, 2 ox + px) of a [2 Hout][2 Wout] destination and all phases share one bias
+    int narrow;                 // set by launch_conv (MODE_N): Hout / Wout hold the virtual [H/2][32] view of a 16-column output
     const void *res;            // residual NHWC bf16 (added before activation) or nullptr
     int res_stride, res_up;     // res_up 1: stored at Hr x Wr, nearest-resized to Hout x Wout (FPN top-down path)
                                 // res_up 2: phase tensor [Hout/2][Wout/2][4 * res_cph], read pixel-shuffled

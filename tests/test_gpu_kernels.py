@@ -147,6 +147,13 @@ CONV_CASES = {
     '3x3_256_flagship_tile': dict(n=8, h=128, w=128, cin=64, cout=256, k=3),
     '3x3_256_flagship_concat_up': dict(n=8, h=128, w=128, cin=32, cout=256, k=3, cin1=64, up1=True, seed=7),
     'fused_head_256_flagship_tile': dict(n=8, h=128, w=128, cin=96, cout=256, k=7, fuse_cout=20, fuse_act='none', seed=9),
+    # outputs exactly 16 pixels wide: MODE_N (a pixel fragment = two rows x 16 columns)
+    '3x3_narrow16_flagship': dict(n=16, h=16, w=16, cin=64, cout=512, k=3, seed=21),
+    '3x3_narrow16_rows24_res': dict(n=2, h=24, w=16, cin=32, cout=64, k=3, res=True, seed=22),
+    '3x3_narrow16_grouped': dict(n=4, h=16, w=16, cin=256, cout=256, k=3, groups=8, seed=23),
+    '3x3_narrow16_concat_up': dict(n=8, h=16, w=16, cin=64, cout=256, k=3, cin1=96, up1=True, seed=24),
+    '7x7_narrow16_fused_head': dict(n=4, h=32, w=16, cin=64, cout=128, k=7, fuse_cout=20, fuse_act='none', seed=25),
+    '5x5_narrow16_f32_out': dict(n=2, h=16, w=16, cin=32, cout=3, k=5, bn=False, act='tanh_scaled', out_f32=True, seed=26),
     '1x1_flagship_tile': dict(n=16, h=32, w=32, cin=96, cout=1024, k=1, seed=11),
     '1x1_flagship_tile_res': dict(n=16, h=32, w=32, cin=64, cout=1024, k=1, res=True, seed=13),
     'fused_head_256': dict(n=1, h=32, w=64, cin=64, cout=256, k=7, fuse_cout=20, fuse_act='none'),
@@ -206,6 +213,7 @@ SUBPIXEL_CASES = {
     'sp_flagship_tile': dict(n=8, h=128, w=128, c0=32, c1=64, cout=256, seed=5),
     'sp_two_cout_blocks': dict(n=4, h=64, w=64, c0=64, c1=64, cout=512, seed=7),
     'sp_no_bias': dict(n=1, h=32, w=64, c0=32, c1=32, cout=32, bias=False, seed=9),
+    'sp_narrow_lowres': dict(n=16, h=32, w=32, c0=64, c1=128, cout=256, seed=11),  # phase conv on 16 x 16 maps: MODE_N
 }
 
 
