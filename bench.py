@@ -129,6 +129,25 @@ def cpu_baseline(sd, tile, seconds_budget=25.):
                        f'decode + NMS) on {cores} threads, best of {reps}')
 
 
+def _sclk_mhz(dev):
+    """Current shader clock of this rank's GPU in MHz (None when no SMI binding is available): N GPUs of one node share
+    its power budget, so a bent weak-scaling curve shows up here first."""
+    try:
+        return float(torch.cuda.clock_rate(dev))
+    except Exception:
+        pass
+    try:
+        out = subprocess.run(['rocm-smi', '-d', str(dev.index or 0), '--showclocks', '--json'], capture_output=True,
+                             text=True, timeout=20).stdout
+        for card in json.loads(out).values():
+            for k, v in card.items():
+                if 'sclk' in k.lower() and 'mhz' in str(v).lower():
+                    return float(''.join(c for c in str(v).split('Mhz')[0].split('(')[-1] if c.isdigit() or c == '.'))
+    except Exception:
+        pass
+    return None
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
@@ -391,6 +410,14 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         dt = float(t.item())
+    sclk = _sclk_mhz(dev)  # right after the timed region, per rank
+    if dist:
+        t = torch.tensor([sclk if sclk is not None else -1.], dtype=torch.float64, device=dev)
+        allc = [torch.zeros_like(t) for _ in range(world)]
+        td.all_gather(allc, t)
+        sclk_all = [None if float(c.item()) < 0 else float(c.item()) for c in allc]
+    else:
+        sclk_all = [sclk]
     conv_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
     if args.profile_layers and rank == 0:
         print('device allocations (hipMalloc) during the timed steps:',
@@ -483,7 +510,10 @@ def main():
                                       == ('CpnResNeXt101UNet', 16, 512, 'bf16') else '')
                                    + ', synthetic weights of the reference shapes',
                        'tiles_per_gpu_per_step': args.batch, 'detections_last_step': ndet,
-                       'world_size_seen_by_rccl': rccl_world,
+                       'world_size_seen_by_rccl': rccl_world, 'sclk_mhz_per_rank_after_timing': sclk_all,
+                       'parity': 'bf16 conv graph: matched against the fp32 reference (per-layer tolerance, IoU match rate), '
+                                 'not bit-exact; decode / NMS bit-exact on identical head maps; precision=fp32 reproduces '
+                                 'the reference within 1e-4 (tests/test_gpu_model.py)',
                        'parallelism': f'tile-sharded x{world}, one process per GPU, no data-path collective',
                        'step_mode': 'forward() per step' if not args.pipeline else
                        'forward_pipelined(): post-processing of step i overlaps the conv graph of step i+1',
@@ -522,8 +552,9 @@ def slide_workload(args, model, dev, world, rank, dist):
     if dist:
         import torch.distributed as td
     S, crop, stride = args.slide, (args.tile, args.tile), (args.stride, args.stride)
-    # every rank holds the same slide (seeded) resident in HBM as uint8: 3 x 16384^2 = 805 MB
-    slide = torch.randint(0, 256, (3, S, S), dtype=torch.uint8, generator=torch.Generator().manual_seed(3)).to(dev)
+    # every rank holds the same slide (seeded, generated ON the device: no 805 MB host tensor per rank) resident in HBM as
+    # uint8: 3 x 16384^2 = 805 MB
+    slide = torch.randint(0, 256, (3, S, S), dtype=torch.uint8, device=dev, generator=torch.Generator(dev).manual_seed(3))
     ntiles = len(list(util.get_tiling_slices((S, S), crop, stride)[0]))
     kw = dict(crop_size=crop, strides=stride, batch_size=args.batch)
     warm = slide[:, :min(S, 4 * args.tile), :min(S, 4 * args.tile)]

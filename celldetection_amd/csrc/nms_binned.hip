@@ -7,8 +7,12 @@
 // Result: the SAME keep list (indices in stable descending-score order) as the dense path / torchvision, because
 // greedy NMS only ever relates boxes with IoU > thr >= 0, i.e. boxes that intersect:
 //   1. rank the boxes by (score desc, index asc) with the same keys as the dense path (stable radix sort);
-//   2. bin the ranked boxes by the grid cell of their centre; the cell edge is >= the largest box width/height, so
-//      two intersecting boxes always sit in the same or in adjacent cells (3x3 neighbourhood);
+//   2. bin the ranked boxes by the grid cell of their centre; the cell edge is the largest box extent, or -- when
+//      that is more than 4x the extent below which all but at most MAX_BIG boxes lie (an extent histogram in 1/8-octave
+//      buckets) -- that smaller extent, so two intersecting NORMAL boxes always sit
+//      in the same or in adjacent cells (3x3 neighbourhood).  The few OVERSIZED boxes (a tile-sized outlier on a slide
+//      of cells would otherwise collapse the grid to a handful of cells and make step 3 quadratic) are kept in a list:
+//      every box tests that list directly, and an oversized box scans every cell its extent reaches;
 //   3. per box: the list of its *suppressor candidates* = higher-ranked boxes of the neighbourhood with IoU > thr
 //      (same fp32 expression, same operation order as the dense mask kernel: count pass -> scan -> fill pass);
 //   4. resolve the greedy recurrence keep[r] = !any(keep[q], q in suppressors(r)) as a monotone fixed point:
@@ -32,7 +36,8 @@ namespace {
 typedef unsigned long long u64;
 
 struct GridParams {       // device-resident, written by grid_setup_kernel
-    float minx, miny, inv_cell;
+    float minx, miny, inv_cell, cell;
+    float big_thr;        // boxes whose larger extent exceeds this are "oversized" (kept in the big list)
     int gw, gh;
 };
 
@@ -47,6 +52,14 @@ __device__ __forceinline__ int f2ord(float f) {
 __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
 
 constexpr int MAX_CELLS = 1 << 22;
+constexpr int MAX_BIG = 256;         // oversized boxes handled through the list (every box tests all of them)
+constexpr int EXT_BUCKETS = 2048;    // extent histogram: float bits >> 20 (8 exponent bits + 3 mantissa bits)
+
+__device__ __forceinline__ float extent_of(const float4 b) {  // larger box extent; NaN / inf -> 0 (never oversized)
+    const float w = fabsf(b.z - b.x), h = fabsf(b.w - b.y);
+    const float e = fmaxf(w - w == 0.f ? w : 0.f, h - h == 0.f ? h : 0.f);
+    return e;
+}
 
 __global__ __launch_bounds__(256) void bn_keys_kernel(const float *__restrict__ scores, long P,
                                                      unsigned int *__restrict__ keys, unsigned int *__restrict__ vals) {
@@ -62,11 +75,13 @@ __global__ __launch_bounds__(256) void bn_keys_kernel(const float *__restrict__ 
 
 __global__ __launch_bounds__(256) void bn_gather_stats_kernel(const float *__restrict__ boxes,
                                                              const unsigned int *__restrict__ vals, long P,
-                                                             float4 *__restrict__ sboxes, Stats *__restrict__ st) {
+                                                             float4 *__restrict__ sboxes, Stats *__restrict__ st,
+                                                             unsigned int *__restrict__ ext_hist) {
     const long i = blockIdx.x * 256l + threadIdx.x;
     if (i >= P) return;
     const float4 b = ((const float4 *) boxes)[vals[i]];
     sboxes[i] = b;
+    atomicAdd(ext_hist + (__float_as_uint(extent_of(b)) >> 20), 1u);
     const float cx = 0.5f * (b.x + b.z), cy = 0.5f * (b.y + b.w), w = b.z - b.x, h = b.w - b.y;
     if (cx - cx == 0.f) { atomicMin(&st->min_cx, f2ord(cx)); atomicMax(&st->max_cx, f2ord(cx)); }  // finite only
     if (cy - cy == 0.f) { atomicMin(&st->min_cy, f2ord(cy)); atomicMax(&st->max_cy, f2ord(cy)); }
@@ -80,13 +95,27 @@ __global__ void bn_stats_init_kernel(Stats *st) {
     st->max_w = st->max_h = f2ord(0.f);
 }
 
-__global__ void bn_grid_setup_kernel(const Stats *__restrict__ st, GridParams *__restrict__ g) {
+__global__ void bn_grid_setup_kernel(const Stats *__restrict__ st, const unsigned int *__restrict__ ext_hist,
+                                     GridParams *__restrict__ g) {
     float minx = ord2f(st->min_cx), miny = ord2f(st->min_cy), maxx = ord2f(st->max_cx), maxy = ord2f(st->max_cy);
     if (!(minx <= maxx)) { minx = 0.f; maxx = 0.f; }  // no finite box at all
     if (!(miny <= maxy)) { miny = 0.f; maxy = 0.f; }
-    // cell edge >= the largest box extent (+0.1 %: rounding of the centre / division never splits intersecting boxes
-    // over non-adjacent cells); doubled until the grid fits MAX_CELLS
-    float cell = fmaxf(fmaxf(ord2f(st->max_w), ord2f(st->max_h)) * 1.001f, 1e-3f);
+    // cell edge >= the extent of all but at most MAX_BIG boxes: the upper edge of the first histogram bucket (from the
+    // top) at which the number of larger boxes would exceed MAX_BIG; (+0.1 %: rounding of the centre / division never
+    // splits intersecting normal boxes over non-adjacent cells); doubled until the grid fits MAX_CELLS
+    unsigned int above = 0;
+    int bstar = EXT_BUCKETS - 1;
+    for (; bstar > 0; --bstar) {
+        if (above + ext_hist[bstar] > (unsigned int) MAX_BIG) break;
+        above += ext_hist[bstar];
+    }
+    // every box in buckets > bstar is oversized; bucket bstar's upper edge bounds the normal ones
+    const float max_ext = fmaxf(ord2f(st->max_w), ord2f(st->max_h));
+    float thr = __uint_as_float((unsigned int) (bstar + 1) << 20);
+    // the list only pays when the largest boxes are real outliers: a grid four times coarser per axis still has 16x fewer
+    // boxes per cell than no grid, while every listed box costs one IoU test per box of the set
+    if (!(max_ext > 4.f * thr)) thr = max_ext;
+    float cell = fmaxf(thr * 1.001f, 1e-3f);
     long gw, gh;
     for (;;) {
         gw = (long) floorf((maxx - minx) / cell) + 1;
@@ -94,7 +123,8 @@ __global__ void bn_grid_setup_kernel(const Stats *__restrict__ st, GridParams *_
         if (gw > 0 && gh > 0 && gw * gh <= MAX_CELLS) break;
         cell *= 2.f;
     }
-    g->minx = minx; g->miny = miny; g->inv_cell = 1.f / cell;
+    g->minx = minx; g->miny = miny; g->inv_cell = 1.f / cell; g->cell = cell;
+    g->big_thr = cell / 1.001f;  // (>= thr: a grid that had to be coarsened makes fewer boxes oversized)
     g->gw = (int) gw; g->gh = (int) gh;
 }
 
@@ -106,14 +136,20 @@ __device__ __forceinline__ void cell_of(const float4 b, const GridParams &g, int
 
 __global__ __launch_bounds__(256) void bn_cell_kernel(const float4 *__restrict__ sboxes, long P,
                                                      const GridParams *__restrict__ gp, unsigned int *__restrict__ cid,
-                                                     unsigned int *__restrict__ rank) {
+                                                     unsigned int *__restrict__ rank, unsigned int *__restrict__ big,
+                                                     unsigned int *__restrict__ nbig) {
     const long i = blockIdx.x * 256l + threadIdx.x;
     if (i >= P) return;
     const GridParams g = *gp;
     int cx, cy;
-    cell_of(sboxes[i], g, cx, cy);
+    const float4 b = sboxes[i];
+    cell_of(b, g, cx, cy);
     cid[i] = (unsigned int) (cy * g.gw + cx);
     rank[i] = (unsigned int) i;
+    if (extent_of(b) > g.big_thr) {  // at most MAX_BIG by construction of the threshold
+        const unsigned int k = atomicAdd(nbig, 1u);
+        if (k < (unsigned int) MAX_BIG) big[k] = (unsigned int) i;
+    }
 }
 
 __global__ __launch_bounds__(256) void bn_cell_bounds_kernel(const unsigned int *__restrict__ scid, long P,
@@ -146,7 +182,9 @@ __global__ __launch_bounds__(256) void bn_edges_kernel(const float4 *__restrict_
                                                       const unsigned int *__restrict__ cbegin,
                                                       const unsigned int *__restrict__ cend, float thr,
                                                       u64 *__restrict__ deg, const u64 *__restrict__ off,
-                                                      unsigned int *__restrict__ edges, u64 max_edges) {
+                                                      unsigned int *__restrict__ edges, u64 max_edges,
+                                                      const unsigned int *__restrict__ big,
+                                                      const unsigned int *__restrict__ nbig) {
     const long r = blockIdx.x * 256l + threadIdx.x;
     if (r >= P) return;
     const GridParams g = *gp;
@@ -155,22 +193,37 @@ __global__ __launch_bounds__(256) void bn_edges_kernel(const float4 *__restrict_
     cell_of(me, g, cx, cy);
     u64 n = 0;
     const u64 base = FILL ? off[r] : 0;
-    for (int dy = -1; dy <= 1; ++dy) {
-        const int y = cy + dy;
-        if (y < 0 || y >= g.gh) continue;
-        for (int dx = -1; dx <= 1; ++dx) {
-            const int x = cx + dx;
-            if (x < 0 || x >= g.gw) continue;
+    // normal box: the 3 x 3 neighbourhood of its centre cell; oversized box: every cell its extent (+ one cell: the other
+    // box's half extent and the rounding margin) reaches.  Oversized candidates are skipped here and taken from the list.
+    int x0 = cx - 1, x1 = cx + 1, y0 = cy - 1, y1 = cy + 1;
+    if (extent_of(me) > g.big_thr) {
+        int ax, ay, bx, by;
+        cell_of(make_float4(me.x, me.y, me.x, me.y), g, ax, ay);
+        cell_of(make_float4(me.z, me.w, me.z, me.w), g, bx, by);
+        x0 = min(ax, bx) - 1; x1 = max(ax, bx) + 1; y0 = min(ay, by) - 1; y1 = max(ay, by) + 1;
+    }
+    for (int y = max(y0, 0); y <= min(y1, g.gh - 1); ++y)
+        for (int x = max(x0, 0); x <= min(x1, g.gw - 1); ++x) {
             const unsigned int c = (unsigned int) (y * g.gw + x);
             const unsigned int e = cend[c];
             for (unsigned int k = cbegin[c]; k < e; ++k) {
                 const unsigned int q = srank[k];
                 if (q >= (unsigned int) r) break;  // ranks ascend within a cell
-                if (suppresses(sboxes[q], me, thr)) {
+                const float4 hi = sboxes[q];
+                if (extent_of(hi) > g.big_thr) continue;
+                if (suppresses(hi, me, thr)) {
                     if (FILL && base + n < max_edges) edges[base + n] = q;
                     ++n;
                 }
             }
+        }
+    const unsigned int nb = min(*nbig, (unsigned int) MAX_BIG);
+    for (unsigned int k = 0; k < nb; ++k) {
+        const unsigned int q = big[k];
+        if (q >= (unsigned int) r) continue;
+        if (suppresses(sboxes[q], me, thr)) {
+            if (FILL && base + n < max_edges) edges[base + n] = q;
+            ++n;
         }
     }
     if (!FILL) deg[r] = n;
@@ -215,7 +268,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Layout {
     size_t keys_in, keys_out, vals_in, vals_out, sboxes, cid_in, cid_out, rank_in, rank_out, cbegin, cend, deg, off,
-        state, stats, grid, counter, edges, tmp, tmp_bytes, total;
+        state, stats, grid, counter, ext_hist, big, edges, tmp, tmp_bytes, total;
 };
 
 Layout layout(int64_t P, int64_t max_edges) {
@@ -230,6 +283,7 @@ Layout layout(int64_t P, int64_t max_edges) {
     L.deg = take(n * 8); L.off = take(n * 8);
     L.state = take(n);
     L.stats = take(sizeof(Stats)); L.grid = take(sizeof(GridParams)); L.counter = take(256);
+    L.ext_hist = take((size_t) EXT_BUCKETS * 4); L.big = take((size_t) MAX_BIG * 4);
     L.edges = take((size_t) (max_edges > 0 ? max_edges : 1) * 4);
     size_t t1 = 0, t2 = 0;
     (void) rocprim::radix_sort_pairs(nullptr, t1, (unsigned int *) nullptr, (unsigned int *) nullptr,
@@ -275,7 +329,9 @@ int cpn_nms_binned(const float *boxes, const float *scores, int64_t P, float thr
     auto *state = (unsigned char *) (ws + L.state);
     auto *stats = (Stats *) (ws + L.stats);
     auto *grid = (GridParams *) (ws + L.grid);
-    auto *counter = (unsigned int *) (ws + L.counter);
+    auto *counter = (unsigned int *) (ws + L.counter);  // [0] undecided boxes of a sweep, [2..3] keep count, [8] big-list length
+    auto *nbig = counter + 8;
+    auto *ext_hist = (unsigned int *) (ws + L.ext_hist), *big = (unsigned int *) (ws + L.big);
     auto *edges = (unsigned int *) (ws + L.edges);
     const unsigned blocks = (unsigned) ((P + 255) / 256);
     size_t tmp = L.tmp_bytes;
@@ -286,9 +342,13 @@ int cpn_nms_binned(const float *boxes, const float *scores, int64_t P, float thr
     if (e != hipSuccess) return cpn::check_hip(e, "cpn_nms_binned: score sort");
     // 2. ranked boxes + extent statistics -> grid
     hipLaunchKernelGGL(bn_stats_init_kernel, dim3(1), dim3(1), 0, st, stats);
-    hipLaunchKernelGGL(bn_gather_stats_kernel, dim3(blocks), dim3(256), 0, st, boxes, vals_out, (long) P, sboxes, stats);
-    hipLaunchKernelGGL(bn_grid_setup_kernel, dim3(1), dim3(1), 0, st, stats, grid);
-    hipLaunchKernelGGL(bn_cell_kernel, dim3(blocks), dim3(256), 0, st, sboxes, (long) P, grid, cid_in, rank_in);
+    e = hipMemsetAsync(ext_hist, 0, (size_t) EXT_BUCKETS * 4, st);
+    if (e == hipSuccess) e = hipMemsetAsync(counter, 0, 256, st);
+    if (e != hipSuccess) return cpn::check_hip(e, "cpn_nms_binned: memset");
+    hipLaunchKernelGGL(bn_gather_stats_kernel, dim3(blocks), dim3(256), 0, st, boxes, vals_out, (long) P, sboxes, stats,
+                       ext_hist);
+    hipLaunchKernelGGL(bn_grid_setup_kernel, dim3(1), dim3(1), 0, st, stats, ext_hist, grid);
+    hipLaunchKernelGGL(bn_cell_kernel, dim3(blocks), dim3(256), 0, st, sboxes, (long) P, grid, cid_in, rank_in, big, nbig);
     tmp = L.tmp_bytes;
     e = rocprim::radix_sort_pairs(ws + L.tmp, tmp, cid_in, cid_out, rank_in, rank_out, (size_t) P, 0, 22, st);
     if (e != hipSuccess) return cpn::check_hip(e, "cpn_nms_binned: cell sort");
@@ -298,7 +358,7 @@ int cpn_nms_binned(const float *boxes, const float *scores, int64_t P, float thr
     hipLaunchKernelGGL(bn_cell_bounds_kernel, dim3(blocks), dim3(256), 0, st, cid_out, (long) P, cbegin, cend);
     // 3. suppressor candidates: count -> scan -> fill
     hipLaunchKernelGGL(bn_edges_kernel<false>, dim3(blocks), dim3(256), 0, st, sboxes, (long) P, grid, rank_out, cbegin,
-                       cend, thresh, deg, (const u64 *) nullptr, (unsigned int *) nullptr, (u64) 0);
+                       cend, thresh, deg, (const u64 *) nullptr, (unsigned int *) nullptr, (u64) 0, big, nbig);
     tmp = L.tmp_bytes;
     e = rocprim::exclusive_scan(ws + L.tmp, tmp, deg, off, (u64) 0, (size_t) P, rocprim::plus<u64>(), st);
     if (e != hipSuccess) return cpn::check_hip(e, "cpn_nms_binned: scan");
@@ -313,14 +373,15 @@ int cpn_nms_binned(const float *boxes, const float *scores, int64_t P, float thr
         return cpn::fail(CPN_E_WORKSPACE, "cpn_nms_binned: more suppressor candidates than max_edges (retry with the "
                                           "returned edges_needed)");
     hipLaunchKernelGGL(bn_edges_kernel<true>, dim3(blocks), dim3(256), 0, st, sboxes, (long) P, grid, rank_out, cbegin,
-                       cend, thresh, deg, off, edges, (u64) max_edges);
+                       cend, thresh, deg, off, edges, (u64) max_edges, big, nbig);
     // 4. fixed point (every sweep decides at least the lowest undecided rank; the host looks at the counter every
     //    few sweeps)
     e = hipMemsetAsync(state, 0, (size_t) P, st);
     if (e != hipSuccess) return cpn::check_hip(e, "cpn_nms_binned: memset");
     int nsweeps = 0;
-    for (;;) {
-        constexpr int CHUNK = 4;
+    // the host looks at the counter after 4, 8, 16, ... 64 sweeps (a sweep over decided boxes is cheap; a long suppression
+    // chain needs one sweep per link and must not cost one host round trip per four of them)
+    for (int CHUNK = 4;; CHUNK = CHUNK < 64 ? 2 * CHUNK : 64) {
         for (int k = 0; k < CHUNK; ++k) {
             e = hipMemsetAsync(counter, 0, 4, st);
             if (e != hipSuccess) return cpn::check_hip(e, "cpn_nms_binned: memset");
@@ -333,7 +394,7 @@ int cpn_nms_binned(const float *boxes, const float *scores, int64_t P, float thr
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) return cpn::check_hip(e, "cpn_nms_binned: resolve");
         if (left == 0) break;
-        if (nsweeps > P + CHUNK) return cpn::fail(CPN_E_INVALID, "cpn_nms_binned: fixed point did not converge");
+        if (nsweeps > P + 128) return cpn::fail(CPN_E_INVALID, "cpn_nms_binned: fixed point did not converge");
     }
     if (sweeps) *sweeps = nsweeps;
     // 5. kept ranks, in rank order (deg / off are reused as flag / position arrays)

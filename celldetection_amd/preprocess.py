@@ -38,8 +38,25 @@ def _order_statistics(x: torch.Tensor, ranks):
         check(_lib.load().cpn_histogram(ptr(flat), _DT[x.dtype], n, ptr(hist), stream_ptr()), 'histogram')
         cum = torch.cumsum(hist.to(torch.int64) & 0xFFFFFFFF, 0).cpu().numpy()  # bins are uint32 counters
         return [float(np.searchsorted(cum, r, side='right')) for r in ranks]
+    # float images: the (up to four) ranks sit in the two tails of the distribution.  ONE top-k per tail and ONE read-back
+    # instead of a kthvalue (= a full selection pass + a host sync) per rank; a full sort only when a rank is far from both
+    # ends (percentiles near 50: not what the slide normalisation asks for)
     flat = flat.float()
-    return [float(torch.kthvalue(flat, r + 1).values.item()) for r in ranks]
+    lo_r = [r for r in ranks if r < n - 1 - r]
+    hi_r = [r for r in ranks if r >= n - 1 - r]
+    k_lo, k_hi = (max(lo_r) + 1 if lo_r else 0), (n - min(hi_r) if hi_r else 0)
+    if max(k_lo, k_hi) > max(4096, n // 64):
+        srt = torch.sort(flat).values
+        return srt[torch.tensor(ranks, device=x.device)].cpu().tolist()
+    parts = []
+    if lo_r:
+        small = torch.topk(flat, k_lo, largest=False, sorted=True).values  # ascending: position r
+        parts.append(small[torch.tensor(lo_r, device=x.device)])
+    if hi_r:
+        large = torch.topk(flat, k_hi, largest=True, sorted=True).values   # descending: position n - 1 - r
+        parts.append(large[torch.tensor([n - 1 - r for r in hi_r], device=x.device)])
+    vals = torch.cat(parts).cpu().tolist()
+    return [vals[(lo_r + hi_r).index(r)] for r in ranks]
 
 
 def normalize_percentile(image: torch.Tensor, percentile=99.9, to_uint8=True):

@@ -780,6 +780,42 @@ def test_nms_binned_equals_dense_and_oracle(dev, P, extent):
               f'workspace {st["workspace_bytes"] / 1e6:.1f} MB')
 
 
+@pytest.mark.parametrize('n_big,chain', [(1, 0), (7, 0), (300, 0), (3, 400)])
+def test_nms_binned_outliers_and_long_chains(dev, n_big, chain):
+    """a few tile-sized outlier boxes among 40 000 cell-sized ones must not collapse the grid (they go through the
+    oversized list: every box tests them, they scan every cell they reach), more outliers than the list holds fall back to
+    the coarse grid, and a suppression chain of hundreds of links (box i suppresses i+1 only) resolves without one host
+    round trip per four sweeps.  Keep lists = dense path = oracle in every case."""
+    import cpn_oracle as orc
+    from celldetection_amd import ops
+    P = 40000
+    rng = np.random.default_rng(n_big * 1000 + chain)
+    xy = rng.uniform(0, 4000, (P, 2)).astype(np.float32)
+    wh = rng.uniform(2, 20, (P, 2)).astype(np.float32)
+    boxes = np.concatenate((xy, xy + wh), 1)
+    scores = rng.random(P).astype(np.float32)
+    big = rng.choice(P, n_big, replace=False)
+    c = rng.uniform(500, 3500, (n_big, 2)).astype(np.float32)
+    half = rng.uniform(300, 2000, (n_big, 2)).astype(np.float32)
+    boxes[big] = np.concatenate((c - half, c + half), 1)
+    scores[big[::2]] = 2. + rng.random(len(big[::2])).astype(np.float32)  # some outliers outrank everything, some do not
+    if chain:  # boxes shifted by 45 % of their width: IoU(i, i+1) = 0.38 > thr, IoU(i, i+2) = 0.05 < thr; descending scores
+        idx = rng.choice(np.setdiff1d(np.arange(P), big), chain, replace=False)
+        x0 = 5000. + 4.5 * np.arange(chain, dtype=np.float32)
+        boxes[idx] = np.stack((x0, np.full(chain, 5000., np.float32), x0 + 10., np.full(chain, 5010., np.float32)), 1)
+        scores[idx] = 1.9 - 1e-3 * np.arange(chain, dtype=np.float32)
+    b, s = torch.as_tensor(boxes).to(dev), torch.as_tensor(scores).to(dev)
+    got, st = ops.nms_binned(b, s, .2, return_stats=True)
+    dense, cnt = ops._nms_segments(b, s, [0, P], .2)
+    np.testing.assert_array_equal(got.cpu().numpy(), dense[:cnt[0]].cpu().numpy())
+    np.testing.assert_array_equal(got.cpu().numpy(), orc.nms(boxes, scores, .2))
+    print(f'outliers {n_big} chain {chain}: kept {got.numel()}, edges {st["edges"]}, sweeps {st["sweeps"]}')
+    if chain:
+        assert st['sweeps'] >= chain // 2  # (the chain really is sequential: alternate links survive)
+    if n_big <= 7:
+        assert st['edges'] < 40 * P  # the grid did not collapse: a handful of candidates per box, not thousands
+
+
 def test_nms_binned_slide_scale(dev):
     """10^6 detections spread like cells on a slide: < 1 GB of workspace (the dense mask would need 125 GB), the keep
     list is sorted by score, idempotent, and agrees with the dense path on a 60 000-box crop of the same set."""
