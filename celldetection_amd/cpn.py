@@ -140,10 +140,19 @@ class _Engine:
         ms, fl = (c_float * nops)(), (c_double * nops)()
         self.run(x, order_total, refinement, _timed=(ms, fl))
         out = []
+        from ctypes import c_int32, c_int64
+        n, _, h, w = x.shape
         for i, op in enumerate(self.plan.ops):
+            oh, ow = c_int32(0), c_int32(0)
+            if op.get('dst') is not None:  # output size of the op (tile selection of the conv kernel depends on it)
+                off, cs = c_int64(0), c_int32(0)
+                if lib.cpn_plan_tensor_info(self.handle, n, h, w, int(op['dst']), off, oh, ow, cs) != 0:
+                    oh, ow = c_int32(0), c_int32(0)
+            elif op.get('out_index') is not None:
+                lib.cpn_plan_output_dims(self.handle, h, w, int(op['out_index']), oh, ow)
             out.append(dict(index=i, op=op['op'], name=op.get('w', ''), ms=float(ms[i]), gflop=float(fl[i]) / 1e9,
                             k=op.get('k'), cin=op.get('cin'), cout=op.get('cout'), groups=op.get('groups'),
-                            stride=op.get('stride')))
+                            stride=op.get('stride'), out_h=int(oh.value), out_w=int(ow.value)))
         return out
 
     def activation_absmax(self, x: torch.Tensor, order_total: int, refinement: bool):
