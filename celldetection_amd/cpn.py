@@ -122,7 +122,9 @@ class _Engine:
         if per_image <= 0:
             _lib.check(per_image or _lib.E_INVALID, 'plan_max_tensor_elements')
         limit = (2 ** 31 - 1) // (2 if self.precision == 'bf16' else 1)  # sources: 2^31 bytes (fp32 path: elements)
-        return max(1, min(n, limit // per_image))
+        cap = max(1, min(n, limit // per_image))
+        runs = -(-n // cap)       # balanced sub-batches (8 tiles with room for 7 run as 4 + 4, not 7 + 1)
+        return -(-n // runs)
 
     def executed_flops(self, n, h, w):
         """2*MAC FLOPs the MFMA loops execute for a batch of n (the sum over the sub-batches the engine splits it into)."""

@@ -12,9 +12,12 @@ csv.field_size_limit(1 << 30)
 
 def short(name):
     name = re.sub(r'^void ', '', name)
-    m = re.match(r'(?:cpn::|\(anonymous namespace\)::)?((?:cpn_fp8::)?\w+)(<[^>]*>)?', name)
-    if m and ('cpn' in name or 'anonymous' in name):
-        return m.group(1) + (m.group(2) or '')
+    if 'cpn' in name or 'anonymous' in name:
+        # our kernels: drop the namespaces (cpn::, cpn::stem::, cpn::sparse::, (anonymous namespace)::) except the cpn_fp8::
+        # marker of the e4m3 compilation unit; keep the kernel name and its template arguments
+        m = re.match(r'((?:\w+|\(anonymous namespace\))::)*(\w+)(<[^>]*>)?', name)
+        if m:
+            return ('cpn_fp8::' if name.startswith('cpn_fp8::') else '') + m.group(2) + (m.group(3) or '')
     return name[:70]
 
 
