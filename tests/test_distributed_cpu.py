@@ -158,3 +158,17 @@ def test_slide_loop_reproduces_reference_stitching_with_duplicates():
     assert scores.shape[0] == int(g['pre_nms_count'])
     keep = orc.nms(boxes.numpy(), scores.numpy(), float(g['nms_thresh']))
     np.testing.assert_array_equal(boxes.numpy()[keep], g['final.boxes'])
+
+
+def test_mid_loop_compaction_keeps_the_result(monkeypatch):
+    """The slide loop selects the kept rows every COMPACT_EVERY batches (bounded memory: ADVICE r2); the result must not
+    depend on where those compactions fall."""
+    img = torch.zeros(1, 3, 200, 328)
+    kw = dict(crop_size=(64, 96), strides=(48, 64), batch_size=3, forward_fn=fake_forward, ops_fns=cpu_ops(),
+              stitching_rule='nms,ex_br', rank=0, world_size=1)
+    ref = reference_loop(img, (64, 96), (48, 64), 4, _Model.nms_thresh)
+    for every in (1, 2, 3, 1000):
+        monkeypatch.setattr(inference, 'COMPACT_EVERY', every)
+        got = inference.tiled_inference(_Model(), img, **kw)
+        for k, v in got.items():
+            np.testing.assert_array_equal(v.numpy(), ref[k], err_msg=f'{k} (COMPACT_EVERY={every})')

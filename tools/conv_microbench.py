@@ -19,6 +19,8 @@ CASES = {
     'dec3cat': dict(n=16, h=128, w=128, cin=256, cin1=512, cout=512, k=3),
     'pw1024': dict(n=16, h=32, w=32, cin=1024, cout=1024, k=1),
     'pw256': dict(n=16, h=128, w=128, cin=256, cout=256, k=1),
+    'pw512': dict(n=16, h=64, w=64, cin=512, cout=512, k=1),
+    'pw2048': dict(n=16, h=16, w=16, cin=2048, cout=2048, k=1),
     'ref7': dict(n=16, h=512, w=512, cin=64, cout=64, k=7),
     'c64': dict(n=16, h=512, w=512, cin=64, cout=64, k=3),
     'grp': dict(n=16, h=32, w=32, cin=1024, cout=1024, k=3, groups=32),
