@@ -96,3 +96,67 @@ def test_contours2labels_slide_scale():
     present[lab.reshape(-1).long().unique()] = True
     assert int(present[1:].sum()) >= 0.999 * K  # (contours clipped onto the same border pixels may coincide)
     assert lab.shape[2] >= 2 and int((lab[..., 0] > 0).sum()) > int((lab[..., 1] > 0).sum())
+
+
+def test_fill_rule_agrees_with_independent_rasterisers_away_from_the_boundary():
+    """NOT a pin of cv2's fill rule (cv2 is absent) -- a sanity bound on the restated rule: for random
+    simple (star-shaped) and self-intersecting polygons with integer vertices the oracle's filled mask must agree with two
+    independent polygon rasterisers -- ``matplotlib.path.Path.contains_points`` at the pixel centres (non-zero winding /
+    even-odd differ only for self-intersecting polygons, which are compared with even-odd = cv2's scan-line pairing) and
+    ``PIL.ImageDraw.polygon`` -- at every pixel farther than one pixel from the polygon's boundary; and it must contain every
+    boundary pixel of the 8-connected outline."""
+    mpath = pytest.importorskip('matplotlib.path')
+    pil_draw = pytest.importorskip('PIL.ImageDraw')
+    from PIL import Image
+    import labels_oracle as lo
+    rng = np.random.default_rng(0)
+
+    def dist_to_boundary(pts, h, w):
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+        d = np.full((h, w), np.inf)
+        n = len(pts)
+        for i in range(n):
+            a, b = pts[i].astype(np.float64), pts[(i + 1) % n].astype(np.float64)
+            ab = b - a
+            t = np.clip(((xx - a[0]) * ab[0] + (yy - a[1]) * ab[1]) / max(ab @ ab, 1e-12), 0., 1.)
+            d = np.minimum(d, np.hypot(xx - (a[0] + t * ab[0]), yy - (a[1] + t * ab[1])))
+        return d
+
+    checked = 0
+    for case in range(40):
+        h, w = int(rng.integers(24, 90)), int(rng.integers(24, 90))
+        s = int(rng.integers(3, 24))
+        if case % 2 == 0:  # star-shaped around the centre: simple polygon
+            ang = np.sort(rng.uniform(0, 2 * np.pi, s))
+            rad = rng.uniform(.25, .48, s) * min(h, w)
+            pts = np.stack((w / 2 + rad * np.cos(ang), h / 2 + rad * np.sin(ang)), 1)
+        else:              # arbitrary vertex order: self-intersections
+            pts = np.stack((rng.uniform(1, w - 2, s), rng.uniform(1, h - 2, s)), 1)
+        pts = np.rint(pts).astype(np.int32)
+        mask = lo.fill_polygon(pts, 0, 0, w, h)
+        far = dist_to_boundary(pts, h, w) > 1.0
+        yy, xx = np.mgrid[0:h, 0:w]
+        if case % 2 == 0:
+            inside = mpath.Path(pts.astype(np.float64)).contains_points(np.stack((xx.ravel(), yy.ravel()), 1)).reshape(h, w)
+            assert np.array_equal(mask[far], inside[far]), f'case {case}: differs from matplotlib away from the boundary'
+        # even-odd reference by ray casting (what scan-line pairing computes), also for self-intersecting polygons
+        eo = np.zeros((h, w), bool)
+        n = len(pts)
+        for i in range(n):
+            (ax, ay), (bx, by) = pts[i].astype(np.float64), pts[(i + 1) % n].astype(np.float64)
+            if ay == by:
+                continue
+            cond = ((ay <= yy) & (yy < by)) | ((by <= yy) & (yy < ay))
+            xcross = ax + (yy - ay) * (bx - ax) / (by - ay)
+            eo ^= cond & (xx < xcross)
+        assert np.array_equal(mask[far], eo[far]), f'case {case}: differs from the even-odd rule away from the boundary'
+        if case % 2 == 0:
+            img = Image.new('1', (w, h), 0)
+            pil_draw.Draw(img).polygon([tuple(int(v) for v in p) for p in pts], fill=1, outline=1)
+            pil = np.array(img, bool)
+            assert np.array_equal(mask[far], pil[far]), f'case {case}: differs from PIL away from the boundary'
+        for i in range(n):  # the outline itself is part of the fill (drawContours draws the edges, too)
+            for x, y in lo._line_pixels(*pts[i], *pts[(i + 1) % n]):
+                assert mask[y, x]
+        checked += int(far.sum())
+    assert checked > 50000
