@@ -1,8 +1,8 @@
-"""In-process A/B of conv-kernel variants that are selected per launch through environment switches (CPN_PWR, CPN_T64,
-CPN_RW ...): ONE model build, then the per-op profile of the conv graph under every setting (min over repeats), printed
+"""In-process A/B of conv-kernel variants that are selected per launch through environment switches (CPN_PWR, CPN_RW, or a
+switch added for an experiment): ONE model build, then the per-op profile of the conv graph under every setting (min over repeats), printed
 per layer class and for the layers whose time changes.
 
-    python tools/ab_layers.py [--model CpnResNeXt101UNet] [--batch 16] [--tile 512] "CPN_PWR=1" "CPN_T64=1" "CPN_PWR=1 CPN_T64=1"
+    python tools/ab_layers.py [--model CpnResNeXt101UNet] [--batch 16] [--tile 512] "CPN_PWR=1" "CPN_RW=1" "CPN_PWR=1 CPN_RW=1"
 """
 import argparse
 import os
