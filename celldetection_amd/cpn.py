@@ -9,6 +9,8 @@ output ``OrderedDict`` of per-image lists.  Training (``compute_loss``, cpn.py:4
 The conv stack runs through the native graph executor of libcpn_hip.so (bf16 NHWC, MFMA), the post-processing
 through the fused decode / NMS kernels; PyTorch only provides device memory, streams and indexing glue.
 """
+import os
+import warnings
 from collections import OrderedDict
 from ctypes import c_void_p
 
@@ -206,7 +208,6 @@ class _Engine:
 
     def _graph_slot(self, key, x, dt, order_total, refinement, gated):
         """The hipGraph instance to replay for this run, or None (shape seen for the first time / graphs disabled)."""
-        import os
         if os.environ.get('CPN_HIP_GRAPH', '1') == '0' or self._graph_broken:
             return None
         st = self._graphs.get(key)
@@ -240,7 +241,6 @@ class _Engine:
                         self._launch(slot['x'], dt, h, w, slot['ws'], need, slot['outputs'], slot['flag'], n)
                 slot['graph'] = g
             except Exception as e:  # capture is an optimisation: fall back to eager launches, loudly
-                import warnings
                 warnings.warn(f'hipGraph capture of the conv graph failed ({type(e).__name__}: {e}); using eager launches',
                               RuntimeWarning)
                 self._graph_broken = True
@@ -453,7 +453,6 @@ class CPN(nn.Module):
                 if self._fp8_scales is None:
                     if calibration_input is None:
                         raise RuntimeError("precision 'fp8' needs activation scales: call calibrate_fp8(batch) first")
-                    import warnings
                     warnings.warn("precision 'fp8': calibrating the static activation scales on the first forwarded "
                                   'batch; activations of later batches that exceed its range saturate at 448 * scale. '
                                   'Call calibrate_fp8() on representative tiles instead.', RuntimeWarning, stacklevel=3)
