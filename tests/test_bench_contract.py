@@ -1,0 +1,72 @@
+"""The JSON line contract of bench.py, checked on the lines this round committed under profiles/ (produced on the MI355X by
+tools/gpu_round_pass.sh): every field the driver reads is present and self-consistent, the roofline numbers recompute from
+their own parts, and the score-gated line prices EXECUTED FLOPs."""
+import glob
+import json
+import os
+
+import pytest
+
+P = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles')
+LINES = sorted(glob.glob(os.path.join(P, 'r03_bench_*.json')))
+
+
+def _load(path):
+    with open(path) as f:
+        return json.loads(f.read().strip().splitlines()[-1])
+
+
+def test_round_three_lines_are_committed():
+    names = {os.path.basename(p) for p in LINES}
+    for want in ('r03_bench_n1.json', 'r03_bench_sparse_heads_n1.json', 'r03_bench_slide_n1.json',
+                 'r03_bench_configs1_resnet18fpn.json', 'r03_bench_configs4_resnet50fpn_bf16.json',
+                 'r03_bench_configs4_resnet50fpn_fp8.json', 'r03_bench_fp8_n1.json'):
+        assert want in names, want
+
+
+@pytest.mark.parametrize('path', LINES, ids=[os.path.basename(p) for p in LINES])
+def test_line_contract(path):
+    d = _load(path)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
+        assert k in d, k
+    assert d['unit'] == 'tiles/s' and d['higher_is_better'] is True and d['vs_baseline'] is None and d['data'] == 'synthetic'
+    assert d['metric'].startswith('tiles/sec (3x') and d['dtype'] in ('bf16', 'fp8') and d['n_gpus'] == 1
+    assert d['scaling'] in ('weak', 'strong') and isinstance(d['config'].get('workload'), str) and 'model' not in d['config']
+    r = d['roofline']
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] == (5000. if d['dtype'] == 'fp8' else 2500.)
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and 0.2 < r['frac'] < 0.75
+    assert 'traffic' in r
+    if d['scaling'] == 'weak':  # tile workload: value = tiles of all steps / time; the conv graph is bracketed by HIP events
+        tiles = d['config']['tiles_per_gpu_per_step']
+        assert abs(d['value'] - tiles / (d['ms_per_step'] / 1e3)) / d['value'] < 1e-6
+        assert r['launch_ms'] <= d['ms_per_step'] * 1.01
+        assert abs(r['executed_frac'] - r['executed_gflop_per_launch'] / r['launch_ms'] / r['peak']) < 1e-9
+        assert r['executed_gflop_per_launch'] > 0
+        bb, dom = r['backbone_stack'], r['dominant_kernel']
+        assert bb is not None and dom is not None and 0 < bb['frac'] < 0.75 and 0.3 < dom['frac'] < 0.75
+        assert abs(bb['frac'] - bb['algorithmic_gflop'] / bb['ms'] / r['peak']) < 1e-9
+
+
+def test_default_line_is_the_dense_reference_graph_with_cpu_baseline():
+    d = _load(os.path.join(P, 'r03_bench_n1.json'))
+    assert 'configs[2]' in d['config']['workload'] and d['config']['heads'] == 'dense (reference graph)'
+    assert d['config']['world_size_seen_by_rccl'] is None  # one rank: no process group, RCCL never initialised
+    r = d['roofline']
+    assert abs(r['achieved'] - r['algorithmic_gflop_per_launch'] / r['launch_ms']) < 1e-6  # ALGORITHMIC FLOPs of the reference graph
+    assert abs(r['algorithmic_gflop_per_launch'] - 16 * 2392.83) < 1. and r['traffic'] > 2e10
+    assert r['executed_gflop_per_launch'] < r['algorithmic_gflop_per_launch']  # the sub-pixel triples execute fewer MACs
+    c = d['cpu_baseline']
+    assert c['kind'] == 'port' and c['unit'] == 'tiles/s' and c['cores'] >= 1 and 0 < c['value'] < 10 and c['sample']
+
+
+def test_score_gated_line_prices_executed_flops():
+    d = _load(os.path.join(P, 'r03_bench_sparse_heads_n1.json'))
+    r, c = d['roofline'], d['config']
+    assert 'score-gated' in c['heads'] and 0 < c['proposal_density'] < 0.2 and c['proposals_per_step'] > 1000
+    ex = r['executed_gflop_per_step']
+    assert abs(ex - (r['executed_gflop_per_launch'] + r['sparse_kernel_gflop_per_step'])) < 1e-6
+    assert abs(r['frac'] - ex / d['ms_per_step'] / r['peak']) < 1e-9
+    assert r['frac'] < r['algorithmic_frac']  # never the reference graph's FLOPs over the gated time
+    dense = _load(os.path.join(P, 'r03_bench_n1.json'))
+    assert d['value'] > 1.25 * dense['value'] and ex < 0.7 * dense['roofline']['executed_gflop_per_launch']
