@@ -435,7 +435,8 @@ class CPN(nn.Module):
                                                         stem_fast=True)
             return self._alt_plans[key]
         if precision not in self._alt_plans:
-            extra = dict(fuse_bilinear=False) if precision == 'fp8' else dict(fuse_readout=False, fuse_bilinear=False)
+            # fp8: the resize stays its own op and the ResNet stem takes its bf16 fast path (e4m3 output); fp32: nothing fused
+            extra = dict(fuse_bilinear=False, stem_fast=True) if precision == 'fp8' else dict(fuse_readout=False, fuse_bilinear=False)
             self._alt_plans[precision] = graph.build_plan(**self._plan_kwargs, **extra)
         return self._alt_plans[precision]
 
@@ -474,6 +475,8 @@ class CPN(nn.Module):
         for op in plan.ops:  # max-pool / bilinear kernels work on the codes: output scale == input scale
             if op['op'] in ('maxpool', 'bilinear'):
                 self._fp8_scales[op['dst']] = self._fp8_scales[op['src0']]
+            elif op['op'] in ('input', 'input_stem'):  # inputs lie in [0, 1] (asserted per forward): a fixed scale, whichever
+                self._fp8_scales[op['dst']] = 1. / 448.  # of the stem alternatives ran during calibration
         if self._engine is not None and self._engine.precision == 'fp8':
             self._engine = None
         return self._fp8_scales

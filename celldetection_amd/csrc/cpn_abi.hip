@@ -92,8 +92,12 @@ static void propagate_dims(const cpn_plan *p, int H, int W, ShapePlan &sp) {
             int tin = -1;
             for (const cpn_op_desc &q : p->ops)
                 if (q.op == CPN_OP_INPUT) { tin = q.dst; break; }
-            const bool fast = p->precision == CPN_PRECISION_BF16 && tin >= 0 &&
-                              (int64_t) (H + STEM_PAD_ROWS) * (W + STEM_PAD_COLS) * 4 <= (int64_t) H * W * p->tensors[tin].channels;
+            // (the padded layout is bf16 [H + 6][W + 8][4] = 8 bytes per pixel in bf16 AND fp8 plans; the input tensor
+            // offers channels * 2 | 1 bytes per pixel)
+            const int elem = p->precision == CPN_PRECISION_FP8 ? 1 : 2;
+            const bool fast = p->precision != CPN_PRECISION_F32 && tin >= 0 &&
+                              (int64_t) (H + STEM_PAD_ROWS) * (W + STEM_PAD_COLS) * 8 <=
+                                  (int64_t) H * W * p->tensors[tin].channels * elem;
             sp.skip[oi] = (o.alt == 2) != fast;
         }
         switch (o.op) {
@@ -339,13 +343,13 @@ int cpn_plan_create(cpn_plan **plan, const cpn_tensor_desc *tensors, int32_t n_t
             return fail(CPN_E_INVALID, "cpn_plan_create: sub-pixel PHASE / LATERAL ops must follow their HEAD op");
         }
         if ((o.op == CPN_OP_INPUT_STEM || o.op == CPN_OP_STEM7) &&
-            (precision != CPN_PRECISION_BF16 || o.alt != 2 || o.dst < 0 ||
+            (precision == CPN_PRECISION_F32 || o.alt != 2 || o.dst < 0 ||
              (o.op == CPN_OP_INPUT_STEM && (o.in_channels < 1 || o.in_channels > 4)) ||
              (o.op == CPN_OP_STEM7 && ((o.cout_b != 32 && o.cout_b != 64) || o.src0 < 0 || o.weight_offset < 0 ||
                                        (size_t) o.weight_offset + (size_t) 7 * o.cout_b * 64 > weight_bytes ||
                                        (o.bias_offset >= 0 && (size_t) o.bias_offset + o.cout_b > bias_count))))) {
             delete p;
-            return fail(CPN_E_INVALID, "cpn_plan_create: malformed stem fast-path op (bf16 plans, alt = 2, <= 4 input "
+            return fail(CPN_E_INVALID, "cpn_plan_create: malformed stem fast-path op (bf16 / fp8 plans, alt = 2, <= 4 input "
                                        "channels, 32 | 64 output channels)");
         }
         if (o.alt < 0 || o.alt > 2) {
@@ -468,7 +472,8 @@ static int run_or_count(cpn_plan *plan, const void *input, int32_t in_dtype, int
             case CPN_OP_STEM7: {
                 StemArgs a{tptr(o.src0), tptr(o.dst), plan->weights + o.weight_offset,
                            o.bias_offset >= 0 ? plan->bias + o.bias_offset : nullptr, N, sp.th[o.src0], sp.tw[o.src0],
-                           sp.th[o.dst], sp.tw[o.dst], o.cout_b, tch(o.dst)};
+                           sp.th[o.dst], sp.tw[o.dst], o.cout_b, tch(o.dst),
+                           fp8 ? 1.f / plan->tensors[o.dst].scale : 0.f};  // fp8 plans: e4m3 output codes
                 const double fl = 2.0 * N * a.Hout * a.Wout * (double) o.cout_b * 7 * 32;
                 if (op_flops) op_flops[i] = fl;
                 if (flops) { *flops += fl; break; }
@@ -523,7 +528,9 @@ static int run_or_count(cpn_plan *plan, const void *input, int32_t in_dtype, int
             default: return fail(CPN_E_INVALID, "cpn_plan_run: unknown op");
         }
         if (rc) return rc;
-        if (absmax && o.dst >= 0) {  // calibration: max |x| of the tensor this op produced
+        if (absmax && o.dst >= 0 && o.op != CPN_OP_INPUT_STEM) {  // calibration: max |x| of the tensor this op produced
+            // (the padded stem layout does not fill the input tensor's storage: its scale is set by the caller -- inputs
+            // lie in [0, 1])
             const cpn_tensor_desc &t = plan->tensors[o.dst];
             const long count = (long) N * sp.th[o.dst] * sp.tw[o.dst] * t.channels;
             rc = check_hip((hipError_t) launch_absmax_bf16(tptr(o.dst), count, absmax + o.dst, st), "absmax kernel");
@@ -622,13 +629,13 @@ int cpn_convert_input_stem(const void *src, int32_t in_dtype, void *dst, int32_t
 }
 
 int cpn_stem7(const cpn_op_desc *op, const void *src, void *dst, int32_t dst_stride, int32_t N, int32_t H, int32_t W,
-              const void *weights, const float *bias, void *stream) {
+              const void *weights, const float *bias, float out_inv_scale, void *stream) {
     if (!op || !src || !dst || !weights || N <= 0 || H <= 0 || W <= 0) return fail(CPN_E_INVALID, "cpn_stem7: bad arguments");
     if (op->op != CPN_OP_STEM7 || (op->cout_b != 32 && op->cout_b != 64) || dst_stride < op->cout_b || dst_stride % 8)
         return fail(CPN_E_INVALID, "cpn_stem7: needs a CPN_OP_STEM7 descriptor with 32 | 64 output channels");
     StemArgs a{src, dst, (const unsigned char *) weights + op->weight_offset,
                (bias && op->bias_offset >= 0) ? bias + op->bias_offset : nullptr, N, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1,
-               op->cout_b, dst_stride};
+               op->cout_b, dst_stride, out_inv_scale > 0.f ? out_inv_scale : 0.f};
     return check_hip((hipError_t) launch_stem7(a, (hipStream_t) stream), "cpn_stem7");
 }
 

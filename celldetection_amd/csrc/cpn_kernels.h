@@ -102,6 +102,7 @@ struct StemArgs {
     const void *weights;   // [7][coutp][32] bf16: filter row ky, output channel, (kx 0..7, c 0..3) -- kx = 7 and c >= C zero
     const float *bias;     // [coutp] or nullptr
     int N, H, W, Hout, Wout, coutp, dst_stride;
+    float out_inv_scale;   // > 0: dst holds e4m3 codes of value * out_inv_scale (fp8 plans; dst_stride in bytes = channels)
 };
 int launch_input_stem(const InputArgs &a, hipStream_t stream);
 int launch_stem7(const StemArgs &a, hipStream_t stream);

@@ -65,7 +65,9 @@ __global__ __launch_bounds__(256) void input_stem_kernel(const InputArgs a) {
 
 // ---- the conv --------------------------------------------------------------------------------------------------------
 // NF = 32-channel output fragments (1 | 2).  One wave = one 32-pixel row fragment at a time.
-template <int NF>
+// F8: the output tensor of an fp8 plan -- OCP e4m3 codes of value * out_inv_scale (the stem itself computes in bf16 on the
+// bf16 input in both cases: more exact than the e4m3 graph's generic stem, and it skips the 64-channel padded input tensor).
+template <int NF, bool F8>
 __global__ __launch_bounds__(256, 2) void stem7_kernel(const StemArgs a) {
     const int lane = threadIdx.x & 63;
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -116,7 +118,8 @@ __global__ __launch_bounds__(256, 2) void stem7_kernel(const StemArgs a) {
             for (int j = 0; j < NF; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][ks], bx[ks], acc[j], 0, 0, 0);
         // epilogue: lane (l31, lhi) holds channels j*32 + 8q + 4 lhi + e of pixel l31.  Swapping the q-odd half of the lower
         // lanes with the q-even half of the upper lanes gives every lane 8 consecutive channels: 16-byte stores
-        unsigned char *drow = (unsigned char *) a.dst + (((size_t) n * a.Hout + oy) * a.Wout + ox) * (size_t) a.dst_stride * 2;
+        unsigned char *drow = (unsigned char *) a.dst +
+                              (((size_t) n * a.Hout + oy) * a.Wout + ox) * (size_t) a.dst_stride * (F8 ? 1 : 2);
 #pragma unroll
         for (int j = 0; j < NF; ++j)
 #pragma unroll
@@ -128,6 +131,22 @@ __global__ __launch_bounds__(256, 2) void stem7_kernel(const StemArgs a) {
                     v0[e] = fmaxf(acc[j][q0 * 4 + e] + bias[j][q0][e], 0.f);
                     v1[e] = fmaxf(acc[j][q1 * 4 + e] + bias[j][q1][e], 0.f);
                 }
+                const int ch = j * 32 + 8 * (lhi ? q1 : q0);
+                if constexpr (F8) {  // four e4m3 codes per dword: one swap gives every lane 8 consecutive channels = 8 bytes
+                    int c0 = 0, c1 = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v0[e] = __builtin_amdgcn_fmed3f(v0[e] * a.out_inv_scale, -448.f, 448.f);
+                        v1[e] = __builtin_amdgcn_fmed3f(v1[e] * a.out_inv_scale, -448.f, 448.f);
+                    }
+                    c0 = __builtin_amdgcn_cvt_pk_fp8_f32(v0[0], v0[1], c0, false);
+                    c0 = __builtin_amdgcn_cvt_pk_fp8_f32(v0[2], v0[3], c0, true);
+                    c1 = __builtin_amdgcn_cvt_pk_fp8_f32(v1[0], v1[1], c1, false);
+                    c1 = __builtin_amdgcn_cvt_pk_fp8_f32(v1[2], v1[3], c1, true);
+                    const u32x2 sw = __builtin_amdgcn_permlane32_swap((unsigned) c0, (unsigned) c1, false, false);
+                    if (ox < a.Wout) *(u32x2 *) (drow + (size_t) ch) = sw;
+                    continue;
+                }
                 unsigned a0 = pack_bf16x2(v0[0], v0[1]), a1 = pack_bf16x2(v0[2], v0[3]);  // channels 8 q0 + 4 lhi ..+3
                 unsigned b0 = pack_bf16x2(v1[0], v1[1]), b1 = pack_bf16x2(v1[2], v1[3]);  // channels 8 q1 + 4 lhi ..+3
                 // v_permlane32_swap(x, y): x of lanes 32..63 <-> y of lanes 0..31
@@ -137,7 +156,6 @@ __global__ __launch_bounds__(256, 2) void stem7_kernel(const StemArgs a) {
                 // upper lanes: (a = lower lanes' q1 channels 0..3, b = own q1 channels 4..7)  -> channels 8 q1 .. +7
                 u32x4 o;
                 o.x = s0.x; o.y = s1.x; o.z = s0.y; o.w = s1.y;
-                const int ch = j * 32 + 8 * (lhi ? q1 : q0);
                 if (ox < a.Wout) *(u32x4 *) (drow + (size_t) ch * 2) = o;
             }
     }
@@ -160,8 +178,14 @@ int launch_stem7(const StemArgs &a, hipStream_t stream) {
     long blocks = (nfrag + 3) / 4;        // 4 waves per block, one fragment per wave and pass
     if (blocks > 256 * 2) blocks = 256 * 2;  // persistent: two blocks per CU (the A-fragments are loaded once per wave)
     if (blocks < 1) blocks = 1;
-    if (a.coutp == 64) hipLaunchKernelGGL(stem::stem7_kernel<2>, dim3((unsigned) blocks), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(stem::stem7_kernel<1>, dim3((unsigned) blocks), dim3(256), 0, stream, a);
+    const bool f8 = a.out_inv_scale > 0.f;  // e4m3 output (fp8 plans)
+    if (a.coutp == 64) {
+        if (f8) hipLaunchKernelGGL((stem::stem7_kernel<2, true>), dim3((unsigned) blocks), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((stem::stem7_kernel<2, false>), dim3((unsigned) blocks), dim3(256), 0, stream, a);
+    } else {
+        if (f8) hipLaunchKernelGGL((stem::stem7_kernel<1, true>), dim3((unsigned) blocks), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((stem::stem7_kernel<1, false>), dim3((unsigned) blocks), dim3(256), 0, stream, a);
+    }
     return (int) hipGetLastError();
 }
 

@@ -562,30 +562,36 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=Non
         d.bias_offset = d.mult_offset = -1
         op_scales.append((0., 0.))
         d.alt = int(op.get('alt', 0))
-        if d.alt and (f32 or fp8):
-            raise ValueError('the stem fast path is a bf16-plan feature')
+        if d.alt and f32:
+            raise ValueError('the stem fast path is a bf16 / fp8-plan feature')
         if op['op'] in ('input', 'input_stem'):
             d.op, d.dst, d.in_channels = (_lib.OP_INPUT if op['op'] == 'input' else _lib.OP_INPUT_STEM), op['dst'], op['in_channels']
             continue
         if op['op'] == 'stem7':
             # weights [7][cout_b][32] bf16: filter row ky, output channel, (kx 0..7, c 0..3) -- the 7 taps of a filter row
             # over a 4-channel NHWC input are 28 contiguous values; kx = 7 and c >= in_channels meet zeros
+            # (fp8 plans: the stem computes in bf16 on the bf16 input, too -- only its OUTPUT is e4m3 codes of the dst
+            # tensor's scale; no weight quantisation, the multiplier slots that keep bias / mult indices aligned are ones)
             w, b = _fold(state_dict, op)
             cout, cin = op['cout'], op['cin']
-            coutp = _pad32(cout)
+            coutp = _pad(cout)
             wk = torch.zeros(7, coutp, 8, 4, dtype=torch.float64)
             wk[:, :cout, :7, :cin] = w.permute(2, 0, 3, 1)  # [cout, cin, ky, kx] -> [ky, cout, kx, cin]
             bias = torch.zeros(coutp, dtype=torch.float64)
             bias[:cout] = b
-            wparts.append(wk.reshape(-1).to(torch.bfloat16))
+            wq = wk.reshape(-1).to(torch.bfloat16)
+            wparts.append(wq.view(torch.uint8) if fp8 else wq)
             bparts.append(bias.to(torch.float32))
+            if fp8:
+                mparts.append(torch.ones(coutp, dtype=torch.float32))
+                op_scales[-1] = (0., 1. / float(act_scales[op['dst']]))
             d.op, d.src0, d.dst = _lib.OP_STEM7, op['src0'], op['dst']
             d.kh = d.kw = 7
             d.stride, d.pad, d.bundles, d.cin_b, d.cout_b = 2, 3, 1, 32, coutp
             d.weight_offset, d.bias_offset = woff, boff
             d.act, d.cout_real, d.out_index = _lib.ACT_RELU, cout, -1
             d.fuse_weight_offset = d.fuse_bias_offset = -1
-            woff += wparts[-1].numel() * 2
+            woff += wq.numel() * 2
             boff += bparts[-1].numel()
             continue
         if op['op'] == 'maxpool':

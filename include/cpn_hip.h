@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CPN_ABI_VERSION 8
+#define CPN_ABI_VERSION 9
 
 #define CPN_E_INVALID (-1)
 #define CPN_E_UNSUPPORTED (-2)
@@ -50,7 +50,7 @@ typedef struct {
 /* CPN_OP_CONV_DEFERRED (score-gated heads, cpn_sparse_heads below): a fused ReadOut head conv that cpn_plan_run does NOT
  * execute -- its weights are packed and its output size is reported like a CPN_OP_CONV's, and its source tensor stays
  * intact in the workspace until the end of the run (cpn_plan_tensor_info locates it). */
-/* CPN_OP_INPUT_STEM / CPN_OP_STEM7 (bf16 plans; csrc/stem.hip): the ResNet stem `body.0` = Conv2d(in_channels <= 4 -> 32 | 64
+/* CPN_OP_INPUT_STEM / CPN_OP_STEM7 (bf16 and fp8 plans; csrc/stem.hip): the ResNet stem `body.0` = Conv2d(in_channels <= 4 -> 32 | 64
  * output channels after padding, 7x7, stride 2, pad 3) + BN + ReLU (celldetection/models/resnet.py:274-284) on a dedicated
  * layout: CPN_OP_INPUT_STEM converts the input to bf16 [N][H + 6][W + 8][4] with a zero border inside the storage of its
  * dst tensor (which needs (H + 6) * (W + 8) * 4 <= H * W * channels elements), CPN_OP_STEM7 reads it with weights
@@ -191,11 +191,12 @@ int cpn_conv2d_fp8(const cpn_op_desc *op, const void *src0, int32_t c0_stride, c
                    float out_inv_scale, void *stream);
 /* ResNet stem fast path (see CPN_OP_INPUT_STEM / CPN_OP_STEM7): input conversion into the padded 4-channel layout
  * (dst: (H + 6) * (W + 8) * 4 bf16 per image) and the 7x7 stride-2 conv + bias + ReLU from it (`op`: a CPN_OP_STEM7
- * descriptor; dst NHWC bf16 [N][(H - 1) / 2 + 1][(W - 1) / 2 + 1][dst_stride]). */
+ * descriptor; dst NHWC bf16 [N][(H - 1) / 2 + 1][(W - 1) / 2 + 1][dst_stride], or -- out_inv_scale > 0, the output tensor
+ * of an fp8 plan -- OCP e4m3 codes of value * out_inv_scale; the stem computes in bf16 on the bf16 input either way). */
 int cpn_convert_input_stem(const void *src, int32_t in_dtype, void *dst, int32_t N, int32_t C, int32_t H, int32_t W,
                            int32_t *range_flag, void *stream);
 int cpn_stem7(const cpn_op_desc *op, const void *src, void *dst, int32_t dst_stride, int32_t N, int32_t H, int32_t W,
-              const void *weights, const float *bias, void *stream);
+              const void *weights, const float *bias, float out_inv_scale, void *stream);
 int cpn_maxpool2d(const void *src, void *dst, int32_t N, int32_t Hin, int32_t Win, int32_t C, int32_t k, int32_t stride,
                   int32_t pad, void *stream);
 int cpn_resize_bilinear(const void *src, void *dst, int32_t N, int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout,

@@ -37,6 +37,8 @@ def calibrate(plan, state_dict, x):
     for op in plan.ops:
         if op['op'] in ('maxpool', 'bilinear'):
             scales[op['dst']] = scales[op['src0']]
+        elif op['op'] in ('input', 'input_stem'):  # like CPN.calibrate_fp8: inputs lie in [0, 1]
+            scales[op['dst']] = 1. / 448.
     return scales
 
 
@@ -59,10 +61,33 @@ def simulate(plan, state_dict, effective_weights, act_scales, x, _absmax=None):
             _q = real_q
 
 
+def _stem_fast(x):
+    """The executor's rule for the stem alternatives (csrc/cpn_abi.hip): the padded 4-channel bf16 layout (8 bytes per pixel,
+    [H + 6][W + 8]) must fit the input tensor's storage (64 bytes per pixel in an fp8 plan)."""
+    h, w = x.shape[-2:]
+    return (h + 6) * (w + 8) * 8 <= h * w * 64
+
+
 def _simulate(plan, state_dict, effective_weights, act_scales, x, T, outs, ei, _absmax):
+    from celldetection_amd import graph
     up = lambda t: F.interpolate(t, scale_factor=2, mode='nearest')
+    fast = _stem_fast(x)
     for op in plan.ops:
         kind = op['op']
+        if op.get('alt') and (op['alt'] == 2) != fast:  # the stem alternative that does not run at this input size
+            if kind == 'conv':
+                ei += 1  # (its dequantised weights are still in the list)
+            continue
+        if kind == 'input_stem':  # bf16 copy of the input in the padded layout: no e4m3 quantisation
+            T[op['dst']] = x.float().to(torch.bfloat16).float()
+            continue
+        if kind == 'stem7':  # conv 7x7 s2 + BN + ReLU in bf16 (csrc/stem.hip); only the OUTPUT is e4m3
+            wf, bf = graph._fold(state_dict, op)
+            y = F.relu(F.conv2d(T[op['src0']].double(), wf.float().to(torch.bfloat16).double(), bf, 2, 3).float())
+            T[op['dst']] = _q(y, act_scales[op['dst']])
+            if _absmax is not None:
+                _absmax[op['dst']] = float(T[op['dst']].abs().max())
+            continue
         if kind == 'input':
             T[op['dst']] = _q(x, act_scales[op['dst']])
         elif kind == 'maxpool':

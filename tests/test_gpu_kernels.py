@@ -384,7 +384,7 @@ def test_stem_fast_path(dev, n, h, w, cin, cout, dtype):
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     cp = _pad32(cout)
     out = torch.full((n, ho, wo, cp), float('nan'), dtype=torch.bfloat16, device=dev)
-    _lib.check(lib.cpn_stem7(ops[3], _lib.ptr(pad), _lib.ptr(out), cp, n, h, w, _lib.ptr(wblob), _lib.ptr(bblob),
+    _lib.check(lib.cpn_stem7(ops[3], _lib.ptr(pad), _lib.ptr(out), cp, n, h, w, _lib.ptr(wblob), _lib.ptr(bblob), 0.,
                              _lib.stream_ptr()), 'stem7')
     # the generic kernel on the 32-channel input, same weights: both approximate the same fp32 conv
     gen_in = to_nhwc_bf16(xq.to(dev))
@@ -401,6 +401,20 @@ def test_stem_fast_path(dev, n, h, w, cin, cout, dtype):
     bad = (err > 1e-2 * scale + 8e-3 * ref.abs()).sum().item()
     assert bad == 0, f'{bad} / {err.numel()} elements off; max abs err {err.max().item():.3e}'
     assert (from_nhwc(gen.cpu(), cout) - got).abs().max().item() < 2e-2 * scale
+    # fp8 plans: the same bf16 stem with e4m3 output codes of value / scale (channel stride 64)
+    scale = float(ref.abs().max()) / 448. + 1e-12
+    cp8 = (cout + 63) // 64 * 64
+    tens8, ops8, wblob8, bblob8, _, _ = graph.pack(P, sd, dev, precision='fp8', act_scales=[1. / 448., scale])
+    codes = torch.full((n, ho, wo, cp8), 0x7f, dtype=torch.uint8, device=dev)
+    _lib.check(lib.cpn_stem7(ops8[3], _lib.ptr(pad), _lib.ptr(codes), cp8, n, h, w, _lib.ptr(wblob8), _lib.ptr(bblob8),
+                             1. / scale, _lib.stream_ptr()), 'stem7 fp8')
+    torch.cuda.synchronize()
+    got8 = codes.cpu().view(torch.float8_e4m3fn).float() * scale
+    assert torch.isfinite(got8).all() and (cout == cp8 or got8[..., cout:].abs().max().item() == 0)
+    got8 = got8[..., :cout].permute(0, 3, 1, 2)
+    err8 = (got8 - ref).abs()
+    assert (err8 > ref.abs() * 0.0725 + scale * 2 ** -9 * 1.01 + 1e-2 * max(ref.abs().max().item(), 1.)).sum().item() == 0, \
+        f'fp8 stem output: max err {err8.max().item():.3e}'  # half an e4m3 code step + the bf16 tolerance of the conv
     bad_in = xin.clone()
     bad_in[0, 0, 1, 1] = 1.5
     if dtype == 0:  # the range flag of the reference's Normalize assert (models/commons.py:694-697)

@@ -339,7 +339,20 @@ def test_stem_fast_path_plan_and_packing():
     assert [(o['op'], o.get('alt')) for o in m._plan.ops[:4]] == [('input', 1), ('input_stem', 2), ('conv', 1), ('stem7', 2)]
     generic = graph.build_plan(**m._plan_kwargs, subpixel=True)
     assert generic.entries == m._plan.entries
-    assert all(not o.get('alt') for p_ in ('fp8', 'fp32') for o in m.plan_for(p_).ops)
+    assert all(not o.get('alt') for o in m.plan_for('fp32').ops)
+    assert [(o['op'], o.get('alt')) for o in m.plan_for('fp8').ops[:4]] == [('input', 1), ('input_stem', 2), ('conv', 1), ('stem7', 2)]
+    # fp8 plans: the stem stays bf16 (weights + input), only its output is e4m3 -> bf16 weight bytes inside the byte blob,
+    # multiplier slots of ones, output scale from the dst tensor
+    sd8 = synth_state_dict(m.state_dict(), seed=0)
+    p8 = m.plan_for('fp8')
+    t8, o8, w8, b8, m8, sc8 = graph.pack(p8, sd8, 'cpu', precision='fp8', act_scales=[.01] * len(p8.tensors))
+    st8 = o8[3]
+    assert (st8.op, st8.alt, st8.cout_b, w8.dtype) == (_lib.OP_STEM7, 2, 64, torch.uint8)
+    wk8 = w8[st8.weight_offset: st8.weight_offset + 7 * 64 * 32 * 2].view(torch.bfloat16).float().reshape(7, 64, 8, 4)
+    wf8, _ = graph._fold(sd8, p8.ops[2])
+    want8 = torch.zeros(7, 64, 8, 4)
+    want8[:, :8, :7, :3] = wf8.permute(2, 0, 3, 1).float().to(torch.bfloat16).float()
+    assert torch.equal(wk8, want8) and abs(sc8[3][1] - 100.) < 1e-3
     assert not any(o.get('alt') for o in cda.models.CpnU22(3).plan_for('bf16').ops)  # (3x3 stride-1 first conv: no stem)
     sd = synth_state_dict(m.state_dict(), seed=0)
     tens, ops, wblob, bblob = graph.pack(m._plan, sd, 'cpu')
