@@ -10,11 +10,11 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CPN_HIP_LIB') or os.path.join(HERE, 'libcpn_hip.so')  # env: kernel A/B tuning only
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 PRECISION_BF16, PRECISION_F32, PRECISION_FP8 = 0, 1, 2
 E_INVALID, E_UNSUPPORTED, E_WORKSPACE = -1, -2, -3
 
-OP_INPUT, OP_CONV, OP_MAXPOOL, OP_BILINEAR, OP_CONV_DEFERRED, OP_INPUT_STEM, OP_STEM7 = 0, 1, 2, 3, 4, 5, 6
+OP_INPUT, OP_CONV, OP_MAXPOOL, OP_BILINEAR, OP_CONV_DEFERRED, OP_INPUT_STEM, OP_STEM7, OP_CONV_PAIR = 0, 1, 2, 3, 4, 5, 6, 7
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH_SCALED = 0, 1, 2, 3
 SUBPIXEL_NONE, SUBPIXEL_HEAD, SUBPIXEL_PHASE, SUBPIXEL_LATERAL, SUBPIXEL_SCATTER = 0, 1, 2, 3, 4
 OUT_SCORES, OUT_LOCATIONS, OUT_FOURIER, OUT_REFINEMENT, OUT_UNCERTAINTY = 0, 1, 2, 3, 4
@@ -64,6 +64,8 @@ _SIGNATURES = [
                                               c_void_p]),
     ('cpn_stem7', ctypes.c_int, [POINTER(OpDesc), c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                  c_float, c_void_p]),
+    ('cpn_conv_pair', ctypes.c_int, [POINTER(OpDesc), c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                     c_void_p, c_void_p, c_void_p]),
     ('cpn_maxpool2d', ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                      c_int32, c_void_p]),
     ('cpn_resize_bilinear', ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,

@@ -18,6 +18,7 @@ SOURCES = {
     # file: extra flags
     'conv_igemm.hip': [],
     'conv_fp8.hip': [],  # the same source with CPN_FP8 = 1 (e4m3 operands)
+    'conv_pair.hip': [],
     'misc_kernels.hip': [],
     'misc_fp8.hip': [],
     'conv_f32.hip': [],
@@ -29,7 +30,7 @@ SOURCES = {
     'stem.hip': [],
     'cpn_abi.hip': [],
 }
-HEADERS = ['cpn_kernels.h', 'cpn_error.h', 'conv_igemm.hip', os.path.join('..', '..', 'include', 'cpn_hip.h')]
+HEADERS = ['cpn_kernels.h', 'cpn_error.h', 'lds_dma.h', 'conv_igemm.hip', os.path.join('..', '..', 'include', 'cpn_hip.h')]
 
 
 def _hipcc():

@@ -380,8 +380,9 @@ class CPN(nn.Module):
         # sub-pixel decomposition of the UNet decoder convs over x2-upsampled maps (bf16 plans; graph._two_conv_norm_relu):
         # 4/9 of the MACs on the upsampled channels, taken wherever the upsampling is an exact x2.  A run-time switch.
         self.subpixel = True
-        # bf16: fused ReadOut tails + fused bilinear head source + sub-pixel decoder convs
-        self._plan = graph.build_plan(**self._plan_kwargs, subpixel=True, stem_fast=True)
+        # bf16: fused ReadOut tails + fused bilinear head source + sub-pixel decoder convs + stem kernel + fused bottleneck
+        # heads (conv1 -> grouped conv2 of the ResNeXt blocks, csrc/conv_pair.hip; the executor picks per input size)
+        self._plan = graph.build_plan(**self._plan_kwargs, subpixel=True, stem_fast=True, fuse_blocks=True)
         self._alt_plans = {}
         for key, shape, kind in self._plan.entries:
             _register(self, key, shape, kind)
@@ -432,7 +433,7 @@ class CPN(nn.Module):
                 return self._plan
             if key not in self._alt_plans:
                 self._alt_plans[key] = graph.build_plan(**self._plan_kwargs, sparse_heads=key[0], subpixel=key[1],
-                                                        stem_fast=True)
+                                                        stem_fast=True, fuse_blocks=True)
             return self._alt_plans[key]
         if precision not in self._alt_plans:
             # fp8: the resize stays its own op and the ResNet stem takes its bf16 fast path (e4m3 output); fp32: nothing fused

@@ -20,8 +20,9 @@
 //     32-MFMA-per-wave step to land;
 //   * LDS records are un-padded 64 B (32 bf16); the 16-byte part index is XOR-swizzled with (record>>2)&3 --
 //     applied on the DMA *source* address and on the ds_read address (LDS-DMA destinations are lane-linear) --
-//     which makes the ds_read_b128 fragment reads bank-conflict free for stride-1 convs at any tap offset
-//     (SQ_LDS_BANK_CONFLICT = 0 measured);
+//     which removes the bank conflicts among the lanes of a ds_read_b128 fragment read for stride-1 convs at any tap
+//     offset (round-3 PMC of the flagship 8x256 tile: SQ_LDS_BANK_CONFLICT 2.5 M cycles per dispatch, ~2 % of its
+//     LDS-array cycles -- what is left comes from the epilogue staging tile and the stride-2 / narrow variants);
 //   * the kernel is issue-bound long before it is LDS- or HBM-bound (a 32x32x16 MFMA hides only ~5-7 other
 //     instructions per wave), so the halo tile has a compile-time row pitch (multiple of 16 pixels): every
 //     fragment address of an item is ONE VGPR (computed with ~6 VALU per 16 MFMAs) + immediate offsets, the
@@ -33,6 +34,7 @@
 #include <cstdlib>
 
 #include "cpn_kernels.h"
+#include "lds_dma.h"
 
 // This source is compiled twice: as is (bf16 operands, v_mfma_f32_32x32x16_bf16) and through csrc/conv_fp8.hip with
 // CPN_FP8 = 1 (OCP e4m3 operands, v_mfma_scale_f32_32x32x64_f8f6f4: a 64-byte LDS record holds 64 channels instead
@@ -59,12 +61,6 @@ constexpr int ES = (int) sizeof(elem_t);  // bytes per channel
 constexpr int CH = 64 / ES;               // channels per 64-byte LDS record (= K extent of one pipeline item)
 constexpr int EPP = 16 / ES;              // channels per 16-byte part
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-typedef __attribute__((ext_vector_type(4))) int i32x4;
-typedef __attribute__((ext_vector_type(8))) int i32x8;
 #if CPN_FP8
 typedef i32x4 frag_t;   // 16 e4m3 (one 16-byte part)
 #else
@@ -74,16 +70,6 @@ typedef bf16x8 frag_t;  // 8 bf16
 constexpr int REC = 64;  // LDS bytes per 32-channel record (pixel or weight row)
 constexpr int TW = 32;   // output tile width in pixels (= one MFMA column fragment)
 
-
-// two fp32 -> packed bf16 pair (lo, hi), round to nearest even: one v_cvt_pk_bf16_f32 on gfx950 (the software
-// sequence cost ~7 VALU per element and made the epilogue of the memory-bound layers VALU-bound)
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
-    const f32x2_t v = {lo, hi};
-    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
-}
-__device__ __forceinline__ float bf16_bits_to_f32(unsigned int b) { return __uint_as_float(b << 16); }
 
 // 8 consecutive channels of one pixel <-> memory (16 B of bf16 | 8 B of e4m3 scaled by 1/out_scale)
 #if CPN_FP8
@@ -124,21 +110,6 @@ __device__ __forceinline__ void add_res8(float (&v)[8], const store8_t r, float)
     }
 }
 #endif
-
-// LDS-DMA through a raw buffer descriptor (buffer_load_dwordx4 ... offen lds): 64 lanes x 16 B -> LDS
-// [lds_wave_base + lane*16] (wave-uniform base).  Address = descriptor base + per-lane 32-bit byte offset + scalar byte
-// offset: no 64-bit address arithmetic per instruction, and a lane whose offset lies beyond the descriptor's size
-// receives ZEROS (tools/probes/buffer_lds_probe.hip: voffset + soffset + 16 > num_records -> 0) -- that is the conv's
-// zero padding; OOB_LANE is the offset used for such lanes (tensors are limited to 2^31 bytes, see cpn_abi.hip)
-constexpr unsigned OOB_LANE = 0x80000000u;
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-__device__ __forceinline__ rsrc_t make_rsrc(const void *base, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc((void *) base, 0, (int) bytes, 0x00020000);
-}
-__device__ __forceinline__ void bdma16(rsrc_t rsrc, unsigned lane_off, unsigned scalar_off, unsigned char *lds_wave_base) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *) lds_wave_base, 16,
-                                             (int) lane_off, (int) scalar_off, 0, 0);
-}
 
 // pointwise stride 1 / KxK stride 1 / KxK stride 2 / KxK stride 1 whose source is read through a bilinear resize
 // MODE_S1R = MODE_S1 with the weight operand loaded from L2 straight into registers (dense KxK, >= 9 taps, 8x256 tile)
@@ -262,15 +233,7 @@ __device__ __forceinline__ void halo_bilinear_store(const HaloGeo &G, int q, int
 #endif
 }
 
-// ---- hand-counted LDS fragment reads ----------------------------------------------------------------------------
-// hipcc (ROCm 7.2) emits `s_waitcnt lgkmcnt(0)` in front of every MFMA group of this kernel (it stops counting DS
-// returns once LDS-DMA is in the function), which serialises "prefetch next fragments -> MFMA current fragments".
-// The fragment reads are therefore inline asm (invisible to the compiler's counters) and every MFMA group is
-// preceded by OUR counted wait, which names the fragment registers as "+v" so that no use can be scheduled above it.
-template <int IMM>
-__device__ __forceinline__ void ds_read16(frag_t &d, unsigned addr) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(IMM));
-}
+// ---- hand-counted LDS fragment reads (ds_read16: lds_dma.h) and their counted waits
 template <int N, int WN, int WM>
 __device__ __forceinline__ void wait_frags(frag_t (&w)[WN], frag_t (&p)[WM]) {
     static_assert((WN == 2 && (WM == 4 || WM == 2 || WM == 1)) || (WN == 1 && (WM == 2 || WM == 1)), "frag shape");

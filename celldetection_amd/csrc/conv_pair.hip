@@ -1,0 +1,416 @@
+// Fused head of a ResNeXt bottleneck block for gfx950 (MI355X / CDNA4):
+//     conv1 (1x1, Cin -> Cmid) + BN + ReLU  ->  conv2 (3x3, groups = 32, stride 1, pad 1) + BN + ReLU
+// in ONE kernel: conv1's output never travels to HBM.  Replaces, on the CPN inference path, the first two thirds of
+// torchvision's Bottleneck.forward as instantiated by celldetection/models/resnet.py:88-116,119-193 (ResNeXt 32x4d / 32x8d
+// stages), i.e. two cpn::conv_igemm launches + one [N, H, W, Cmid] tensor written and re-read per block.
+//
+// Why this shape (MI355X-first, not a translation of anything):
+//   * a grouped conv needs, for an output channel, only the Cmid / 32 input channels of its own group -- so a workgroup that
+//     owns a SLAB of SL conv1 output channels (= whole groups) can run conv2 for those groups without any other slab;
+//     what it needs from conv1 is the slab on its output tile + a one-pixel halo.  Tiles are FULL-WIDTH ROW STRIPS of the
+//     image (W = 16 | 32 | 64 exactly): the left / right halo is the conv's zero padding, only the two halo ROWS are
+//     recomputed (10 rows for 8: 1.25 x conv1's MACs);
+//   * stage 1 = conv1 as an implicit GEMM  D1[SL][halo px] += W1[SL][Cin] * X[Cin][halo px]  on v_mfma_f32_32x32x16_bf16:
+//     halo pixels flattened (a pixel fragment is ANY 32 consecutive pixels of the strip -- rows are contiguous in NHWC), wave
+//     tile 64 channels x 160 pixels (10 MFMAs per 7 fragment reads), operands staged by LDS-DMA through a 3-deep ring of
+//     32-channel chunks (two chunks of prefetch distance, one workgroup barrier per chunk);
+//   * the activated slab is rounded to bf16 into LDS as [32-channel chunk][halo pixel][32] records (same XOR-swizzled 64-byte
+//     records as the conv_igemm halo tiles; pixels outside the image are ZERO = conv2's padding) and OVERWRITES the staging
+//     ring: 81920 values x 2 B = the whole 160 KiB;
+//   * stage 2 = conv2 from that tile: a wave owns 64 output channels (two 32-channel bundles, or one 64-channel bundle) on a
+//     quarter of the output fragments, reads the pixel operand from LDS (tap offsets are address immediates; the columns the
+//     3x3 window reaches beyond the image edge are masked to zero in registers) and the block-diagonal packed weights of
+//     ITS bundles straight from L2 into registers -- no barrier, no weight staging, nothing shared between waves;
+//   * epilogue: bias + ReLU, bf16, per-wave LDS transpose, 16-byte NHWC stores of 128-byte channel runs.
+#include <atomic>
+
+#include "cpn_kernels.h"
+#include "lds_dma.h"
+
+namespace cpn {
+namespace {
+
+typedef bf16x8 frag_t;
+
+template <int WLOG, int SL>
+struct PairCfg {
+    static constexpr int W = 1 << WLOG;                      // image width = row pitch of the strip
+    static constexpr int WC = SL / 64;                       // stage 1: waves along the channels (64 each)
+    static constexpr int WP = 8 / WC;                        //          waves along the pixels (5 fragments each)
+    static constexpr int NF1 = 5 * WP;                       // pixel fragments of the halo strip
+    static constexpr int NPXP = NF1 * 32;                    // pixels staged (incl. padding up to whole fragments)
+    static constexpr int ROWS = W == 16 ? 18 : NPXP / W;     // halo rows
+    static constexpr int NPX = ROWS * W;                     // real halo pixels
+    static constexpr int THO = ROWS - 2;                     // output rows per strip
+    static constexpr int OUTF = THO * W / 32;                // output fragments per strip
+    static constexpr int PQ = OUTF / 4;                      // stage 2: waves along the pixels (4 fragments each)
+    static constexpr int XBUF = NPXP * 64;                   // one 32-channel chunk of the strip
+    static constexpr int WBUF = SL * 64;                     // one 32-channel chunk of the slab's weights
+    static constexpr int XI = NPXP / 16;                     // 1-KiB DMA instructions per activation chunk
+    static constexpr int XIW = (XI + 7) / 8;                 //   per wave (the last round may be partial)
+    static constexpr int WIW = SL / 16 / 8;                  // weight DMA instructions per wave and chunk
+    static constexpr int LDS = (SL / 32) * XBUF;             // the bf16 slab tile
+    static_assert(SL == 128 || SL == 256, "slab");
+    static_assert(NPX <= NPXP && OUTF % 4 == 0 && (SL / 64) * PQ == 8, "eight stage-2 jobs");
+    static_assert(3 * (XBUF + WBUF) <= LDS && LDS == 160 * 1024, "LDS budget");
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// stage-1 fragment set: 2 weight fragments (64 channels) + 5 pixel fragments (160 pixels) of one k-half
+struct Set1 {
+    frag_t w[2], p[5];
+};
+__device__ __forceinline__ void load_set1(Set1 &s, unsigned waddr, unsigned paddr) {
+    ds_read16<0>(s.w[0], waddr);
+    ds_read16<2048>(s.w[1], waddr);
+    ds_read16<0>(s.p[0], paddr);
+    ds_read16<2048>(s.p[1], paddr);
+    ds_read16<4096>(s.p[2], paddr);
+    ds_read16<6144>(s.p[3], paddr);
+    ds_read16<8192>(s.p[4], paddr);
+}
+template <int N>
+__device__ __forceinline__ void wait_set1(Set1 &s) {
+    asm volatile("s_waitcnt lgkmcnt(%7)"
+                 : "+v"(s.w[0]), "+v"(s.w[1]), "+v"(s.p[0]), "+v"(s.p[1]), "+v"(s.p[2]), "+v"(s.p[3]), "+v"(s.p[4])
+                 : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void wait_p4(frag_t (&p)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]) : "n"(N));
+}
+
+template <int WLOG, int SL, int CB>
+__global__ __launch_bounds__(512) void conv_pair_kernel(const PairArgs a) {
+    using C = PairCfg<WLOG, SL>;
+    constexpr int W = C::W;
+    constexpr int XB = C::XBUF, WB = C::WBUF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
+    typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int tiles_y = (a.H + C::THO - 1) / C::THO;
+    const int ty = blockIdx.x % tiles_y, n = blockIdx.x / tiles_y;
+    const int oy0 = ty * C::THO;      // first output row of the strip; halo row r is image row oy0 - 1 + r
+    const int n0 = blockIdx.y * SL;   // first conv1 output channel of the slab
+    const int nchunks = a.cin >> 5;
+    const unsigned lds0 = (unsigned) (size_t) (lds_u8 *) smem;
+
+    // ------------------------------------------------------------------------------------------------------------
+    // stage 1: conv1 on the halo strip
+    // ------------------------------------------------------------------------------------------------------------
+    // activation DMA: instruction q covers halo pixels q*16 .. +15 (lane -> pixel q*16 + lane/4, 16-byte slot lane%4 which
+    // holds channel part slot ^ ((pixel >> 2) & 3)); per-lane offsets are loop constants, the chunk travels in the scalar
+    // offset.  Pixels of rows outside the image (and the padding behind the last real pixel) read zeros.
+    const rsrc_t rsx = make_rsrc(a.src, (unsigned) ((size_t) a.N * a.H * W * a.c_stride * 2));
+    unsigned x_voff[C::XIW];
+#pragma unroll
+    for (int it = 0; it < C::XIW; ++it) {
+        const int q = wave + it * 8;
+        const int p = q * 16 + (lane >> 2);
+        const int part = (lane & 3) ^ ((p >> 2) & 3);
+        const int iy = oy0 - 1 + (p >> WLOG), ix = p & (W - 1);
+        const bool ok = p < C::NPX && iy >= 0 && iy < a.H;
+        x_voff[it] = ok ? (unsigned) ((((n * a.H + iy) * W + ix) * a.c_stride + part * 8) * 2) : OOB_LANE;
+    }
+    const bool x_extra = wave + (C::XIW - 1) * 8 < C::XI;  // (wave-uniform) this wave issues the last, partial round
+    // weight DMA: instruction q covers rows q*16 .. +15 of the slab's chunk slab [SL][32] (same swizzle)
+    const int nitems1 = nchunks + (nchunks & 1);  // (the packer pads an odd item count with an all-zero slab)
+    const rsrc_t rsw = make_rsrc(a.w1, (unsigned) ((size_t) nitems1 * a.cmid * 64));
+    const unsigned w_dma_lane = (unsigned) ((lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));
+    unsigned char *const xring = smem;
+    unsigned char *const wring = smem + 3 * XB;
+#define PAIR_DMA(CHUNK, BUF)                                                                                   \
+    {                                                                                                          \
+        const unsigned xs_ = (unsigned) (CHUNK) * 64u;                                                         \
+        _Pragma("unroll") for (int it = 0; it < C::XIW; ++it)                                                  \
+            if (it + 1 < C::XIW || x_extra) bdma16(rsx, x_voff[it], xs_, xring + (BUF) * XB + ((wave + it * 8) << 10)); \
+        const unsigned ws_ = (unsigned) (((CHUNK) * a.cmid + n0) * 64);                                        \
+        _Pragma("unroll") for (int it = 0; it < C::WIW; ++it)                                                  \
+            bdma16(rsw, (unsigned) ((wave + it * 8) << 10) + w_dma_lane, ws_, wring + (BUF) * WB + ((wave + it * 8) << 10)); \
+    }
+
+    const int wc = wave / C::WP, wp = wave % C::WP;  // this wave: channels wc*64 .. +63, pixel fragments wp*5 .. +4
+    const unsigned swz = (unsigned) ((lhi ^ ((l31 >> 2) & 3)) << 4);
+    const unsigned p_lane = lds0 + (unsigned) ((wp * 5 * 32 + l31) * 64) + swz;
+    const unsigned w_lane = lds0 + (unsigned) (3 * XB + (wc * 64 + l31) * 64) + swz;
+
+    f32x16 acc[2][5];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int f = 0; f < 5; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][f][r] = 0.f;
+
+#define MMA_SET1(S, PENDING)                                                                                   \
+    {                                                                                                          \
+        wait_set1<PENDING>(S);                                                                                 \
+        _Pragma("unroll") for (int f = 0; f < 5; ++f) {                                                        \
+            acc[0][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(S.w[0], S.p[f], acc[0][f], 0, 0, 0);           \
+            acc[1][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(S.w[1], S.p[f], acc[1][f], 0, 0, 0);           \
+        }                                                                                                      \
+    }
+
+    // prologue: three chunks in flight, the first one landed
+    PAIR_DMA(0, 0);
+    if (nchunks > 1) PAIR_DMA(1, 1);
+    if (nchunks > 2) PAIR_DMA(2, 2);
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    Set1 A, B;
+    load_set1(A, w_lane, p_lane);
+    int buf = 0;
+    // every chunk that is followed by another one: the loop body is branch-free with respect to the accumulators and the
+    // fragment sets (conditional MFMA groups make hipcc rename / spill accumulators); the last chunk is peeled
+    for (int c = 0; c + 1 < nchunks; ++c) {
+        load_set1(B, (w_lane + (unsigned) (buf * WB)) ^ 32u, (p_lane + (unsigned) (buf * XB)) ^ 32u);  // k-half 1 of chunk c
+        MMA_SET1(A, 7);                                                                                // k-half 0
+        // step boundary: my DMA of chunk c+1 landed (chunk c+2's may still fly), all my reads of chunk c returned ...
+        if (c + 2 < nchunks) {
+            if (x_extra) wait_vm<C::XIW + C::WIW>();
+            else wait_vm<C::XIW - 1 + C::WIW>();
+        } else {
+            wait_vm<0>();
+        }
+        wait_set1<0>(B);
+        __builtin_amdgcn_s_barrier();  // ... and so have everybody else's: ring slot `buf` is free
+        if (c + 3 < nchunks) PAIR_DMA(c + 3, buf);
+        buf = buf == 2 ? 0 : buf + 1;
+        load_set1(A, w_lane + (unsigned) (buf * WB), p_lane + (unsigned) (buf * XB));  // k-half 0 of chunk c+1
+        MMA_SET1(B, 7);
+    }
+    load_set1(B, (w_lane + (unsigned) (buf * WB)) ^ 32u, (p_lane + (unsigned) (buf * XB)) ^ 32u);
+    MMA_SET1(A, 7);
+    MMA_SET1(B, 0);
+#undef MMA_SET1
+#undef PAIR_DMA
+
+    // ---- the slab tile: relu(conv1 + bias) as bf16 records [chunk][halo pixel][32], zero outside the image
+    __syncthreads();  // every wave is done with the staging ring
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int chunk = wc * 2 + j;
+        float4 b4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            b4[q] = a.b1 ? *(const float4 *) (a.b1 + n0 + chunk * 32 + 8 * q + 4 * lhi) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int f = 0; f < 5; ++f) {
+            const int p = (wp * 5 + f) * 32 + l31;
+            const int iy = oy0 - 1 + (p >> WLOG);
+            const bool ok = p < C::NPX && iy >= 0 && iy < a.H;
+            lds_u8 *rec = (lds_u8 *) smem + chunk * XB + p * 64 + lhi * 8;
+            const int sw = (p >> 2) & 3;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v0 = acc[j][f][q * 4 + 0] + b4[q].x, v1 = acc[j][f][q * 4 + 1] + b4[q].y;
+                const float v2 = acc[j][f][q * 4 + 2] + b4[q].z, v3 = acc[j][f][q * 4 + 3] + b4[q].w;
+                u32x2 o;
+                o.x = ok ? pack_bf16x2(fmaxf(v0, 0.f), fmaxf(v1, 0.f)) : 0u;
+                o.y = ok ? pack_bf16x2(fmaxf(v2, 0.f), fmaxf(v3, 0.f)) : 0u;
+                *(lds_u32x2 *) (rec + ((q ^ sw) << 4)) = o;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------------------------------------------------
+    // stage 2: grouped 3x3 conv from the slab tile.  Job of this wave: 64 output channels n0 + jp*64 .. +63 (row blocks
+    // j = 0, 1 of 32) on output fragments pq*4 .. +3.  CB = 1: row block j is the 32-channel bundle 2 jp + j and reads slab
+    // chunk 2 jp + j; CB = 2: both row blocks belong to the 64-channel bundle jp and read chunks 2 jp, 2 jp + 1.
+    // ------------------------------------------------------------------------------------------------------------
+    const int jp = wave / C::PQ, pq = wave % C::PQ;
+    f32x16 acc2[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[j][f][r] = 0.f;
+
+    // pixel operand of output pixel o = (pq*4 + f)*32 + l31 at tap (ky, kx): slab pixel o + ky*W + kx - 1
+    unsigned a_kx[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int xo = l31 + kx - 1;  // (-1 for lane 0 at kx = 0: the address is garbage and the value masked)
+        a_kx[kx] = lds0 + (unsigned) (jp * 2 * XB + pq * 4 * 2048) + (unsigned) (xo * 64) + (unsigned) ((lhi ^ ((xo >> 2) & 3)) << 4);
+    }
+    // weights: packed [bundle][item = chunk-in-bundle * 9 + tap (+ 1 zero item if odd)][cout_b][32] bf16, rows are the MFMA
+    // fragment rows (not swizzled): lane -> row l31 of row block j, 16-byte part 2 * khalf + lhi
+    constexpr int COB = 32 * CB;                  // channels per bundle
+    constexpr int NI2 = 9 * CB + ((9 * CB) & 1);  // items per bundle incl. padding
+    const unsigned char *wrow[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int bundle = CB == 1 ? (n0 >> 5) + jp * 2 + j : (n0 >> 6) + jp;
+        const int row = CB == 1 ? l31 : j * 32 + l31;
+        wrow[j] = (const unsigned char *) a.w2 + ((size_t) bundle * NI2 * COB + row) * 64 + lhi * 16;
+    }
+    // group g = (s, tap, khalf), s = row block (CB = 1) | chunk of the bundle (CB = 2): 4 pixel fragments, 4 | 8 MFMAs
+    constexpr int NG = 36;
+    frag_t P[2][4];
+    frag_t Wr[3][2];
+#define PAIR_G_S(G) ((G) / 18)
+#define PAIR_G_TAP(G) (((G) % 18) >> 1)
+#define PAIR_G_KH(G) ((G) & 1)
+#define PAIR_LOADP(G)                                                                                          \
+    {                                                                                                          \
+        constexpr int s_ = PAIR_G_S(G), t_ = PAIR_G_TAP(G), kh_ = PAIR_G_KH(G);                                \
+        constexpr int ky_ = t_ / 3, kx_ = t_ % 3;                                                              \
+        const unsigned ad_ = (a_kx[kx_] + (unsigned) (s_ * XB)) ^ (unsigned) (kh_ * 32);                       \
+        ds_read16<0 * 2048 + ky_ * W * 64>(P[(G) & 1][0], ad_);                                                \
+        ds_read16<1 * 2048 + ky_ * W * 64>(P[(G) & 1][1], ad_);                                                \
+        ds_read16<2 * 2048 + ky_ * W * 64>(P[(G) & 1][2], ad_);                                                \
+        ds_read16<3 * 2048 + ky_ * W * 64>(P[(G) & 1][3], ad_);                                                \
+    }
+#define PAIR_LOADW(G)                                                                                          \
+    {                                                                                                          \
+        constexpr int s_ = PAIR_G_S(G), t_ = PAIR_G_TAP(G), kh_ = PAIR_G_KH(G);                                \
+        if constexpr (CB == 1) {                                                                               \
+            Wr[(G) % 3][0] = *(const frag_t *) (wrow[s_] + t_ * (COB * 64) + kh_ * 32);                        \
+        } else {                                                                                               \
+            Wr[(G) % 3][0] = *(const frag_t *) (wrow[0] + (s_ * 9 + t_) * (COB * 64) + kh_ * 32);              \
+            Wr[(G) % 3][1] = *(const frag_t *) (wrow[1] + (s_ * 9 + t_) * (COB * 64) + kh_ * 32);              \
+        }                                                                                                      \
+    }
+    // columns beyond the left / right image edge (the conv's zero padding): output x = (fragment * 32 + l31) mod W
+    const bool edge_l = (l31 & (W - 1)) == 0, edge_r = (l31 & (W - 1)) == ((W - 1) & 31);
+    const frag_t zero_frag = {};
+    PAIR_LOADW(0);
+    PAIR_LOADW(1);
+    PAIR_LOADP(0);
+#define PAIR_GROUP(G)                                                                                          \
+    {                                                                                                          \
+        if constexpr ((G) + 2 < NG) PAIR_LOADW((G) + 2);                                                       \
+        if constexpr ((G) + 1 < NG) {                                                                          \
+            PAIR_LOADP((G) + 1);                                                                               \
+            wait_p4<4>(P[(G) & 1]);                                                                            \
+        } else {                                                                                               \
+            wait_p4<0>(P[(G) & 1]);                                                                            \
+        }                                                                                                      \
+        constexpr int kx_ = PAIR_G_TAP(G) % 3;                                                                 \
+        _Pragma("unroll") for (int f = 0; f < 4; ++f) {                                                        \
+            frag_t pv = P[(G) & 1][f];                                                                         \
+            /* W = 64: a fragment is half a row -- the left edge lies in even, the right edge in odd fragments */ \
+            if (kx_ == 0 && (W < 64 || (f & 1) == 0)) pv = edge_l ? zero_frag : pv;                  \
+            if (kx_ == 2 && (W < 64 || (f & 1) == 1)) pv = edge_r ? zero_frag : pv;                  \
+            if constexpr (CB == 1) {                                                                           \
+                acc2[PAIR_G_S(G)][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[(G) % 3][0], pv, acc2[PAIR_G_S(G)][f], 0, 0, 0); \
+            } else {                                                                                           \
+                acc2[0][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[(G) % 3][0], pv, acc2[0][f], 0, 0, 0); \
+                acc2[1][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[(G) % 3][1], pv, acc2[1][f], 0, 0, 0); \
+            }                                                                                                  \
+        }                                                                                                      \
+    }
+#define PAIR_G4(G) PAIR_GROUP(G) PAIR_GROUP((G) + 1) PAIR_GROUP((G) + 2) PAIR_GROUP((G) + 3)
+    PAIR_G4(0) PAIR_G4(4) PAIR_G4(8) PAIR_G4(12) PAIR_G4(16) PAIR_G4(20) PAIR_G4(24) PAIR_G4(28) PAIR_G4(32)
+#undef PAIR_G4
+#undef PAIR_GROUP
+#undef PAIR_LOADW
+#undef PAIR_LOADP
+#undef PAIR_G_S
+#undef PAIR_G_TAP
+#undef PAIR_G_KH
+
+    // ---- epilogue: bias + ReLU -> bf16 -> per-wave LDS transpose -> 16-byte NHWC stores (128-byte channel runs)
+    __syncthreads();  // every wave is done reading the slab tile
+    constexpr int SP = 144;  // staging pitch per pixel: 64 channels x 2 B + 16 B pad
+    lds_u8 *const stg = (lds_u8 *) smem + wave * (32 * SP);
+    float4 b2[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            b2[j][q] = a.b2 ? *(const float4 *) (a.b2 + n0 + jp * 64 + j * 32 + 8 * q + 4 * lhi) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int px_l = lane >> 3, part_l = lane & 7;
+    const long img_px = (long) a.H * W;
+    unsigned char *const dst_n = (unsigned char *) a.dst + ((size_t) n * img_px * a.dst_stride + n0 + jp * 64 + part_l * 8) * 2;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                u32x2 o;
+                o.x = pack_bf16x2(fmaxf(acc2[j][f][q * 4 + 0] + b2[j][q].x, 0.f), fmaxf(acc2[j][f][q * 4 + 1] + b2[j][q].y, 0.f));
+                o.y = pack_bf16x2(fmaxf(acc2[j][f][q * 4 + 2] + b2[j][q].z, 0.f), fmaxf(acc2[j][f][q * 4 + 3] + b2[j][q].w, 0.f));
+                *(lds_u32x2 *) (stg + l31 * SP + j * 64 + q * 16 + lhi * 8) = o;
+            }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int px = it * 8 + px_l;
+            const u32x4 v = *(const lds_u32x4 *) (stg + px * SP + part_l * 16);
+            const long lin = (long) oy0 * W + (pq * 4 + f) * 32 + px;  // pixel index within the image
+            if (lin < img_px) *(u32x4 *) (dst_n + (size_t) lin * a.dst_stride * 2) = v;
+        }
+    }
+}
+
+constexpr size_t PAIR_LDS = 160 * 1024;
+constexpr int MAX_DEVICES = 64;
+
+template <int WLOG, int SL, int CB>
+int launch_pair_cfg(const PairArgs &a, hipStream_t stream) {
+    using C = PairCfg<WLOG, SL>;
+    static std::atomic<bool> attr_set[MAX_DEVICES];
+    auto kern = conv_pair_kernel<WLOG, SL, CB>;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return (int) hipErrorInvalidDevice;
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) PAIR_LDS);
+        if (e != hipSuccess) return (int) e;
+        attr_set[dev].store(true, std::memory_order_release);
+    }
+    const int tiles_y = (a.H + C::THO - 1) / C::THO;
+    dim3 grid((unsigned) (a.N * tiles_y), (unsigned) (a.cmid / SL), 1);
+    hipLaunchKernelGGL(kern, grid, dim3(512), PAIR_LDS, stream, a);
+    return (int) hipGetLastError();
+}
+
+int pair_slab(int W) { return W == 64 ? 128 : 256; }
+int pair_rows(int W) { return W == 16 ? 16 : 8; }  // output rows per strip
+
+}  // namespace
+
+bool conv_pair_supported(const PairArgs &a) {
+    if (a.W != 16 && a.W != 32 && a.W != 64) return false;
+    if (a.N <= 0 || a.H <= 0 || a.cin <= 0 || a.cin % 32 || a.cmid <= 0 || a.cmid % pair_slab(a.W)) return false;
+    if (a.cb2 != 32 && a.cb2 != 64) return false;
+    if (a.c_stride < a.cin || a.dst_stride < a.cmid || a.c_stride % 8 || a.dst_stride % 8) return false;
+    // sources are read through raw buffer descriptors (2^31-byte limit), destinations with 32-bit element offsets
+    if ((int64_t) a.N * a.H * a.W * a.c_stride * 2 >= (1ll << 31) || (int64_t) a.N * a.H * a.W * a.dst_stride >= (1ll << 31)) return false;
+    return true;
+}
+
+int launch_conv_pair(const PairArgs &a, hipStream_t stream) {
+    if (!conv_pair_supported(a) || !a.src || !a.dst || !a.w1 || !a.w2) return (int) hipErrorInvalidValue;
+    const bool cb2 = a.cb2 == 64;
+    switch (a.W) {
+        case 16: return cb2 ? launch_pair_cfg<4, 256, 2>(a, stream) : launch_pair_cfg<4, 256, 1>(a, stream);
+        case 32: return cb2 ? launch_pair_cfg<5, 256, 2>(a, stream) : launch_pair_cfg<5, 256, 1>(a, stream);
+        default: return cb2 ? launch_pair_cfg<6, 128, 2>(a, stream) : launch_pair_cfg<6, 128, 1>(a, stream);
+    }
+}
+
+// MFMA FLOPs the launch executes: conv1 on every staged halo pixel (incl. the recomputed halo rows and fragment padding) +
+// the block-diagonal conv2 bundles
+double conv_pair_executed_flops(const PairArgs &a) {
+    const int tho = pair_rows(a.W);
+    const int tiles_y = (a.H + tho - 1) / tho;
+    const double staged = a.W == 64 ? 640. : 320.;
+    const double s1 = 2.0 * a.N * tiles_y * staged * (double) a.cmid * a.cin;
+    const double s2 = 2.0 * a.N * tiles_y * (double) (tho * a.W) * (double) a.cmid * a.cb2 * 9.;
+    return s1 + s2;
+}
+
+}  // namespace cpn

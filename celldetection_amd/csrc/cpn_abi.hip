@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -68,7 +69,23 @@ static int64_t tensor_bytes(const cpn_tensor_desc &t, int N, int h, int w, int e
 // (F.interpolate(size=lateral.shape), models/unet.py:213-217, torchvision FPN) or, without one, twice its own size
 // (scale_factor=2, bridge levels); CPN_OP_BILINEAR resizes to the INPUT size (_equal_size(features, inputs),
 // models/cpn.py:277-278) and is a no-op alias when the sizes already agree.
-static void propagate_dims(const cpn_plan *p, int H, int W, ShapePlan &sp) {
+// argument struct of a CPN_OP_CONV_PAIR op (tensor pointers / strides filled by the caller)
+static PairArgs pair_args(const cpn_plan *p, const cpn_op_desc &o, int N, int H, int W) {
+    PairArgs a{};
+    a.N = N; a.H = H; a.W = W;
+    a.cin = o.cin_b; a.cmid = o.cout_b; a.cb2 = o.fuse_cout;
+    a.c_stride = o.src0 >= 0 && p ? p->tensors[o.src0].channels : o.cin_b;
+    a.dst_stride = o.dst >= 0 && p ? p->tensors[o.dst].channels : o.cout_b;
+    if (p) {
+        a.w1 = p->weights + o.weight_offset;
+        a.b1 = o.bias_offset >= 0 ? p->bias + o.bias_offset : nullptr;
+        a.w2 = p->weights + o.fuse_weight_offset;
+        a.b2 = o.fuse_bias_offset >= 0 ? p->bias + o.fuse_bias_offset : nullptr;
+    }
+    return a;
+}
+
+static void propagate_dims(const cpn_plan *p, int N, int H, int W, ShapePlan &sp) {
     const int nt = (int) p->tensors.size();
     sp.th.assign(nt, 0);
     sp.tw.assign(nt, 0);
@@ -101,6 +118,16 @@ static void propagate_dims(const cpn_plan *p, int H, int W, ShapePlan &sp) {
             sp.skip[oi] = (o.alt == 2) != fast;
         }
         switch (o.op) {
+            case CPN_OP_CONV_PAIR: {
+                // runs instead of the two convs in front of it wherever the kernel's full-width strips fit the feature map
+                // (CPN_PAIR=0: kernel A/B switch, read when a shape is planned)
+                const char *e = getenv("CPN_PAIR");
+                const bool fused = !(e && atoi(e) == 0) && p->precision == CPN_PRECISION_BF16 &&
+                                   conv_pair_supported(pair_args(p, o, N, sp.th[o.dst], sp.tw[o.dst]));
+                sp.skip[oi] = !fused;
+                sp.skip[oi - 1] = sp.skip[oi - 2] = fused;
+                break;
+            }
             case CPN_OP_INPUT:
             case CPN_OP_INPUT_STEM: sp.th[o.dst] = H; sp.tw[o.dst] = W; break;
             case CPN_OP_STEM7:
@@ -158,7 +185,7 @@ static const ShapePlan &get_shape_plan(cpn_plan *p, int N, int H, int W) {
     auto it = p->shape_plans.find(key);
     if (it != p->shape_plans.end()) return it->second;
     ShapePlan sp;
-    propagate_dims(p, H, W, sp);
+    propagate_dims(p, N, H, W, sp);
     const int nt = (int) p->tensors.size();
     sp.offsets.assign(nt, -1);
     if (sp.error) return p->shape_plans.emplace(key, std::move(sp)).first->second;
@@ -352,6 +379,26 @@ int cpn_plan_create(cpn_plan **plan, const cpn_tensor_desc *tensors, int32_t n_t
             return fail(CPN_E_INVALID, "cpn_plan_create: malformed stem fast-path op (bf16 / fp8 plans, alt = 2, <= 4 input "
                                        "channels, 32 | 64 output channels)");
         }
+        if (o.op == CPN_OP_CONV_PAIR) {
+            const cpn_op_desc *c1 = oi_ >= 2 ? &p->ops[oi_ - 2] : nullptr, *c2 = oi_ >= 2 ? &p->ops[oi_ - 1] : nullptr;
+            const size_t it1 = (size_t) (o.cin_b / 32), it2 = (size_t) (o.fuse_cout / 32) * 9;
+            if (precision != CPN_PRECISION_BF16 || !c1 || c1->op != CPN_OP_CONV || c2->op != CPN_OP_CONV || c1->kh != 1 ||
+                c1->kw != 1 || c1->stride != 1 || c1->pad != 0 || c1->bundles != 1 || c1->src1 >= 0 || c1->res >= 0 ||
+                c1->up0 || c1->act != CPN_ACT_RELU || c1->subpixel || c1->alt || c1->dst < 0 || c2->src0 != c1->dst ||
+                c2->src1 >= 0 || c2->res >= 0 || c2->up0 || c2->kh != 3 || c2->kw != 3 || c2->stride != 1 || c2->pad != 1 ||
+                c2->act != CPN_ACT_RELU || c2->subpixel || c2->alt || c2->dst < 0 || c2->cin_b != c2->cout_b ||
+                (c2->cout_b != 32 && c2->cout_b != 64) || c2->bundles * c2->cout_b != c1->cout_b || o.src0 != c1->src0 ||
+                o.dst != c2->dst || o.cin_b != c1->cin_b || o.cout_b != c1->cout_b || o.fuse_cout != c2->cout_b ||
+                o.bundles != c2->bundles || o.weight_offset != c1->weight_offset || o.bias_offset != c1->bias_offset ||
+                o.fuse_weight_offset != c2->weight_offset || o.fuse_bias_offset != c2->bias_offset || o.cin_b % 32 ||
+                p->tensors[o.dst].channels != o.cout_b ||
+                (size_t) o.weight_offset + (it1 + (it1 & 1)) * o.cout_b * 64 > weight_bytes ||
+                (size_t) o.fuse_weight_offset + (size_t) o.bundles * (it2 + (it2 & 1)) * o.fuse_cout * 64 > weight_bytes) {
+                delete p;
+                return fail(CPN_E_INVALID, "cpn_plan_create: a CPN_OP_CONV_PAIR op must follow the 1x1 conv + ReLU and the grouped "
+                                           "3x3 stride-1 conv + ReLU (bundles of 32 | 64 channels) it restates and share their offsets");
+            }
+        }
         if (o.alt < 0 || o.alt > 2) {
             delete p;
             return fail(CPN_E_INVALID, "cpn_plan_create: alt must be 0, 1 or 2");
@@ -497,6 +544,16 @@ static int run_or_count(cpn_plan *plan, const void *input, int32_t in_dtype, int
                                                                                    : launch_bilinear(a, st)), "bilinear kernel");
                 break;
             }
+            case CPN_OP_CONV_PAIR: {
+                PairArgs a = pair_args(plan, o, N, sp.th[o.dst], sp.tw[o.dst]);
+                a.src = tptr(o.src0);
+                a.dst = tptr(o.dst);
+                const double fl = conv_pair_executed_flops(a);
+                if (op_flops) op_flops[i] = fl;
+                if (flops) { *flops += fl; break; }
+                rc = check_hip((hipError_t) launch_conv_pair(a, st), "conv pair kernel");
+                break;
+            }
             case CPN_OP_CONV_DEFERRED: break;  // evaluated at the proposal pixels only (cpn_sparse_heads)
             case CPN_OP_CONV: {
                 int Hin, Win;  // virtual input size (see propagate_dims)
@@ -618,6 +675,22 @@ int cpn_conv2d_fp8(const cpn_op_desc *op, const void *src0, int32_t c0_stride, c
         a.fuse_b = (bias && op->fuse_bias_offset >= 0) ? bias + op->fuse_bias_offset : nullptr;
     }
     return check_hip((hipError_t) launch_conv_fp8(a, (hipStream_t) stream), "cpn_conv2d_fp8");
+}
+
+int cpn_conv_pair(const cpn_op_desc *op, const void *src, int32_t c_stride, void *dst, int32_t dst_stride, int32_t N,
+                  int32_t H, int32_t W, const void *weights, const float *bias, void *stream) {
+    if (!op || !src || !dst || !weights || op->op != CPN_OP_CONV_PAIR || N <= 0 || H <= 0 || W <= 0)
+        return fail(CPN_E_INVALID, "cpn_conv_pair: needs a CPN_OP_CONV_PAIR descriptor and non-null buffers");
+    PairArgs a = pair_args(nullptr, *op, N, H, W);
+    a.src = src; a.c_stride = c_stride; a.dst = dst; a.dst_stride = dst_stride;
+    a.w1 = (const unsigned char *) weights + op->weight_offset;
+    a.w2 = (const unsigned char *) weights + op->fuse_weight_offset;
+    a.b1 = (bias && op->bias_offset >= 0) ? bias + op->bias_offset : nullptr;
+    a.b2 = (bias && op->fuse_bias_offset >= 0) ? bias + op->fuse_bias_offset : nullptr;
+    if (!conv_pair_supported(a))
+        return fail(CPN_E_UNSUPPORTED, "cpn_conv_pair: needs W = 16 | 32 | 64, conv1 output channels a multiple of 256 (128 at "
+                                       "W = 64), conv2 bundles of 32 | 64 channels");
+    return check_hip((hipError_t) launch_conv_pair(a, (hipStream_t) stream), "cpn_conv_pair");
 }
 
 int cpn_convert_input_stem(const void *src, int32_t in_dtype, void *dst, int32_t N, int32_t C, int32_t H, int32_t W,

@@ -72,6 +72,25 @@ int launch_conv_fp8(const ConvArgs &a, hipStream_t stream);  // e4m3 operands, v
 // algorithmic FLOPs actually executed by the MFMA loop of that launch (for utilisation reports)
 double conv_executed_flops(const ConvArgs &a);
 
+// Fused head of a grouped bottleneck block (csrc/conv_pair.hip): conv1 1x1 (cin -> cmid) + bias + ReLU -> conv2 3x3 stride 1
+// pad 1 in bundles of cb2 channels (block-diagonal packed like any grouped CPN_OP_CONV) + bias + ReLU, NHWC bf16 in / out
+struct PairArgs {
+    const void *src;       // [N][H][W][c_stride] bf16
+    int c_stride;
+    int N, H, W;           // W must be 16, 32 or 64 (full-width row strips)
+    int cin, cmid;         // multiples of 32 / of the slab width (256; 128 for W = 64)
+    const void *w1;        // [cin/32 items (+1 zero item if odd)][cmid][32] bf16
+    const float *b1;       // [cmid] or nullptr
+    const void *w2;        // [cmid/cb2 bundles][(cb2/32)*9 items (+1 zero item if odd)][cb2][32] bf16
+    const float *b2;       // [cmid] or nullptr
+    int cb2;               // channels per conv2 bundle: 32 | 64
+    void *dst;             // [N][H][W][dst_stride] bf16
+    int dst_stride;
+};
+bool conv_pair_supported(const PairArgs &a);
+int launch_conv_pair(const PairArgs &a, hipStream_t stream);
+double conv_pair_executed_flops(const PairArgs &a);
+
 struct PoolArgs {
     const void *src; void *dst;
     int N, Hin, Win, Hout, Wout, C;   // C = channel stride (multiple of 8)

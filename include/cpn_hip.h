@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CPN_ABI_VERSION 9
+#define CPN_ABI_VERSION 10
 
 #define CPN_E_INVALID (-1)
 #define CPN_E_UNSUPPORTED (-2)
@@ -57,8 +57,19 @@ typedef struct {
  * [7][cout_b][32] bf16 at weight_offset (filter row, output channel, (kx 0..7, c 0..3); kx = 7 and c >= in_channels zero).
  * Both carry `alt` = 2 and stand next to the generic CPN_OP_INPUT / CPN_OP_CONV pair (`alt` = 1): the executor runs the
  * fast pair at every input size the layout fits into the tensor, the generic pair otherwise. */
+/* CPN_OP_CONV_PAIR (bf16 plans; csrc/conv_pair.hip): the head of a grouped bottleneck block -- conv1 1x1 + BN + ReLU ->
+ * conv2 3x3 (groups, stride 1, pad 1) + BN + ReLU, torchvision Bottleneck.forward as built by
+ * celldetection/models/resnet.py:88-116,119-193 for the ResNeXt encoders -- as ONE kernel: conv1's output stays in LDS.
+ * The op stands directly BEHIND the two CPN_OP_CONV ops it restates (conv1 at index i - 2, conv2 at i - 1) and adds no
+ * weights: src0 = conv1's source, dst = conv2's destination, cin_b / cout_b = conv1's input / output channels,
+ * weight_offset / bias_offset = conv1's, fuse_weight_offset / fuse_bias_offset = conv2's, bundles = conv2's bundles,
+ * fuse_cout = conv2's channels per bundle (32 | 64).  The executor runs it INSTEAD of the two convs at every input size at
+ * which the block's feature map is exactly 16, 32 or 64 pixels wide (full-width row strips) and conv1's output channels
+ * are a multiple of the kernel's slab (256; 128 at width 64); the two convs run otherwise.  Same operands and per-conv
+ * rounding (bf16 activations between the two convs) as the unfused pair; conv1 is recomputed on one halo row above and
+ * below each 8-row strip. */
 enum { CPN_OP_INPUT = 0, CPN_OP_CONV = 1, CPN_OP_MAXPOOL = 2, CPN_OP_BILINEAR = 3, CPN_OP_CONV_DEFERRED = 4,
-       CPN_OP_INPUT_STEM = 5, CPN_OP_STEM7 = 6 };
+       CPN_OP_INPUT_STEM = 5, CPN_OP_STEM7 = 6, CPN_OP_CONV_PAIR = 7 };
 enum { CPN_ACT_NONE = 0, CPN_ACT_RELU = 1, CPN_ACT_SIGMOID = 2, CPN_ACT_TANH_SCALED = 3 };
 /* Sub-pixel decomposition of a k = 3 conv over cat(lateral, nearest-x2-upsampled top-down map) -- the first conv of every
  * GeneralizedUNet decoder level (celldetection/models/unet.py:213-224).  Output pixel (2i+py, 2j+px) sees the upsampled
@@ -197,6 +208,11 @@ int cpn_convert_input_stem(const void *src, int32_t in_dtype, void *dst, int32_t
                            int32_t *range_flag, void *stream);
 int cpn_stem7(const cpn_op_desc *op, const void *src, void *dst, int32_t dst_stride, int32_t N, int32_t H, int32_t W,
               const void *weights, const float *bias, float out_inv_scale, void *stream);
+/* Fused bottleneck head (see CPN_OP_CONV_PAIR; `op`: such a descriptor, `weights` / `bias`: the blobs its four offsets
+ * index): src NHWC bf16 [N][H][W][c_stride] -> dst NHWC bf16 [N][H][W][dst_stride], channels [0, cout_b).  Returns
+ * CPN_E_UNSUPPORTED when W is not 16 / 32 / 64 or cout_b is no multiple of the slab width (run the two convs instead). */
+int cpn_conv_pair(const cpn_op_desc *op, const void *src, int32_t c_stride, void *dst, int32_t dst_stride, int32_t N,
+                  int32_t H, int32_t W, const void *weights, const float *bias, void *stream);
 int cpn_maxpool2d(const void *src, void *dst, int32_t N, int32_t Hin, int32_t Win, int32_t C, int32_t k, int32_t stride,
                   int32_t pad, void *stream);
 int cpn_resize_bilinear(const void *src, void *dst, int32_t N, int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout,
