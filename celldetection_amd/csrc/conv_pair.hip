@@ -23,6 +23,7 @@
 //     ITS bundles straight from L2 into registers -- no barrier, no weight staging, nothing shared between waves;
 //   * epilogue: bias + ReLU, bf16, per-wave LDS transpose, 16-byte NHWC stores of 128-byte channel runs.
 #include <atomic>
+#include <cstdlib>
 
 #include "cpn_kernels.h"
 #include "lds_dma.h"
@@ -52,7 +53,7 @@ struct PairCfg {
     static constexpr int LDS = (SL / 32) * XBUF;             // the bf16 slab tile
     static_assert(SL == 128 || SL == 256, "slab");
     static_assert(NPX <= NPXP && OUTF % 4 == 0 && (SL / 64) * PQ == 8, "eight stage-2 jobs");
-    static_assert(3 * (XBUF + WBUF) <= LDS && LDS == 160 * 1024, "LDS budget");
+    static_assert(LDS == 160 * 1024, "LDS budget");
 };
 
 template <int N>
@@ -84,9 +85,13 @@ __device__ __forceinline__ void wait_p4(frag_t (&p)[4]) {
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]) : "n"(N));
 }
 
-template <int WLOG, int SL, int CB>
+// CPS = 32-channel chunks per stage-1 pipeline step: 1 = ring of three chunks (two chunks of prefetch distance), 2 = ring of
+// two steps x two chunks like conv_igemm's 1x1 loop (half the barriers; needs an even chunk count and 4 ring slots in LDS)
+template <int WLOG, int SL, int CB, int CPS>
 __global__ __launch_bounds__(512) void conv_pair_kernel(const PairArgs a) {
     using C = PairCfg<WLOG, SL>;
+    constexpr int NR = CPS == 2 ? 4 : 3;  // ring slots
+    static_assert(NR * (C::XBUF + C::WBUF) <= C::LDS, "staging ring exceeds the LDS");
     constexpr int W = C::W;
     constexpr int XB = C::XBUF, WB = C::WBUF;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const PairArgs a) {
     const rsrc_t rsw = make_rsrc(a.w1, (unsigned) ((size_t) nitems1 * a.cmid * 64));
     const unsigned w_dma_lane = (unsigned) ((lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));
     unsigned char *const xring = smem;
-    unsigned char *const wring = smem + 3 * XB;
+    unsigned char *const wring = smem + NR * XB;
 #define PAIR_DMA(CHUNK, BUF)                                                                                   \
     {                                                                                                          \
         const unsigned xs_ = (unsigned) (CHUNK) * 64u;                                                         \
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const PairArgs a) {
     const int wc = wave / C::WP, wp = wave % C::WP;  // this wave: channels wc*64 .. +63, pixel fragments wp*5 .. +4
     const unsigned swz = (unsigned) ((lhi ^ ((l31 >> 2) & 3)) << 4);
     const unsigned p_lane = lds0 + (unsigned) ((wp * 5 * 32 + l31) * 64) + swz;
-    const unsigned w_lane = lds0 + (unsigned) (3 * XB + (wc * 64 + l31) * 64) + swz;
+    const unsigned w_lane = lds0 + (unsigned) (NR * XB + (wc * 64 + l31) * 64) + swz;
 
     f32x16 acc[2][5];
 #pragma unroll
@@ -152,15 +157,24 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const PairArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][f][r] = 0.f;
 
+#ifdef PAIR_EXP_NOMFMA1
+#define PAIR_MMA(ACC, A_, B_) asm volatile("" ::"v"(A_), "v"(B_))
+#else
+#define PAIR_MMA(ACC, A_, B_) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, ACC, 0, 0, 0)
+#endif
 #define MMA_SET1(S, PENDING)                                                                                   \
     {                                                                                                          \
         wait_set1<PENDING>(S);                                                                                 \
         _Pragma("unroll") for (int f = 0; f < 5; ++f) {                                                        \
-            acc[0][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(S.w[0], S.p[f], acc[0][f], 0, 0, 0);           \
-            acc[1][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(S.w[1], S.p[f], acc[1][f], 0, 0, 0);           \
+            PAIR_MMA(acc[0][f], S.w[0], S.p[f]);                                                               \
+            PAIR_MMA(acc[1][f], S.w[1], S.p[f]);                                                               \
         }                                                                                                      \
     }
 
+    // tuning builds (tools/build_variant.sh; results are wrong by construction): -DPAIR_EXP_NOS1 skips stage 1's DMA + MFMA
+    // loop, -DPAIR_EXP_NOS2 stage 2's groups, -DPAIR_EXP_NOEPI the output stores
+#ifndef PAIR_EXP_NOS1
+  if constexpr (CPS == 1) {
     // prologue: three chunks in flight, the first one landed
     PAIR_DMA(0, 0);
     if (nchunks > 1) PAIR_DMA(1, 1);
@@ -183,8 +197,12 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const PairArgs a) {
             wait_vm<0>();
         }
         wait_set1<0>(B);
+#ifndef PAIR_EXP_NOBAR
         __builtin_amdgcn_s_barrier();  // ... and so have everybody else's: ring slot `buf` is free
+#endif
+#ifndef PAIR_EXP_NODMA
         if (c + 3 < nchunks) PAIR_DMA(c + 3, buf);
+#endif
         buf = buf == 2 ? 0 : buf + 1;
         load_set1(A, w_lane + (unsigned) (buf * WB), p_lane + (unsigned) (buf * XB));  // k-half 0 of chunk c+1
         MMA_SET1(B, 7);
@@ -192,8 +210,91 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const PairArgs a) {
     load_set1(B, (w_lane + (unsigned) (buf * WB)) ^ 32u, (p_lane + (unsigned) (buf * XB)) ^ 32u);
     MMA_SET1(A, 7);
     MMA_SET1(B, 0);
+  } else {
+    // two chunks per step: step s = chunks 2s, 2s+1 in ring slots 2(s & 1), 2(s & 1) + 1; the DMA of step s+2 is issued at the
+    // boundary that closes step s and has the whole of step s+1 (40 MFMAs per wave) to land
+    const int nsteps = nchunks >> 1;
+    PAIR_DMA(0, 0);
+    PAIR_DMA(1, 1);
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if (nsteps > 1) {
+        PAIR_DMA(2, 2);
+        PAIR_DMA(3, 3);
+    }
+    Set1 A, B;
+    load_set1(A, w_lane, p_lane);
+    unsigned xo = 0, wo = 0;  // byte offsets of the current step's first ring slot
+    for (int st = 0; st + 1 < nsteps; ++st) {
+        load_set1(B, (w_lane + wo) ^ 32u, (p_lane + xo) ^ 32u);             // chunk 0, k-half 1
+        MMA_SET1(A, 7);                                                      // chunk 0, k-half 0
+        load_set1(A, w_lane + wo + WB, p_lane + xo + XB);                    // chunk 1, k-half 0
+        MMA_SET1(B, 7);
+        load_set1(B, (w_lane + wo + WB) ^ 32u, (p_lane + xo + XB) ^ 32u);    // chunk 1, k-half 1
+        MMA_SET1(A, 7);
+        // step boundary: my DMA of step st+1 landed, all my reads of step st returned ...
+        wait_vm<0>();
+        wait_set1<0>(B);
+#ifndef PAIR_EXP_NOBAR
+        __builtin_amdgcn_s_barrier();  // ... and so have everybody else's: the two slots of step st are free
+#endif
+#ifndef PAIR_EXP_NODMA
+        if (st + 2 < nsteps) {
+            const int sl_ = (st & 1) * 2;
+            PAIR_DMA(2 * st + 4, sl_);
+            PAIR_DMA(2 * st + 5, sl_ + 1);
+        }
+#endif
+        xo = xo ? 0u : (unsigned) (2 * XB);
+        wo = wo ? 0u : (unsigned) (2 * WB);
+        load_set1(A, w_lane + wo, p_lane + xo);                              // first group of step st+1
+        MMA_SET1(B, 7);                                                      // last group of step st (operands in registers)
+    }
+    load_set1(B, (w_lane + wo) ^ 32u, (p_lane + xo) ^ 32u);
+    MMA_SET1(A, 7);
+    load_set1(A, w_lane + wo + WB, p_lane + xo + XB);
+    MMA_SET1(B, 7);
+    load_set1(B, (w_lane + wo + WB) ^ 32u, (p_lane + xo + XB) ^ 32u);
+    MMA_SET1(A, 7);
+    MMA_SET1(B, 0);
+  }
+#endif
 #undef MMA_SET1
+#undef PAIR_MMA
 #undef PAIR_DMA
+
+    // stage 2's job of this wave (see below): its first weight fragments are requested from L2 NOW, ahead of the slab-tile
+    // write and its two barriers
+    const int jp = wave / C::PQ, pq = wave % C::PQ;
+    // weights: packed [bundle][item = chunk-in-bundle * 9 + tap (+ 1 zero item if odd)][cout_b][32] bf16, rows are the MFMA
+    // fragment rows (not swizzled): lane -> row l31 of row block j, 16-byte part 2 * khalf + lhi
+    constexpr int COB = 32 * CB;                  // channels per bundle
+    constexpr int NI2 = 9 * CB + ((9 * CB) & 1);  // items per bundle incl. padding
+    const unsigned char *wrow[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int bundle = CB == 1 ? (n0 >> 5) + jp * 2 + j : (n0 >> 6) + jp;
+        const int row = CB == 1 ? l31 : j * 32 + l31;
+        wrow[j] = (const unsigned char *) a.w2 + ((size_t) bundle * NI2 * COB + row) * 64 + lhi * 16;
+    }
+    frag_t Wr[3][2];
+#define PAIR_G_S(G) ((G) / 18)
+#define PAIR_G_TAP(G) (((G) % 18) >> 1)
+#define PAIR_G_KH(G) ((G) & 1)
+#define PAIR_LOADW(G)                                                                                          \
+    {                                                                                                          \
+        constexpr int s_ = PAIR_G_S(G), t_ = PAIR_G_TAP(G), kh_ = PAIR_G_KH(G);                                \
+        if constexpr (CB == 1) {                                                                               \
+            Wr[(G) % 3][0] = *(const frag_t *) (wrow[s_] + t_ * (COB * 64) + kh_ * 32);                        \
+        } else {                                                                                               \
+            Wr[(G) % 3][0] = *(const frag_t *) (wrow[0] + (s_ * 9 + t_) * (COB * 64) + kh_ * 32);              \
+            Wr[(G) % 3][1] = *(const frag_t *) (wrow[1] + (s_ * 9 + t_) * (COB * 64) + kh_ * 32);              \
+        }                                                                                                      \
+    }
+#ifndef PAIR_EXP_NOS2
+    PAIR_LOADW(0);
+    PAIR_LOADW(1);
+#endif
 
     // ---- the slab tile: relu(conv1 + bias) as bf16 records [chunk][halo pixel][32], zero outside the image
     __syncthreads();  // every wave is done with the staging ring
@@ -229,7 +330,6 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const PairArgs a) {
     // j = 0, 1 of 32) on output fragments pq*4 .. +3.  CB = 1: row block j is the 32-channel bundle 2 jp + j and reads slab
     // chunk 2 jp + j; CB = 2: both row blocks belong to the 64-channel bundle jp and read chunks 2 jp, 2 jp + 1.
     // ------------------------------------------------------------------------------------------------------------
-    const int jp = wave / C::PQ, pq = wave % C::PQ;
     f32x16 acc2[2][4];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -245,24 +345,9 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const PairArgs a) {
         const int xo = l31 + kx - 1;  // (-1 for lane 0 at kx = 0: the address is garbage and the value masked)
         a_kx[kx] = lds0 + (unsigned) (jp * 2 * XB + pq * 4 * 2048) + (unsigned) (xo * 64) + (unsigned) ((lhi ^ ((xo >> 2) & 3)) << 4);
     }
-    // weights: packed [bundle][item = chunk-in-bundle * 9 + tap (+ 1 zero item if odd)][cout_b][32] bf16, rows are the MFMA
-    // fragment rows (not swizzled): lane -> row l31 of row block j, 16-byte part 2 * khalf + lhi
-    constexpr int COB = 32 * CB;                  // channels per bundle
-    constexpr int NI2 = 9 * CB + ((9 * CB) & 1);  // items per bundle incl. padding
-    const unsigned char *wrow[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int bundle = CB == 1 ? (n0 >> 5) + jp * 2 + j : (n0 >> 6) + jp;
-        const int row = CB == 1 ? l31 : j * 32 + l31;
-        wrow[j] = (const unsigned char *) a.w2 + ((size_t) bundle * NI2 * COB + row) * 64 + lhi * 16;
-    }
     // group g = (s, tap, khalf), s = row block (CB = 1) | chunk of the bundle (CB = 2): 4 pixel fragments, 4 | 8 MFMAs
     constexpr int NG = 36;
     frag_t P[2][4];
-    frag_t Wr[3][2];
-#define PAIR_G_S(G) ((G) / 18)
-#define PAIR_G_TAP(G) (((G) % 18) >> 1)
-#define PAIR_G_KH(G) ((G) & 1)
 #define PAIR_LOADP(G)                                                                                          \
     {                                                                                                          \
         constexpr int s_ = PAIR_G_S(G), t_ = PAIR_G_TAP(G), kh_ = PAIR_G_KH(G);                                \
@@ -273,21 +358,10 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const PairArgs a) {
         ds_read16<2 * 2048 + ky_ * W * 64>(P[(G) & 1][2], ad_);                                                \
         ds_read16<3 * 2048 + ky_ * W * 64>(P[(G) & 1][3], ad_);                                                \
     }
-#define PAIR_LOADW(G)                                                                                          \
-    {                                                                                                          \
-        constexpr int s_ = PAIR_G_S(G), t_ = PAIR_G_TAP(G), kh_ = PAIR_G_KH(G);                                \
-        if constexpr (CB == 1) {                                                                               \
-            Wr[(G) % 3][0] = *(const frag_t *) (wrow[s_] + t_ * (COB * 64) + kh_ * 32);                        \
-        } else {                                                                                               \
-            Wr[(G) % 3][0] = *(const frag_t *) (wrow[0] + (s_ * 9 + t_) * (COB * 64) + kh_ * 32);              \
-            Wr[(G) % 3][1] = *(const frag_t *) (wrow[1] + (s_ * 9 + t_) * (COB * 64) + kh_ * 32);              \
-        }                                                                                                      \
-    }
     // columns beyond the left / right image edge (the conv's zero padding): output x = (fragment * 32 + l31) mod W
     const bool edge_l = (l31 & (W - 1)) == 0, edge_r = (l31 & (W - 1)) == ((W - 1) & 31);
     const frag_t zero_frag = {};
-    PAIR_LOADW(0);
-    PAIR_LOADW(1);
+#ifndef PAIR_EXP_NOS2
     PAIR_LOADP(0);
 #define PAIR_GROUP(G)                                                                                          \
     {                                                                                                          \
@@ -314,6 +388,7 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const PairArgs a) {
     }
 #define PAIR_G4(G) PAIR_GROUP(G) PAIR_GROUP((G) + 1) PAIR_GROUP((G) + 2) PAIR_GROUP((G) + 3)
     PAIR_G4(0) PAIR_G4(4) PAIR_G4(8) PAIR_G4(12) PAIR_G4(16) PAIR_G4(20) PAIR_G4(24) PAIR_G4(28) PAIR_G4(32)
+#endif
 #undef PAIR_G4
 #undef PAIR_GROUP
 #undef PAIR_LOADW
@@ -351,6 +426,9 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const PairArgs a) {
             const int px = it * 8 + px_l;
             const u32x4 v = *(const lds_u32x4 *) (stg + px * SP + part_l * 16);
             const long lin = (long) oy0 * W + (pq * 4 + f) * 32 + px;  // pixel index within the image
+#ifdef PAIR_EXP_NOEPI
+            if (a.N < 0)
+#endif
             if (lin < img_px) *(u32x4 *) (dst_n + (size_t) lin * a.dst_stride * 2) = v;
         }
     }
@@ -359,11 +437,11 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const PairArgs a) {
 constexpr size_t PAIR_LDS = 160 * 1024;
 constexpr int MAX_DEVICES = 64;
 
-template <int WLOG, int SL, int CB>
-int launch_pair_cfg(const PairArgs &a, hipStream_t stream) {
+template <int WLOG, int SL, int CB, int CPS>
+int launch_pair_cps(const PairArgs &a, hipStream_t stream) {
     using C = PairCfg<WLOG, SL>;
     static std::atomic<bool> attr_set[MAX_DEVICES];
-    auto kern = conv_pair_kernel<WLOG, SL, CB>;
+    auto kern = conv_pair_kernel<WLOG, SL, CB, CPS>;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return (int) hipErrorInvalidDevice;
     if (!attr_set[dev].load(std::memory_order_acquire)) {
@@ -375,6 +453,16 @@ int launch_pair_cfg(const PairArgs &a, hipStream_t stream) {
     dim3 grid((unsigned) (a.N * tiles_y), (unsigned) (a.cmid / SL), 1);
     hipLaunchKernelGGL(kern, grid, dim3(512), PAIR_LDS, stream, a);
     return (int) hipGetLastError();
+}
+
+template <int WLOG, int SL, int CB>
+int launch_pair_cfg(const PairArgs &a, hipStream_t stream) {
+    // two chunks per pipeline step wherever four ring slots fit the LDS (the 256-channel slabs) and the chunk count is even
+    if constexpr (4 * (PairCfg<WLOG, SL>::XBUF + PairCfg<WLOG, SL>::WBUF) <= PairCfg<WLOG, SL>::LDS) {
+        const char *e = getenv("CPN_PAIR_CPS");  // kernel A/B switch
+        if ((a.cin & 63) == 0 && !(e && atoi(e) == 1)) return launch_pair_cps<WLOG, SL, CB, 2>(a, stream);
+    }
+    return launch_pair_cps<WLOG, SL, CB, 1>(a, stream);
 }
 
 int pair_slab(int W) { return W == 64 ? 128 : 256; }
@@ -390,6 +478,13 @@ bool conv_pair_supported(const PairArgs &a) {
     // sources are read through raw buffer descriptors (2^31-byte limit), destinations with 32-bit element offsets
     if ((int64_t) a.N * a.H * a.W * a.c_stride * 2 >= (1ll << 31) || (int64_t) a.N * a.H * a.W * a.dst_stride >= (1ll << 31)) return false;
     return true;
+}
+
+// workgroups of the launch (strips x slabs): below ~3/4 of the 256 CUs the two plain convs, whose tiles shrink with the
+// problem, are as fast or faster (profiles/r04_pair_microbench.txt)
+long conv_pair_blocks(const PairArgs &a) {
+    const int tho = pair_rows(a.W);
+    return (long) a.N * ((a.H + tho - 1) / tho) * (a.cmid / pair_slab(a.W));
 }
 
 int launch_conv_pair(const PairArgs &a, hipStream_t stream) {

@@ -120,10 +120,12 @@ static void propagate_dims(const cpn_plan *p, int N, int H, int W, ShapePlan &sp
         switch (o.op) {
             case CPN_OP_CONV_PAIR: {
                 // runs instead of the two convs in front of it wherever the kernel's full-width strips fit the feature map
-                // (CPN_PAIR=0: kernel A/B switch, read when a shape is planned)
+                // and its strips x slabs fill the chip (CPN_PAIR=0 / 2: never / wherever supported -- kernel A/B and tests)
                 const char *e = getenv("CPN_PAIR");
-                const bool fused = !(e && atoi(e) == 0) && p->precision == CPN_PRECISION_BF16 &&
-                                   conv_pair_supported(pair_args(p, o, N, sp.th[o.dst], sp.tw[o.dst]));
+                const int mode = e ? atoi(e) : 1;
+                const PairArgs pa = pair_args(p, o, N, sp.th[o.dst], sp.tw[o.dst]);
+                const bool fused = mode != 0 && p->precision == CPN_PRECISION_BF16 && conv_pair_supported(pa) &&
+                                   (mode == 2 || conv_pair_blocks(pa) >= 192);
                 sp.skip[oi] = !fused;
                 sp.skip[oi - 1] = sp.skip[oi - 2] = fused;
                 break;

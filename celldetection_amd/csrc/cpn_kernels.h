@@ -89,6 +89,7 @@ struct PairArgs {
 };
 bool conv_pair_supported(const PairArgs &a);
 int launch_conv_pair(const PairArgs &a, hipStream_t stream);
+long conv_pair_blocks(const PairArgs &a);  // workgroups of that launch
 double conv_pair_executed_flops(const PairArgs &a);
 
 struct PoolArgs {

@@ -64,8 +64,9 @@ typedef struct {
  * weights: src0 = conv1's source, dst = conv2's destination, cin_b / cout_b = conv1's input / output channels,
  * weight_offset / bias_offset = conv1's, fuse_weight_offset / fuse_bias_offset = conv2's, bundles = conv2's bundles,
  * fuse_cout = conv2's channels per bundle (32 | 64).  The executor runs it INSTEAD of the two convs at every input size at
- * which the block's feature map is exactly 16, 32 or 64 pixels wide (full-width row strips) and conv1's output channels
- * are a multiple of the kernel's slab (256; 128 at width 64); the two convs run otherwise.  Same operands and per-conv
+ * which the block's feature map is exactly 16, 32 or 64 pixels wide (full-width row strips), conv1's output channels
+ * are a multiple of the kernel's slab (256; 128 at width 64) and batch x strips x slabs give >= 192 workgroups; the two
+ * convs run otherwise.  Same operands and per-conv
  * rounding (bf16 activations between the two convs) as the unfused pair; conv1 is recomputed on one halo row above and
  * below each 8-row strip. */
 enum { CPN_OP_INPUT = 0, CPN_OP_CONV = 1, CPN_OP_MAXPOOL = 2, CPN_OP_BILINEAR = 3, CPN_OP_CONV_DEFERRED = 4,

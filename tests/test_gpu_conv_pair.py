@@ -120,6 +120,7 @@ def test_plan_picks_the_fused_pair_per_input_size(dev, size, fused, monkeypatch)
     stage's feature map is 16 / 32 / 64 pixels wide -- head maps are identical to the plan without fused ops."""
     import celldetection_amd as cda
     from celldetection_amd.synth import synth_state_dict
+    monkeypatch.setenv('CPN_PAIR', '2')  # wherever the kernel applies (by default: only where the launch fills the chip)
     m = cda.models.CpnResNeXt50FPN(3, nms_thresh=.5, score_thresh=.5)
     m.load_state_dict(synth_state_dict(m.state_dict(), seed=1))
     m = m.to(dev)
@@ -137,5 +138,32 @@ def test_plan_picks_the_fused_pair_per_input_size(dev, size, fused, monkeypatch)
     m2 = m2.to(dev)
     exp = m2.core_forward(x)
     assert not any(p['op'] == 'conv_pair' and p['gflop'] > 0 for p in m2.engine(dev).profile(x, m2.core.order, True))
+    for a, b in zip(got, exp):
+        assert torch.equal(a, b)
+
+
+def test_fused_pairs_run_by_default_where_they_fill_the_chip(dev):
+    """Batch 16 of 256^2 tiles through a ResNeXt101 (32x8d) encoder: stage 1 (64 pixels wide, 256 channels) gives 16 x 8 x 2 =
+    256 workgroups -> fused by default; the deeper stages (128 / 64 workgroups) keep the two convs.  Same head maps either way."""
+    import os
+    import celldetection_amd as cda
+    from celldetection_amd.synth import synth_state_dict
+    assert os.environ.get('CPN_PAIR') is None
+    m = cda.models.CpnResNeXt101FPN(3, nms_thresh=.5, score_thresh=.5)
+    m.load_state_dict(synth_state_dict(m.state_dict(), seed=2))
+    m = m.to(dev)
+    x = torch.rand(16, 3, 256, 256, generator=torch.Generator().manual_seed(0)).to(dev)
+    prof = m.engine(dev).profile(x, m.core.order, True)
+    ran = [p['name'] for p in prof if p['op'] == 'conv_pair' and p['gflop'] > 0]
+    assert len(ran) == 3 and all('body.1.1.' in r for r in ran), ran
+    got = [t.clone() for t in m.core_forward(x)]
+    os.environ['CPN_PAIR'] = '0'
+    try:
+        m2 = cda.models.CpnResNeXt101FPN(3, nms_thresh=.5, score_thresh=.5)
+        m2.load_state_dict(m.state_dict())
+        m2 = m2.to(dev)
+        exp = m2.core_forward(x)
+    finally:
+        del os.environ['CPN_PAIR']
     for a, b in zip(got, exp):
         assert torch.equal(a, b)

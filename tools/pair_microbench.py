@@ -63,7 +63,7 @@ def main():
         same = torch.equal(out, out2)
         gf = 2. * n * h * w * cmid * (cin + cmid // c['groups'] * 9) / 1e9
         print(f'{name:8s} fused {t_f:7.1f} us   conv1 {t_1:6.1f} + conv2 {t_2:6.1f} = {t_1 + t_2:6.1f} (back to back {t_12:6.1f}) us   '
-              f'x{t_12 / t_f:.2f}   {gf / t_f * 1e-3:7.1f} TF/s algorithmic   identical={same}', flush=True)
+              f'x{t_12 / t_f:.2f}   {gf / t_f * 1e3:7.1f} TF/s algorithmic   identical={same}', flush=True)
 
 
 if __name__ == '__main__':
