@@ -3,6 +3,7 @@ switch added for an experiment): ONE model build, then the per-op profile of the
 per layer class and for the layers whose time changes.
 
     python tools/ab_layers.py [--model CpnResNeXt101UNet] [--batch 16] [--tile 512] "CPN_PWR=1" "CPN_RW=1" "CPN_PWR=1 CPN_RW=1"
+    python tools/ab_layers.py --fresh "CPN_PAIR=0"        (switches read when a shape is planned need a fresh engine)
 """
 import argparse
 import os
@@ -18,6 +19,8 @@ from celldetection_amd.synth import synth_state_dict  # noqa: E402
 
 def klass(p):
     n = p['name']
+    if p['op'] == 'conv_pair':
+        return 'enc pair (conv1+conv2)'
     if p['op'] != 'conv':
         return 'helpers'
     if 'backbone.body' in n:
@@ -35,6 +38,8 @@ def main():
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--tile', type=int, default=512)
     ap.add_argument('--reps', type=int, default=4)
+    ap.add_argument('--fresh', action='store_true', help='re-create the engine per setting (switches that are read when a '
+                                                         'shape is planned, e.g. CPN_PAIR)')
     ap.add_argument('settings', nargs='*')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
@@ -53,6 +58,10 @@ def main():
             for kv in s.split():
                 k, v = kv.split('=')
                 os.environ[k] = v
+            if args.fresh:
+                model.repack()
+                eng = model.engine(dev)
+                eng.profile(x, model.core.order, True)  # (a fresh engine's first run pays one-time set-up)
             prof = eng.profile(x, model.core.order, True)
             cur = res.setdefault(s, prof)
             for a, b in zip(cur, prof):
