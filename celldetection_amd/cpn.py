@@ -222,14 +222,17 @@ class _Engine:
             self._graphs[key] = self._graphs.pop(key)  # most recently used last
         if len(st['slots']) < self.GRAPH_SLOTS:
             n, _, h, w = x.shape
-            need = int(_lib.load().cpn_plan_workspace_bytes(self.handle, n, h, w))
-            slot = dict(x=torch.empty_like(x), ws=torch.empty(max(need, 1), dtype=torch.uint8, device=self.device),
-                        need=need, outputs=self._alloc_outputs(n, h, w, order_total, refinement, gated),
-                        flag=torch.zeros(1, dtype=torch.int32, device=self.device))
             cur = torch.cuda.current_stream(self.device)
             side = torch.cuda.Stream(self.device)
             side.wait_stream(cur)
+            slot = None
             try:
+                # a slot owns its input copy, arena and head maps: on a memory-tight GPU this allocation may fail -- like a
+                # failed capture that only costs the optimisation (eager launches, the shape's slots released)
+                need = int(_lib.load().cpn_plan_workspace_bytes(self.handle, n, h, w))
+                slot = dict(x=torch.empty_like(x), ws=torch.empty(max(need, 1), dtype=torch.uint8, device=self.device),
+                            need=need, outputs=self._alloc_outputs(n, h, w, order_total, refinement, gated),
+                            flag=torch.zeros(1, dtype=torch.int32, device=self.device))
                 with torch.cuda.stream(side):
                     slot['x'].copy_(x)
                     # eager run on the capture stream first: per-device function attributes (dynamic LDS limit) are set on
@@ -241,10 +244,13 @@ class _Engine:
                         self._launch(slot['x'], dt, h, w, slot['ws'], need, slot['outputs'], slot['flag'], n)
                 slot['graph'] = g
             except Exception as e:  # capture is an optimisation: fall back to eager launches, loudly
-                warnings.warn(f'hipGraph capture of the conv graph failed ({type(e).__name__}: {e}); using eager launches',
+                warnings.warn(f'hipGraph slot of the conv graph not available ({type(e).__name__}: {e}); using eager launches',
                               RuntimeWarning)
-                self._graph_broken = True
-                self._graphs.pop(key, None)
+                self._graph_broken = True  # (no retry per forward: a model that ran eagerly keeps running eagerly)
+                slot = None
+                self._graphs.clear()       # releases the arenas / head maps of every captured shape
+                if isinstance(e, torch.cuda.OutOfMemoryError):
+                    torch.cuda.empty_cache()
                 return None
             finally:
                 cur.wait_stream(side)
@@ -276,9 +282,15 @@ class _Engine:
             raise ValueError('per-op profiling needs a batch whose tensors stay below 2^31 elements')
         if gated and nb < n:  # (CPN.core_forward routes such batches to the dense plan)
             raise NotImplementedError('score-gated heads need the whole batch in one graph run (tensors below 2^31 bytes)')
+        cin = self.plan.meta.get('in_channels')
+        if cin is not None and x.shape[1] != cin:  # (a slot's input copy would silently broadcast a 1-channel batch)
+            raise ValueError(f'inputs have {x.shape[1]} channels, the model was built for {cin}')
         slot = None
         if _timed is None and _absmax is None and nb == n and self.precision != 'fp32':
-            slot = self._graph_slot((n, h, w, dt, order_total, bool(refinement)), x, dt, order_total, refinement, gated)
+            # kernel-selection switches that are read per launch are frozen into a captured graph: part of the key
+            env = tuple(os.environ.get(k) for k in ('CPN_RW', 'CPN_PWR', 'CPN_PAIR_CPS'))
+            slot = self._graph_slot((n, x.shape[1], h, w, dt, order_total, bool(refinement), env), x, dt, order_total,
+                                    refinement, gated)
         if slot is not None and 'graph' in slot:
             slot['x'].copy_(x, non_blocking=True)
             slot['graph'].replay()
@@ -373,9 +385,14 @@ class CPN(nn.Module):
         self.precision = 'bf16'
         # score-gated location / Fourier heads (bf16 only; csrc/sparse_heads.hip): the two heads are evaluated at the
         # proposal pixels only -- CPN.forward reads nothing else of their maps (cpn.py:613-637); outputs are identical.
-        # Validated bit-identical on the MI355X (tests/test_gpu_sparse_heads.py); a run-time switch, default off so that the
-        # default graph is the reference's dense one: set ``model.sparse_heads = True``
-        self.sparse_heads = False
+        # Validated bit-identical on the MI355X (tests/test_gpu_sparse_heads.py).  A run-time switch:
+        #   'auto' (default)  forward() / forward_pipelined() and everything built on them (tile loops) gate the two heads
+        #                     wherever the plan qualifies, with the dense convs as fallback above the measured break-even
+        #                     density (ops.SPARSE_HEADS_MAX_DENSITY) and for batches the engine must split; the public
+        #                     core_forward() / engine() -- CPNCore.forward's dense maps, per-op profiles -- stay dense
+        #   True              additionally core_forward() / engine() use the gated plan (locations / fourier maps are None)
+        #   False             the reference's dense graph everywhere
+        self.sparse_heads = 'auto'
         self._fp8_scales = None
         # sub-pixel decomposition of the UNet decoder convs over x2-upsampled maps (bf16 plans; graph._two_conv_norm_relu):
         # 4/9 of the MACs on the upsampled channels, taken wherever the upsampling is an exact x2.  A run-time switch.
@@ -421,14 +438,14 @@ class CPN(nn.Module):
             raise NotImplementedError('celldetection_amd.CPN is an inference engine; training is out of scope.')
         return super().train(False)
 
-    def plan_for(self, precision: str) -> graph.Plan:
+    def plan_for(self, precision: str, gate: bool = None) -> graph.Plan:
         """Layer plan per precision: bf16 fuses the ReadOut tails and the bilinear resize in front of the refinement head;
         fp8 keeps that resize as its own op (on e4m3 codes; also the plan its bf16 calibration run uses, so that the
         tensor ids of the activation scales match); fp32 (verification) fuses nothing."""
         if precision == 'bf16':
             # score-gated heads: same entries / weights, the two head convs are deferred ops; sub-pixel decoder convs:
             # same entries, the first conv of every UNet decoder level additionally carries its decomposition
-            key = (bool(self.sparse_heads), bool(self.subpixel))
+            key = (self._gate_requested(False) if gate is None else bool(gate), bool(self.subpixel))
             if key == (False, True):
                 return self._plan
             if key not in self._alt_plans:
@@ -441,14 +458,25 @@ class CPN(nn.Module):
             self._alt_plans[precision] = graph.build_plan(**self._plan_kwargs, **extra)
         return self._alt_plans[precision]
 
-    def engine(self, device=None, calibration_input=None) -> _Engine:
+    def _gate_requested(self, forward_path: bool) -> bool:
+        sh = self.sparse_heads
+        if isinstance(sh, str):
+            if sh != 'auto':
+                raise ValueError("sparse_heads must be True, False or 'auto'")
+            return forward_path
+        return bool(sh)
+
+    def engine(self, device=None, calibration_input=None, _forward_path: bool = False) -> _Engine:
         device = torch.device(device) if device is not None else self.order_weights_device()
         if device.type != 'cuda':
             raise RuntimeError('celldetection_amd runs on the MI355X (HIP) only: move the model and inputs to a GPU. '
                                'There is no CPU fallback in the product path.')
         if self.precision not in ('bf16', 'fp32', 'fp8'):
             raise ValueError("precision must be 'bf16', 'fp32' or 'fp8'")
-        sparse = (bool(self.sparse_heads), bool(self.subpixel)) if self.precision == 'bf16' else None
+        gate = self._gate_requested(_forward_path)
+        if self.precision == 'bf16' and not gate and self.sparse_heads == 'auto':
+            return self._dense_engine(device)  # ('auto': the dense engine lives next to the gated one)
+        sparse = (gate, bool(self.subpixel)) if self.precision == 'bf16' else None
         if self._engine is None or self._engine.device != device or self._engine.precision != self.precision or \
                 self._engine.sparse_requested != sparse:
             if self.precision == 'fp8':
@@ -461,9 +489,18 @@ class CPN(nn.Module):
                     self.calibrate_fp8(calibration_input)
                 self._engine = _Engine(self.plan_for('fp8'), self.state_dict(), device, 'fp8', act_scales=self._fp8_scales)
             else:
-                self._engine = _Engine(self.plan_for(self.precision), self.state_dict(), device, self.precision)
+                self._engine = _Engine(self.plan_for(self.precision, gate), self.state_dict(), device, self.precision)
             self._engine.sparse_requested = sparse
         return self._engine
+
+    def _dense_engine(self, device) -> _Engine:
+        """bf16 engine of the plan WITHOUT score-gated heads: the public core_forward() / engine() of an 'auto' model and the
+        fallback for batches the engine must split (the gathered heads read the heads' source of the whole batch)."""
+        key = bool(self.subpixel)
+        if self._engine_dense is None or self._engine_dense.device != device or self._engine_dense.sparse_requested != key:
+            self._engine_dense = _Engine(self.plan_for('bf16', False), self.state_dict(), device, 'bf16')
+            self._engine_dense.sparse_requested = key
+        return self._engine_dense
 
     @torch.no_grad()
     def calibrate_fp8(self, inputs: torch.Tensor):
@@ -487,20 +524,15 @@ class CPN(nn.Module):
 
     # ---- forward --------------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def core_forward(self, inputs: torch.Tensor, _static_ok: bool = False):
+    def core_forward(self, inputs: torch.Tensor, _static_ok: bool = False, _forward_path: bool = False):
         """CPNCore.forward (cpn.py:238-283) -> (scores(sigmoid applied), locations, refinement, fourier).
-        (``_static_ok``: internal -- the forward paths consume the maps before the engine re-uses their hipGraph slot.)"""
-        eng = self.engine(inputs.device, calibration_input=inputs)
+        (``_static_ok`` / ``_forward_path``: internal -- the forward paths consume the maps before the engine re-uses their
+        hipGraph slot, and are the callers for which ``sparse_heads = 'auto'`` gates the location / Fourier heads.)"""
+        eng = self.engine(inputs.device, calibration_input=inputs, _forward_path=_forward_path)
         if eng.sparse and eng.max_batch(inputs.shape[0], *inputs.shape[-2:]) < inputs.shape[0]:
             # the engine has to split this batch (2^31-byte tensors), but the gathered heads read the heads' source of the
             # WHOLE batch after the run: such batches take the dense plan (same outputs)
-            if self._engine_dense is None or self._engine_dense.device != eng.device:
-                sh, self.sparse_heads = self.sparse_heads, False
-                try:
-                    self._engine_dense = _Engine(self.plan_for('bf16'), self.state_dict(), eng.device, 'bf16')
-                finally:
-                    self.sparse_heads = sh
-            eng = self._engine_dense
+            eng = self._dense_engine(eng.device)
         scores, locations, refinement, fourier, flag = eng.run(inputs, self.core.order, self.refinement,
                                                                static_ok=_static_ok)
         self._last_flag = flag
@@ -515,7 +547,7 @@ class CPN(nn.Module):
         if not inputs.is_cuda:
             raise RuntimeError('celldetection_amd.CPN.forward needs GPU inputs (no CPU fallback).')
         original_size = tuple(inputs.shape[-2:])
-        scores, locations, refinement, fourier = self.core_forward(inputs, _static_ok=True)
+        scores, locations, refinement, fourier = self.core_forward(inputs, _static_ok=True, _forward_path=True)
         return self.postprocess(scores, locations, refinement, fourier, original_size, nms=nms, flag=self._last_flag,
                                 uncertainty=self._last_uncertainty, sparse=self._last_sparse, **kwargs)
 
@@ -557,7 +589,7 @@ class CPN(nn.Module):
             if not x.is_cuda:
                 raise RuntimeError('celldetection_amd.CPN.forward needs GPU inputs (no CPU fallback).')
             s_conv.wait_stream(caller)  # x was produced on the caller's stream
-            if self.sparse_heads and post_done[0] is not None:
+            if self._gate_requested(True) and post_done[0] is not None:
                 # score-gated heads: this run re-uses the arena of the run before the previous one, whose head source
                 # was read by that batch's post-processing (finished before post_done[0] was recorded)
                 s_conv.wait_event(post_done[0])
@@ -565,7 +597,7 @@ class CPN(nn.Module):
                 if _events is not None:  # (start, end) HIP events around the conv graph, on its launch stream
                     e0 = torch.cuda.Event(enable_timing=True)
                     e0.record(s_conv)
-                maps = self.core_forward(x, _static_ok=True)
+                maps = self.core_forward(x, _static_ok=True, _forward_path=True)
                 ev = torch.cuda.Event(enable_timing=_events is not None)
                 ev.record(s_conv)
                 if _events is not None:

@@ -114,7 +114,8 @@ __global__ void bn_grid_setup_kernel(const Stats *__restrict__ st, const unsigne
     float thr = __uint_as_float((unsigned int) (bstar + 1) << 20);
     // the list only pays when the largest boxes are real outliers: a grid four times coarser per axis still has 16x fewer
     // boxes per cell than no grid, while every listed box costs one IoU test per box of the set
-    if (!(max_ext > 4.f * thr)) thr = max_ext;
+    const bool use_list = max_ext > 4.f * thr;
+    if (!use_list) thr = max_ext;
     float cell = fmaxf(thr * 1.001f, 1e-3f);
     long gw, gh;
     for (;;) {
@@ -124,7 +125,11 @@ __global__ void bn_grid_setup_kernel(const Stats *__restrict__ st, const unsigne
         cell *= 2.f;
     }
     g->minx = minx; g->miny = miny; g->inv_cell = 1.f / cell; g->cell = cell;
-    g->big_thr = cell / 1.001f;  // (>= thr: a grid that had to be coarsened makes fewer boxes oversized)
+    // oversized = larger extent > big_thr.  With the list: exactly the boxes of the histogram buckets above bstar (<= MAX_BIG
+    // by construction; a grid that had to be coarsened raises the bound: fewer oversized boxes).  Without it NO box is
+    // oversized: scaling the largest extent up and down again can land one ulp below it, which would have sent
+    // every box that shares the maximum extent to the list
+    g->big_thr = use_list ? fmaxf(thr, cell / 1.001f) : __uint_as_float(0x7f800000u);
     g->gw = (int) gw; g->gh = (int) gh;
 }
 
@@ -363,10 +368,14 @@ int cpn_nms_binned(const float *boxes, const float *scores, int64_t P, float thr
     e = rocprim::exclusive_scan(ws + L.tmp, tmp, deg, off, (u64) 0, (size_t) P, rocprim::plus<u64>(), st);
     if (e != hipSuccess) return cpn::check_hip(e, "cpn_nms_binned: scan");
     u64 last[2] = {0, 0};
+    unsigned int nbig_host = 0;
     e = hipMemcpyAsync(&last[0], off + (P - 1), 8, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(&last[1], deg + (P - 1), 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(&nbig_host, nbig, 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return cpn::check_hip(e, "cpn_nms_binned: edge count");
+    if (nbig_host > (unsigned int) MAX_BIG)  // (cannot happen by construction of big_thr; a dropped box would be a wrong result)
+        return cpn::fail(CPN_E_UNSUPPORTED, "cpn_nms_binned: more oversized boxes than the list holds");
     const u64 E = last[0] + last[1];
     if (edges_needed) *edges_needed = (int64_t) E;
     if (E > (u64) max_edges)

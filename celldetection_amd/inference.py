@@ -152,7 +152,7 @@ def tiled_inference(model, img: torch.Tensor, crop_size=(1024, 1024), strides=(7
                     world_size: Optional[int] = None, group=None, nms_thresh: Optional[float] = None,
                     forward_fn: Optional[Callable] = None, ops_fns=None, mask: Optional[torch.Tensor] = None,
                     point_mask: Optional[torch.Tensor] = None, point_mask_exclusive: bool = False,
-                    timings: Optional[dict] = None):
+                    timings: Optional[dict] = None, bug_compatible_offsets: bool = False):
     """Slide-level CPN inference.
 
     Args:
@@ -168,6 +168,10 @@ def tiled_inference(model, img: torch.Tensor, crop_size=(1024, 1024), strides=(7
         forward_fn / ops_fns: injection points used by the CPU (gloo) tests of the sharding/gather logic:
             ``forward_fn(tiles, offsets, **kw)`` -> per-image lists; ``ops_fns`` = (border_keep_batched(contours,
             image_index, sides, offsets, size, pad) -> mask, stitch_rule_batched, nms).
+        bug_compatible_offsets: models WITHOUT refinement only.  The reference adds the tile offset to such a model's
+            contours twice (models/cpn.py:655-656,697-699), so its script filters and returns contours displaced by their
+            tile origin; by default this loop takes one offset back (``_undo_double_offset``).  True = bit-parity with the
+            reference script's output for such models (a caller-supplied ``forward_fn`` is never corrected).
         mask: optional [H, W] (or [1, H, W]) foreground mask: tiles whose mask crop is empty are skipped and the crop
             is passed as ``scores_upper_bound`` (TileLoader semantics, cpn_inference.py:94-100).
         point_mask: optional [H, W] map of seed points: tiles without seeds are skipped, ``clip(crop, 0, 1)`` is passed
@@ -242,7 +246,7 @@ def tiled_inference(model, img: torch.Tensor, crop_size=(1024, 1024), strides=(7
         samples, order = flat['contours'].shape[1], flat['fourier'].shape[1]
         if flat['scores'].shape[0] == 0:
             continue
-        if forward_fn is None:
+        if forward_fn is None and not bug_compatible_offsets:
             flat = _undo_double_offset(model, flat, offs, dev)
         sides = []
         for i in idxs:  # sides that have a neighbouring tile (cpn_inference.py:372-380)

@@ -268,6 +268,14 @@ def test_tile_loops_without_refinement_take_one_offset_back(dev):
         H, W = img.shape[-2:]
         assert con.shape[0] > 0 and con[..., 0].min() >= -1 and con[..., 0].max() <= W and con[..., 1].max() <= H
         assert torch.allclose(con.min(1).values, box[:, :2], atol=1e-3) and torch.allclose(con.max(1).values, box[:, 2:], atol=1e-3)
+    # the switch for bit-parity with the reference script: contours keep the doubled offset, i.e. every tile but
+    # the one at the origin returns contours that no longer fit their boxes
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', RuntimeWarning)
+        bug = inference.tiled_inference(model, img, crop, stride, batch_size=4, border_removal=int(g['border']),
+                                        bug_compatible_offsets=True)
+    d = (bug['contours'].min(1).values - bug['boxes'][:, :2]).abs().max(1).values
+    assert bug['scores'].shape[0] > 0 and (d > 1.).any()
     tile = (img if img.ndim == 4 else img[None])[..., :crop[0], :crop[1]]
     y = model(tile, offsets=torch.tensor([[100, 50]]))  # CPN.forward itself stays bug-compatible
     assert not torch.allclose(y['contours'][0].min(1).values, y['boxes'][0][:, :2], atol=1.)

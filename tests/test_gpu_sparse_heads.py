@@ -1,4 +1,4 @@
-"""Score-gated ReadOut heads on the GPU (csrc/sparse_heads.hip, ``model.sparse_heads = True``).
+"""Score-gated ReadOut heads on the GPU (csrc/sparse_heads.hip; ``model.sparse_heads`` = 'auto' (default: forward paths) | True | False).
 
 Validated on the MI355X in round 3 (profiles/r03_pytest_sparse_first_run.log: all cases green on the first hardware run).
 The bar is bit-exactness: the kernel repeats the dense fused head's arithmetic at the proposal pixels, so every output
@@ -150,4 +150,66 @@ def test_batches_the_engine_must_split_take_the_dense_plan(dev, monkeypatch):
     for k in ref:
         if ref[k] is not None:
             for a, b in zip(got[k], ref[k]):
+                assert torch.equal(a, b), k
+
+
+def test_default_auto_gates_the_forward_paths_only(dev):
+    """The product default ``sparse_heads = 'auto'``: forward() / forward_pipelined() gate the two heads (identical outputs),
+    the public core_forward() / engine() keep CPNCore.forward's dense maps (per-op profiles, calibration)."""
+    import celldetection_amd as cda
+    m0 = _model(dev)  # bench recipe: dense graph (sparse_heads = False)
+    m = cda.models.CpnResNet18FPN(3)
+    assert m.sparse_heads == 'auto'
+    m.load_state_dict(m0.state_dict())
+    m = m.to(dev)
+    x = torch.rand(3, 3, 96, 160, generator=torch.Generator().manual_seed(1)).to(dev)
+    offs = torch.tensor([[0, 0], [100, 7], [3, 900]], device=dev)
+    ref = m0(x, offsets=offs)
+    assert sum(int(v.shape[0]) for v in ref['scores']) > 10, 'degenerate test model: no detections'
+    for _ in range(5):  # incl. the hipGraph replays of the gated plan (captured the 2nd .. 4th time a shape is seen)
+        got = m(x, offsets=offs)
+        assert m._last_sparse is not None, 'the default forward() did not take the score-gated plan'
+        for k in ref:
+            if ref[k] is None:
+                assert got[k] is None
+                continue
+            for a, b in zip(got[k], ref[k]):
+                assert torch.equal(a, b), k
+    maps = m.core_forward(x)
+    assert all(t is not None for t in maps) and m._last_sparse is None
+    for a, b in zip(maps, m0.core_forward(x)):
+        assert torch.equal(a, b)
+    eng = m.engine(dev)
+    assert not eng.sparse and m.engine(dev, _forward_path=True).sparse
+    assert len(eng.profile(x, m.core.order, True)) == len(eng.plan.ops)
+    batches = [torch.rand(2, 3, 96, 160, generator=torch.Generator().manual_seed(s)).to(dev) for s in range(5)]
+    for xb, out in zip(batches, list(m.forward_pipelined(iter(batches)))):
+        want = m0(xb)
+        for k in want:
+            if want[k] is not None:
+                for a, b in zip(out[k], want[k]):
+                    assert torch.equal(a, b), k
+    m.score_thresh = m0.score_thresh = 0.  # every pixel a proposal: the dense convs run instead (same values)
+    ref, got = m0(x, nms=False), m(x, nms=False)
+    for k in ref:
+        if ref[k] is not None:
+            for a, b in zip(got[k], ref[k]):
+                assert torch.equal(a, b), k
+
+
+def test_default_auto_on_a_plan_that_does_not_qualify(dev):
+    """U22 heads read 64-channel features (hidden width 64): no score-gated plan -- 'auto' silently stays dense."""
+    import celldetection_amd as cda
+    from celldetection_amd.synth import synth_state_dict
+    m = cda.models.CpnU22(3, backbone_kwargs={'backbone_kwargs': {'base_channels': 32}}, score_thresh=.5)
+    m.load_state_dict(synth_state_dict(m.state_dict(), seed=0))
+    m = m.to(dev)
+    x = torch.rand(2, 3, 64, 96, generator=torch.Generator().manual_seed(0)).to(dev)
+    y = m(x)
+    assert m._last_sparse is None and not m.engine(dev, _forward_path=True).sparse
+    m.sparse_heads = False
+    y2 = m(x)
+    for k in y:
+        if y[k] is not None:
+            for a, b in zip(y[k], y2[k]):
                 assert torch.equal(a, b), k
