@@ -45,6 +45,8 @@ def check_exact(prefix, y, g, n, raw_atol=1e-4, flip_frac=0.):
     coordinate within 1e-6 of x.5 rounds to the other pixel in ``local_refinement`` -- a discontinuity of the
     algorithm, not of the arithmetic)."""
     keys = KEYS + (('box_uncertainties',) if f'{prefix}.box_uncertainties.0' in g.files else ())
+    if prefix == 'nms':  # a fixture that keeps a handful of detections pins next to nothing of the NMS keep set (VERDICT r3)
+        assert all(len(g[f'nms.scores.{i}']) >= 20 for i in range(n)), 'thin golden fixture: regenerate with >= 30 kept detections'
     if len(keys) == len(KEYS):
         assert y['box_uncertainties'] is None
     for k in keys:
@@ -422,6 +424,8 @@ def test_hip_graph_replay_equals_eager_launches(dev, monkeypatch):
     ``core_forward`` must survive later runs (they are cloned out of the slot), and the pipelined tile loop -- which reads
     the slots from a second stream -- must equal per-batch ``forward``."""
     model, g = build('CpnU22_wide', dev)
+    model.sparse_heads = False  # ONE engine behind forward() and the public core_forward() (the default 'auto' keeps a gated
+    # engine for the forward paths next to the dense one: its replays are covered by tests/test_gpu_sparse_heads.py)
     xs = [torch.rand(2, 3, 96, 128, generator=torch.Generator().manual_seed(s)).to(dev) for s in range(7)]
     monkeypatch.setenv('CPN_HIP_GRAPH', '0')
     eager = [model(x) for x in xs]

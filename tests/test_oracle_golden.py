@@ -75,6 +75,8 @@ def _load_model_fixture(name):
 
 def _check_outputs(prefix, y, g, n):
     keys = ('contours', 'boxes', 'scores', 'classes', 'locations', 'fourier', 'contour_proposals')
+    if prefix == 'nms':  # a fixture that keeps a handful of detections pins next to nothing of the NMS keep set
+        assert all(len(g[f'nms.scores.{i}']) >= 20 for i in range(n)), 'thin golden fixture: regenerate with >= 30 kept detections'
     if f'{prefix}.box_uncertainties.0' in g.files:
         keys += ('box_uncertainties',)
     else:
