@@ -119,6 +119,9 @@ __device__ __forceinline__ void add_res8(float (&v)[8], const store8_t r, float)
 // MFMA pixel fragment is TWO output rows x 16 columns instead of one row x 32, so no half of the 32-pixel tile is empty.
 // [N][H][16] IS [N][H/2][32] in memory, hence the launcher passes the output (and a same-size residual) with those
 // virtual dimensions and the epilogue is unchanged; only the halo geometry and the fragment addresses know about it.
+#ifndef CPN_RW_DEFAULT
+#define CPN_RW_DEFAULT 0  // see conv_mode
+#endif
 enum Mode : int { MODE_PW = 0, MODE_S1 = 1, MODE_S2 = 2, MODE_BL = 3, MODE_S1R = 4, MODE_PWR = 5, MODE_N = 6 };
 
 template <int MODE>
@@ -274,18 +277,21 @@ __device__ __forceinline__ void load_frags(frag_t (&w)[WN], frag_t (&p)[WM], uns
     }
 }
 
-// pixel fragments only (MODE_S1R: the weight fragments come from global memory)
+// pixel fragments only (MODE_S1R / MODE_PWR: the weight fragments come from global memory)
 template <int WM, int FRAG_STRIDE>
 __device__ __forceinline__ void load_pfrags(frag_t (&p)[WM], unsigned paddr) {
-    static_assert(WM == 4, "register-weight loop: 128-pixel wave tile");
+    static_assert(WM == 4 || WM == 2, "register-weight loop: 128- or 64-pixel wave tile");
     ds_read16<0>(p[0], paddr);
     ds_read16<FRAG_STRIDE>(p[1], paddr);
-    ds_read16<2 * FRAG_STRIDE>(p[2], paddr);
-    ds_read16<3 * FRAG_STRIDE>(p[3], paddr);
+    if constexpr (WM > 2) {
+        ds_read16<2 * FRAG_STRIDE>(p[2], paddr);
+        ds_read16<3 * FRAG_STRIDE>(p[3], paddr);
+    }
 }
 template <int N, int WM>
 __device__ __forceinline__ void wait_pfrags(frag_t (&p)[WM]) {
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]) : "n"(N));
+    if constexpr (WM == 4) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]) : "n"(N));
+    else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(p[0]), "+v"(p[1]) : "n"(N));
 }
 
 struct ItemState {  // one K item = (32-channel chunk c, filter tap (ky, kx)); wave-uniform scalars
@@ -1046,10 +1052,15 @@ static int conv_mode(const ConvArgs &a) {
     }
     if (a.up0 == 2) return MODE_BL;
     if (a.stride == 2) return MODE_S2;
-    // MODE_S1R is opt-in (CPN_RW=1; read per call so that tests can toggle it): on random operands it runs within 1 % of
-    // the LDS-weight loop (both sit on the same power wall), on all-zero operands 7x7 +8 % / 3x3 -4 %
+    // MODE_S1R (register-weight loop; CPN_RW read per call so that tests can toggle it), bit 0: the 8x256 tile -- opt-in: on
+    // random operands it runs within 1 % of the LDS-weight loop (both sit on the same power wall), on all-zero operands 7x7
+    // +8 % / 3x3 -4 %; bit 1: the 64-channel tiles (2 weight + 2 pixel fragment reads per 4 MFMAs in the LDS-weight
+    // loop -> 2 pixel reads; every wave streams the 8 KiB of a 64 -> 64 tap from L2 itself)
     const char *e = getenv("CPN_RW");
-    return (!CPN_FP8 && e && atoi(e) != 0 && a.KH * a.KW >= 9) ? MODE_S1R : MODE_S1;  // (8x256 tile only)
+    const int rw = e ? atoi(e) : CPN_RW_DEFAULT;
+    if (CPN_FP8 || a.KH * a.KW < 9) return MODE_S1;
+    if (a.cout_b == 64 && a.bundles == 1) return (rw & 2) ? MODE_S1R : MODE_S1;
+    return (rw & 1) ? MODE_S1R : MODE_S1;  // (taken by the 8x256 tile only)
 }
 
 static size_t lds_bytes(const ConvArgs &a, int TH, int BN) {
@@ -1106,7 +1117,8 @@ static int launch_cfg(const ConvArgs &a, hipStream_t stream) {
         case MODE_S1: return launch_mode<TH, BN, WM, WN, MODE_S1>(a, stream);
         case MODE_S1R:
 #if !CPN_FP8
-            if constexpr (TH == 8 && BN == 256 && WM == 4 && WN == 2) return launch_mode<TH, BN, WM, WN, MODE_S1R>(a, stream);
+            if constexpr ((TH == 8 && BN == 256 && WM == 4 && WN == 2) || (BN == 64 && WM == 2 && WN == 2))
+                return launch_mode<TH, BN, WM, WN, MODE_S1R>(a, stream);
 #endif
             return launch_mode<TH, BN, WM, WN, MODE_S1>(a, stream);
 #if !CPN_FP8  // bf16 only: the e4m3 kernel has no registers to spare for the in-register blend (it spilled, and ran at

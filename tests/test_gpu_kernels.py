@@ -206,6 +206,32 @@ def test_conv_register_weight_loop(dev, name, monkeypatch):
     assert (rw - ref).abs().max().item() < 5e-2 * scale
 
 
+C64_CASES = {
+    # the 64-channel tiles: <16,64,2,2> (3x3_c64_th16_tile / 7x7_c64_th16_tile: 4 x 256^2), <8,64,2,2> (small maps), a fused
+    # ReadOut head with 64 hidden units, a concat source, partial tiles
+    '3x3_c64_th16_tile': None, '7x7_c64_th16_tile': None, '3x3_64_64': None, '7x7_head': None,
+    'c64_fused_head_th16': dict(n=4, h=256, w=256, cin=64, cout=64, k=7, fuse_cout=2, fuse_act='tanh_scaled', seed=11),
+    'c64_concat_up_partial': dict(n=3, h=40, w=72, cin=32, cout=64, k=3, cin1=64, up1=True, seed=12),
+    'c64_k5_three_chunks': dict(n=2, h=64, w=64, cin=96, cout=64, k=5, seed=13),
+}
+
+
+@pytest.mark.parametrize('name', list(C64_CASES))
+def test_conv_register_weight_loop_64_channel_tiles(dev, name, monkeypatch):
+    """CPN_RW bit 1: MODE_S1R on the 64-output-channel tiles (the refinement ReadOut head, commons.py:461-511 at 64 -> 64, and
+    the bridge convs): weight fragments from L2 into registers, LDS holds only the halo -- half the LDS fragment reads.  Same K
+    order and MFMA sequence as the LDS-weight loop: bit-identical outputs."""
+    cfg = C64_CASES[name] or CONV_CASES[name]
+    monkeypatch.setenv('CPN_RW', '0')
+    lds, ref, f32 = run_conv(dev, **cfg)
+    monkeypatch.setenv('CPN_RW', '2')
+    rw, _, _ = run_conv(dev, **cfg)
+    assert torch.equal(rw, lds), f'{name}: register-weight loop differs from the LDS-weight loop ' \
+                                 f'(max abs {(rw - lds).abs().max().item():.3e})'
+    scale = max(ref.abs().max().item(), 1.)
+    assert (rw - ref).abs().max().item() < 5e-2 * scale
+
+
 SUBPIXEL_CASES = {
     'sp_64_128_64': dict(n=2, h=32, w=32, c0=64, c1=128, cout=64),
     'sp_padded_channels': dict(n=1, h=64, w=64, c0=8, c1=16, cout=16),
