@@ -229,15 +229,20 @@ def flat_outputs(prefix, y, out):
 # per-spec calibrate_heads arguments.  The head-option / odd-size models have coarse head grids (stride 4: 16 x 24 pixels):
 # denser scores and smaller contours so that >= 30 detections per image survive the NMS (with 1..8 kept
 # detections the keep-index part of those fixtures pinned almost nothing)
-_FPN_DENSE = dict(score_shift=.3, fourier_std=.25, location_std=.4)  # stride-4 head grid (16 x 24 pixels per 64 x 96 image)
+# stride-4 head grid (16 x 24 pixels per 64 x 96 image): dense scores, small contours and SMALL refinement steps -- with the
+# default refinement_raw_std = 1 (up to 3 px per iteration) the pixel snapping of local_refinement turns bf16-sized differences
+# into pixel-sized box changes, which an IoU > 0.5 match of small boxes does not survive (measured: bf16 0.88, fp8 0.55)
+_FPN_DENSE = dict(score_shift=1.5, fourier_std=.4, location_std=.4, refinement_raw_std=.3)
 _U22_SMALL = dict(score_shift=-.5, fourier_std=.3, location_std=.4)                   # full-resolution head grid: smaller contours
 MODEL_CALIBRATION = {'CpnU22_classes4': dict(score_shift=-3.5),
                      # every model fixture keeps >= 30 detections per image after the NMS (the FPN families of
                      # BASELINE configs[1] / [4] and the only pin of uncertainty_nms kept 2..5)
-                     'CpnResNet18FPN': _FPN_DENSE, 'CpnResNet18FPN_odd': _FPN_DENSE, 'CpnResNet18FPN_heads': _FPN_DENSE,
+                     'CpnResNet18FPN': _FPN_DENSE, 'CpnResNet18FPN_odd': _FPN_DENSE, 'CpnResNet18FPN_heads': dict(_FPN_DENSE, score_shift=2.2, fourier_std=.35),
                      'CpnResNet50FPN': _FPN_DENSE, 'CpnU22': _U22_SMALL, 'CpnU22_buckets': dict(_U22_SMALL, score_shift=-.2, refinement_raw_std=.3),
                      'CpnU22_uncertainty': dict(score_shift=1., fourier_std=.3, location_std=.4),
-                     'CpnResNeXt101UNet': dict(fourier_std=1.), 'CpnResNeXt101UNet_odd': dict(fourier_std=1.),
+                     # (CpnResNeXt101UNet keeps its round-1 fixture, 21 kept per image: a denser one put two proposals within
+                     # fp32 summation-order noise of each other in the score sort -- a tie the fp32 parity test cannot order)
+                     'CpnResNeXt101UNet_odd': dict(fourier_std=1.),
                      'CpnResNet50UNet': dict(fourier_std=.6),
                      'CpnU22_strided': dict(score_shift=0., fourier_std=.12, location_std=.3),
                      'CpnU22_odd': dict(score_shift=-1.5, fourier_std=.25, location_std=.4),
