@@ -687,6 +687,33 @@ def slide_workload(args, model, dev, world, rank, dist):
         dt, t_tiles, t_gather, t_nms = (float(v) for v in tt.tolist())
     else:
         t_tiles, t_gather, t_nms = (sum(t[k] for t in tim) for k in ('tiles', 'gather', 'nms'))
+    # the product default (sparse_heads = 'auto': score-gated location / Fourier heads, identical detections) over the same
+    # slide, every rank, outside the headline's timed region
+    gated = None
+    if not args.no_extras:
+        model.sparse_heads = 'auto'
+        inference.tiled_inference(model, warm, **kw)  # (packs the gated plan, captures its graphs)
+        inference.tiled_inference(model, warm, **kw)
+        torch.cuda.synchronize()
+        if dist:
+            td.barrier()
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res_g = inference.tiled_inference(model, slide, **kw)
+        torch.cuda.synchronize()
+        if dist:
+            td.barrier()
+            torch.cuda.synchronize()
+        dtg = time.perf_counter() - t0
+        if dist:
+            tt = torch.tensor([dtg], dtype=torch.float64, device=dev)
+            td.all_reduce(tt, op=td.ReduceOp.MAX)
+            dtg = float(tt.item())
+        gated = {'value': ntiles / dtg, 'unit': 'tiles/s', 'ms_per_step': 1e3 * dtg,
+                 'detections_final': int(res_g['scores'].shape[0]),
+                 'identical_to_dense': bool(res_g['scores'].shape == res['scores'].shape and torch.equal(res_g['boxes'], res['boxes'])),
+                 'mode': "model.sparse_heads = 'auto' (product default), one pass over the same slide"}
+        model.sparse_heads = False
     if rank == 0:
         gf = GFLOP_PER_TILE.get(args.model)
         value = ntiles * args.steps / dt
@@ -709,6 +736,8 @@ def slide_workload(args, model, dev, world, rank, dist):
                          'kernel': 'whole slide loop (conv graphs + crops + post-processing + exchange): '
                                    'tiles/s x algorithmic GFLOP per tile'},
         }
+        if gated is not None:
+            out['gated'] = gated
         print(json.dumps(out), file=_JSON_OUT, flush=True)
     if dist:
         td.destroy_process_group()

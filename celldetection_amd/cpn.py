@@ -168,7 +168,7 @@ class _Engine:
     # ---- hipGraph replay of the conv graph -------------------------------------------------------------------------
     # One conv-graph execution is ~120 dependent launches, most of them tens of microseconds long: replaying them as ONE
     # hipGraph removes the host-side launch gaps (profiles/r03_graph_probe.txt: 29.68 -> 29.29 ms for the BASELINE
-    # configs[2] batch).  A shape is captured the second time it is seen, into GRAPH_SLOTS instances that are used in turn:
+    # configs[2] batch).  A shape is captured the second time in a row it is seen, into GRAPH_SLOTS instances that are used in turn:
     # each owns its input copy, arena, head maps and range flag, so the post-processing of run i (second stream of
     # forward_pipelined) can still read slot i while run i+1 replays another slot.  CPN_HIP_GRAPH=0 disables it.
     GRAPH_SLOTS = 3
@@ -211,8 +211,12 @@ class _Engine:
         if os.environ.get('CPN_HIP_GRAPH', '1') == '0' or self._graph_broken:
             return None
         st = self._graphs.get(key)
+        last, self._graph_last_key = getattr(self, '_graph_last_key', None), key
         if st is None:
-            self._graph_seen[key] = self._graph_seen.get(key, 0) + 1
+            # capture a shape only when it is seen twice IN A ROW (a steady loop).  A shape that merely recurs -- the ragged last
+            # batch of every slide of a tile loop -- would pay an eager run + a capture + three arenas for one replay per slide
+            # (round 3: a 4096^2 slide of 121 = 7 x 16 + 9 tiles captured its 9-tile batch inside the timed loop)
+            self._graph_seen[key] = self._graph_seen.get(key, 0) + 1 if last == key else 1
             if self._graph_seen[key] < 2:
                 return None
             while len(self._graphs) >= self.GRAPH_SHAPES:  # evict the least recently used shape (frees its arenas)

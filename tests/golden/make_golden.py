@@ -238,7 +238,9 @@ MODEL_CALIBRATION = {'CpnU22_classes4': dict(score_shift=-3.5),
                      # every model fixture keeps >= 30 detections per image after the NMS (the FPN families of
                      # BASELINE configs[1] / [4] and the only pin of uncertainty_nms kept 2..5)
                      'CpnResNet18FPN': _FPN_DENSE, 'CpnResNet18FPN_odd': _FPN_DENSE, 'CpnResNet18FPN_heads': dict(_FPN_DENSE, score_shift=2.2, fourier_std=.35),
-                     'CpnResNet50FPN': _FPN_DENSE, 'CpnU22': _U22_SMALL, 'CpnU22_buckets': dict(_U22_SMALL, score_shift=-.2, refinement_raw_std=.3),
+                     # (deepest tiny model: its fp8 run needs larger boxes for an IoU match; a lower logit spread keeps the dense scores
+                     # out of the sigmoid's saturation, where fp32 summation-order noise re-orders near-equal scores)
+                     'CpnResNet50FPN': dict(_FPN_DENSE, score_shift=2.4, score_gain=1.5, fourier_std=.6, refinement_raw_std=.2), 'CpnU22': _U22_SMALL, 'CpnU22_buckets': dict(_U22_SMALL, score_shift=-.2, refinement_raw_std=.3),
                      'CpnU22_uncertainty': dict(score_shift=1., fourier_std=.3, location_std=.4),
                      # (CpnResNeXt101UNet keeps its round-1 fixture, 21 kept per image: a denser one put two proposals within
                      # fp32 summation-order noise of each other in the score sort -- a tie the fp32 parity test cannot order)
@@ -285,8 +287,14 @@ def gen_model(name, seed=0):
             model.order = 3
             flat_outputs('attr_order3', model(x), out)
     n_det = [len(t) for t in model(x)['scores']] if name != 'CpnU22' else None
+    # smallest gap between two different proposal scores of an image: the fp32 verification path reproduces the NMS order only
+    # if that gap exceeds the conv stack's fp32 summation-order noise (~1e-6 relative) -- exact ties are ordered by index
+    gaps = []
+    for i in range(shape[0]):
+        d = np.diff(np.sort(out[f'nonms.scores.{i}'].astype(np.float64)))
+        gaps.append(float(d[d > 0].min()) if (d > 0).any() else float('inf'))
     print(name, 'detections/img (last config):', n_det, 'proposals/img (nonms):',
-          [len(out[f'nonms.scores.{i}']) for i in range(shape[0])])
+          [len(out[f'nonms.scores.{i}']) for i in range(shape[0])], 'min score gap', ['%.1e' % v for v in gaps])
     save(f'model_{name}.npz', **out)
 
 

@@ -246,9 +246,12 @@ def test_fp32_path_end_to_end_parity(dev, name):
     n = x.shape[0]
     # index sets equal; refined contours / boxes / scores within 1e-4; the raw (un-rounded, x2..x4 up-scaled)
     # regression outputs carry the conv stack's fp32 summation-order noise: 5e-4 px on coordinates of O(100) px
-    check_exact('nms', model(x), g, n, raw_atol=5e-4)
-    check_exact('nonms', model(x, nms=False), g, n, raw_atol=5e-4)
-    check_exact('offs', model(x, offsets=torch.as_tensor(g['offsets'])), g, n, raw_atol=5e-4)
+    # (flip_frac: the thick fixtures hold 100-400 proposals x 32 samples x 4 refinement iterations -- a handful of coordinates
+    # sit within fp32 summation-order noise of x.5, where local_refinement's pixel snap is discontinuous: measured 2 of 12480
+    # on CpnResNet50FPN; same allowance as the other whole-forward fp32 tests below)
+    check_exact('nms', model(x), g, n, raw_atol=5e-4, flip_frac=1e-3)
+    check_exact('nonms', model(x, nms=False), g, n, raw_atol=5e-4, flip_frac=1e-3)
+    check_exact('offs', model(x, offsets=torch.as_tensor(g['offsets'])), g, n, raw_atol=5e-4, flip_frac=1e-3)
 
 
 def test_tile_loops_without_refinement_take_one_offset_back(dev):
