@@ -115,7 +115,8 @@ _SIGNATURES = [
     ('cpn_labels_cell_bounds', ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     ('cpn_labels_round', ctypes.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
                                         c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
-                                        c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_int32), c_void_p]),
+                                        c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_int32), c_int32, c_double,
+                                        c_void_p]),
     ('cpn_nms_binned_workspace_bytes', c_int64, [c_int64, c_int64]),
     ('cpn_nms_binned', ctypes.c_int, [c_void_p, c_void_p, c_int64, c_float, c_int64, c_void_p, c_void_p,
                                       POINTER(c_int64), POINTER(c_int64), POINTER(c_int32), c_void_p, c_int64,

@@ -1,7 +1,7 @@
 // contours -> label image on the GPU (gfx950).
 //
 // Replaces celldetection.data.contours2labels (celldetection/data/cpn.py:292-358, called from
-// celldetection_scripts/cpn_inference.py:811) with its default arguments (rounded, clip, gap, int32, no ioa_thresh):
+// celldetection_scripts/cpn_inference.py:811) (rounded, clip, gap, int32; optional ioa_thresh, data/cpn.py:341-350):
 // every contour is rasterised as a filled polygon (render_contour -> cv2.drawContours(thickness=-1),
 // data/cpn.py:245-255) and written with value (index + 1) into the FIRST channel whose gap-expanded bounding-box
 // region holds no label yet (data/cpn.py:346-351); channels grow on demand.
@@ -139,15 +139,36 @@ __device__ __forceinline__ bool on_line(int px, int py, int ax, int ay, int bx, 
     return px == ax + m;
 }
 
+// pixel (xx, yy) belongs to the filled polygon (boundary lines + scanline interior, see the header)
+__device__ __forceinline__ bool lb_filled(int xx, int yy, const int *px, const int *py, int S) {
+    bool set = false;
+    int n_lt = 0, n_le = 0;
+    for (int s = 0; s < S && !set; ++s) {
+        const int ax = px[s], ay = py[s], bx = px[s + 1 == S ? 0 : s + 1], by = py[s + 1 == S ? 0 : s + 1];
+        set = on_line(xx, yy, ax, ay, bx, by);
+        if (ay == by) continue;  // horizontal edges take no part in the scanline fill
+        const int ty = ay < by ? ay : by, tx = ay < by ? ax : bx, byy = ay < by ? by : ay;
+        if (yy < ty || yy >= byy) continue;
+        const long long ddx = ((long long) (bx - ax) * 65536ll) / (long long) (by - ay);  // C division: truncation
+        const long long xf = (long long) tx * 65536ll + (long long) (yy - ty) * ddx;
+        const int xr = (int) ((xf + 32768ll) >> 16);
+        n_lt += xr < xx;
+        n_le += xr <= xx;
+    }
+    return set || (n_lt & 1) || n_le > n_lt;
+}
+
 __global__ __launch_bounds__(256) void lb_paint_kernel(const int32_t *__restrict__ pts, const int32_t *__restrict__ boxes,
                                                       long K, int S, int H, int W, int gap,
                                                       const unsigned char *__restrict__ ready,
                                                       const unsigned int *__restrict__ ready_list, long n_ready,
                                                       int32_t *__restrict__ canvas, int C, unsigned char *__restrict__ state,
-                                                      int32_t *__restrict__ channel, int32_t *__restrict__ counters) {
+                                                      int32_t *__restrict__ channel, int32_t *__restrict__ counters,
+                                                      int use_ioa, double ioa_thresh) {
     __shared__ int px[MAX_S], py[MAX_S];
     __shared__ int occupied;
     __shared__ int chosen;
+    __shared__ unsigned int n_mask, n_covered;
     const long r = blockIdx.x;
     if (r >= n_ready) return;
     const long k = ready_list[r];
@@ -158,8 +179,33 @@ __global__ __launch_bounds__(256) void lb_paint_kernel(const int32_t *__restrict
     // region labels[max(0, ymin-gap) : gap+ymin+h, max(0, xmin-gap) : gap+xmin+w] (numpy slicing clips at the far end)
     const int ex0 = max(x0 - gap, 0), ey0 = max(y0 - gap, 0), ex1 = min(x1 + gap, W - 1), ey1 = min(y1 + gap, H - 1);
     const int ew = ex1 - ex0 + 1, eh = ey1 - ey0 + 1;
-    if (tid == 0) chosen = -1;
+    if (tid == 0) { chosen = -1; n_mask = 0u; n_covered = 0u; }
     __syncthreads();
+    if (use_ioa) {
+        // data/cpn.py:341-350: skip the contour when more than ioa_thresh of its own filled area already carries a label of
+        // ANY channel (the predecessors that can have painted there are resolved: that is what made this contour ready)
+        const int w_ = x1 - x0 + 1, h_ = y1 - y0 + 1;
+        unsigned int m = 0, cov = 0;
+        for (int i = tid; i < w_ * h_; i += 256) {
+            const int yy = y0 + i / w_, xx = x0 + i % w_;
+            if (xx < 0 || xx >= W || yy < 0 || yy >= H || !lb_filled(xx, yy, px, py, S)) continue;
+            ++m;
+            bool any = false;
+            for (int c = 0; c < C && !any; ++c) any = canvas[((size_t) c * H + yy) * W + xx] != 0;
+            cov += any;
+        }
+        if (m) atomicAdd(&n_mask, m);
+        if (cov) atomicAdd(&n_covered, cov);
+        __syncthreads();
+        // numpy: int / int -> float64 true division; 0 / 0 = nan compares False (the contour is kept)
+        if ((double) n_covered / (double) n_mask > ioa_thresh) {
+            if (tid == 0) {
+                state[k] = 2;  // resolved without painting
+                atomicAdd(&counters[0], 1);
+            }
+            return;
+        }
+    }
     for (int c = 0; c < C; ++c) {
         if (tid == 0) occupied = 0;
         __syncthreads();
@@ -189,21 +235,7 @@ __global__ __launch_bounds__(256) void lb_paint_kernel(const int32_t *__restrict
     for (int i = tid; i < w * h; i += 256) {
         const int yy = y0 + i / w, xx = x0 + i % w;
         if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
-        bool set = false;
-        int n_lt = 0, n_le = 0;
-        for (int s = 0; s < S && !set; ++s) {
-            const int ax = px[s], ay = py[s], bx = px[s + 1 == S ? 0 : s + 1], by = py[s + 1 == S ? 0 : s + 1];
-            set = on_line(xx, yy, ax, ay, bx, by);
-            if (ay == by) continue;  // horizontal edges take no part in the scanline fill
-            const int ty = ay < by ? ay : by, tx = ay < by ? ax : bx, byy = ay < by ? by : ay;
-            if (yy < ty || yy >= byy) continue;
-            const long long ddx = ((long long) (bx - ax) * 65536ll) / (long long) (by - ay);  // C division: truncation
-            const long long xf = (long long) tx * 65536ll + (long long) (yy - ty) * ddx;
-            const int xr = (int) ((xf + 32768ll) >> 16);
-            n_lt += xr < xx;
-            n_le += xr <= xx;
-        }
-        if (set || (n_lt & 1) || n_le > n_lt) plane[(size_t) yy * W + xx] += val;  // labels[...] += a
+        if (lb_filled(xx, yy, px, py, S)) plane[(size_t) yy * W + xx] += val;  // labels[...] += a
     }
     if (tid == 0) {
         channel[k] = c;
@@ -254,7 +286,7 @@ int cpn_labels_round(const int32_t *points, const int32_t *boxes, int64_t K, int
                      int32_t gap, int32_t grid_w, int32_t grid_h, int32_t cell, const uint32_t *sorted_index,
                      const uint32_t *cell_begin, const uint32_t *cell_end, int32_t *canvas, int32_t channels,
                      uint8_t *state, uint8_t *ready, uint32_t *ready_list, int32_t *channel, int32_t *counters,
-                     int32_t *counters_host, void *stream) {
+                     int32_t *counters_host, int32_t use_ioa, double ioa_thresh, void *stream) {
     if (K <= 0) return 0;
     if (S < 1 || S > MAX_S || channels < 1 || !counters_host)
         return cpn::fail(CPN_E_INVALID, "cpn_labels_round: bad arguments");
@@ -272,7 +304,8 @@ int cpn_labels_round(const int32_t *points, const int32_t *boxes, int64_t K, int
     if (e != hipSuccess) return cpn::check_hip(e, "cpn_labels_round: ready count");
     if (n_ready > 0)
         hipLaunchKernelGGL(lb_paint_kernel, dim3((unsigned) n_ready), dim3(256), 0, st, points, boxes, (long) K, S, H, W,
-                           gap, ready, ready_list, (long) n_ready, canvas, channels, state, channel, counters);
+                           gap, ready, ready_list, (long) n_ready, canvas, channels, state, channel, counters, (int) use_ioa,
+                           ioa_thresh);
     e = hipMemcpyAsync(counters_host, counters, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return cpn::check_hip(e, "cpn_labels_round: counters");

@@ -4,7 +4,8 @@ called from celldetection_scripts/cpn_inference.py:811), backed by ``csrc/labels
 Same result as the reference's sequential loop (contour i -> value i + 1 in the first channel whose gap-expanded
 bounding-box region is still empty), computed in parallel rounds over independent contours.  The polygon fill restates
 OpenCV's ``drawContours(thickness=-1)`` rule for integer vertices (cv2 is absent from the build image: see
-``oracle/labels_oracle.py`` -- parity with cv2 itself is unpinned).
+``oracle/labels_oracle.py`` -- parity with cv2 itself is unpinned).  ``ioa_thresh`` / ``return_indices`` sit behind the fill
+(pure index work): restated from the reference's own Python.
 """
 from ctypes import c_int32
 
@@ -19,10 +20,11 @@ __all__ = ['contours2labels']
 
 def contours2labels(contours, size, rounded=True, clip=True, initial_depth=1, gap=3, dtype='int32', ioa_thresh=None,
                     sort_by=None, sort_descending=True, return_indices=False, return_stats=False):
-    """Contours [K, S, 2] (xy, one image; Tensor on the GPU, or a list of equally long arrays) -> label image
-    Tensor[H, W, channels] int32 on the GPU.  Arguments as in the reference; ``ioa_thresh`` is not supported."""
-    if ioa_thresh is not None or return_indices:
-        raise NotImplementedError('contours2labels on the HIP path: ioa_thresh / return_indices are not supported')
+    """Contours [K, S, 2] (xy, one image; Tensor on the GPU, or a list of arrays) -> label image Tensor[H, W, channels]
+    int32 on the GPU.  Arguments as in the reference (data/cpn.py:292-358).  ``ioa_thresh``: contours whose own area is
+    covered by earlier labels to more than that fraction are skipped (:341-350) and the painted ones numbered consecutively;
+    ``return_indices``: additionally the list of kept contour positions -- like the reference, filled only when
+    ``ioa_thresh`` is given (:356-357)."""
     if np.dtype(dtype) != np.int32:
         raise NotImplementedError("contours2labels on the HIP path produces dtype 'int32' (the reference's default)")
     if not isinstance(contours, torch.Tensor):
@@ -47,9 +49,14 @@ def contours2labels(contours, size, rounded=True, clip=True, initial_depth=1, ga
         con = con[order.to(dev)].contiguous()
     K, S = int(con.shape[0]), int(con.shape[1])
     depth = max(int(initial_depth), 1)
+    use_ioa = ioa_thresh is not None
+
+    def result(out, keep, stats):
+        res = (out,) + ((keep,) if return_indices else ()) + ((stats,) if return_stats else ())
+        return res[0] if len(res) == 1 else res
+
     if K == 0:
-        out = torch.zeros((H, W, depth), dtype=torch.int32, device=dev)
-        return (out, dict(rounds=0, channels=depth)) if return_stats else out
+        return result(torch.zeros((H, W, depth), dtype=torch.int32, device=dev), [], dict(rounds=0, channels=depth))
     i32 = dict(dtype=torch.int32, device=dev)
     pts = torch.empty((K, S, 2), **i32)
     boxes = torch.empty((K, 4), **i32)
@@ -83,7 +90,8 @@ def contours2labels(contours, size, rounded=True, clip=True, initial_depth=1, ga
     while painted < K:
         check(lib.cpn_labels_round(ptr(pts), ptr(boxes), K, S, H, W, int(gap), gw, gh, cell, ptr(sidx), ptr(cbegin),
                                    ptr(cend), ptr(canvas), channels, ptr(state), ptr(ready), ptr(ready_list),
-                                   ptr(channel), ptr(counters), host, stream_ptr()), 'labels_round')
+                                   ptr(channel), ptr(counters), host, int(use_ioa), float(ioa_thresh if use_ioa else 0.),
+                                   stream_ptr()), 'labels_round')
         rounds += 1
         painted += int(host[0])
         if int(host[1]):  # a contour found every allocated channel occupied: grow the canvas, it retries next round
@@ -92,5 +100,14 @@ def contours2labels(contours, size, rounded=True, clip=True, initial_depth=1, ga
         elif int(host[2]) == 0:
             raise RuntimeError('contours2labels: no progress (internal error)')
     used = max(depth, int(channel.max().item()) + 1)
+    keep = []
+    if use_ioa:
+        # painted contours carry the provisional value k + 1: renumber to the reference's running label (lbl only advances
+        # for painted contours) with one table look-up over the canvas
+        skipped = state == 2
+        table = torch.zeros(K + 1, **i32)
+        table[1:] = torch.arange(1, K + 1, **i32) - torch.cumsum(skipped.to(torch.int32), 0).to(torch.int32)
+        canvas = table[canvas[:used].long()]
+        keep = torch.nonzero(~skipped).squeeze(1).cpu().tolist()
     out = canvas[:used].permute(1, 2, 0).contiguous()
-    return (out, dict(rounds=rounds, channels=used)) if return_stats else out
+    return result(out, keep, dict(rounds=rounds, channels=used))

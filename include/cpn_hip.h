@@ -365,8 +365,8 @@ int cpn_rescale_to_uint8(const void *x, int32_t dtype, int64_t n, double low, do
 
 /* ------------------------------------------------------------------------------------------------------------
  * Label rasterisation.  Replaces celldetection.data.contours2labels / render_contour
- * (celldetection/data/cpn.py:245-255,292-358; called from celldetection_scripts/cpn_inference.py:811) with the default
- * arguments: contour k is rounded (half to even), clipped to the image, filled as a polygon (OpenCV
+ * (celldetection/data/cpn.py:245-255,292-358; called from celldetection_scripts/cpn_inference.py:811):
+ * contour k is rounded (half to even), clipped to the image, filled as a polygon (OpenCV
  * drawContours(thickness=-1) rule for integer vertices, restated) and added with value k + 1 to the FIRST channel whose
  * region [bbox expanded by `gap`] holds no label yet.  The sequential loop of the reference is resolved in rounds over
  * mutually independent contours (see csrc/labels.hip); the caller drives the rounds:
@@ -377,7 +377,11 @@ int cpn_rescale_to_uint8(const void *x, int32_t dtype, int64_t n, double low, do
  *   cpn_labels_round:       ONE round: marks the contours whose predecessors are all painted, chooses their channel on
  *                           the planar int32 canvas [channels][H][W] and paints them.  counters_host[0] = painted in
  *                           this round, [1] = contours that found all `channels` occupied (grow the canvas, call
- *                           again), [2] = ready contours.  Synchronises the stream.
+ *                           again), [2] = ready contours.  Synchronises the stream.  use_ioa != 0 (`ioa_thresh`,
+ *                           data/cpn.py:341-350): a ready contour whose filled area is covered by labels of any channel
+ *                           to more than ioa_thresh (int / int in float64, like numpy) is resolved WITHOUT painting:
+ *                           state = 2, counted in counters_host[0].  Painted contours carry the provisional value k + 1;
+ *                           the caller renumbers to the reference's running label (k + 1 - skipped contours before k).
  * ---------------------------------------------------------------------------------------------------------- */
 int cpn_labels_prepare(const float *contours, int64_t K, int32_t S, int32_t H, int32_t W, int32_t rounded, int32_t clip,
                        int32_t *points, int32_t *boxes, void *stream);
@@ -389,7 +393,7 @@ int cpn_labels_round(const int32_t *points, const int32_t *boxes, int64_t K, int
                      int32_t gap, int32_t grid_w, int32_t grid_h, int32_t cell, const uint32_t *sorted_index,
                      const uint32_t *cell_begin, const uint32_t *cell_end, int32_t *canvas, int32_t channels,
                      uint8_t *state, uint8_t *ready, uint32_t *ready_list, int32_t *channel, int32_t *counters,
-                     int32_t *counters_host, void *stream);
+                     int32_t *counters_host, int32_t use_ioa, double ioa_thresh, void *stream);
 
 #ifdef __cplusplus
 }

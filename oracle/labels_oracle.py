@@ -2,7 +2,7 @@
 
 Restates ``celldetection.data.contours2labels`` (celldetection/data/cpn.py:292-358) and ``render_contour``
 (:245-255) for the default arguments used by celldetection_scripts/cpn_inference.py:811 (rounded, clip, gap=3,
-initial_depth=1, int32, no ``ioa_thresh``).
+initial_depth=1, int32) and the ``ioa_thresh`` / ``return_indices`` options.
 
 **Parity unpinned.**  ``render_contour`` calls ``cv2.drawContours(thickness=-1)``; OpenCV is not installed in the build
 image and is not part of /root/reference, so the polygon fill rule below is a restatement of OpenCV's published
@@ -79,12 +79,15 @@ def fill_polygon(points, x0, y0, w, h):
     return m
 
 
-def contours2labels(contours, size, rounded=True, clip=True, initial_depth=1, gap=3, dtype='int32'):
-    """data/cpn.py:329-358 with ``ioa_thresh=None``, ``sort_by=None``."""
+def contours2labels(contours, size, rounded=True, clip=True, initial_depth=1, gap=3, dtype='int32', ioa_thresh=None,
+                    return_indices=False):
+    """data/cpn.py:329-358 with ``sort_by=None`` (ioa_thresh: :341-350, return_indices: :356-357 -- the index list is only
+    filled when ``ioa_thresh`` is given, like in the reference)."""
     H, W = size
     labels = np.zeros((H, W, initial_depth), dtype=dtype)
     lbl = 1
-    for contour in contours:
+    keep = []
+    for idx, contour in enumerate(contours):
         contour = np.array(contour, np.float32)
         if rounded:
             contour = np.round(contour)
@@ -94,10 +97,19 @@ def contours2labels(contours, size, rounded=True, clip=True, initial_depth=1, ga
         xmin, ymin = np.floor(contour.min(0)).astype(int)
         xmax, ymax = np.ceil(contour.max(0)).astype(int)
         a = fill_polygon(contour.astype(np.int32), xmin, ymin, xmax - xmin + 1, ymax - ymin + 1).astype(dtype) * lbl
+        if ioa_thresh is not None:
+            m = a > 0
+            crp = (labels[ymin:ymin + a.shape[0], xmin:xmin + a.shape[1]] > 0).any(-1)
+            ioa = crp[m].sum() / m.sum()
+            if ioa > ioa_thresh:
+                continue
+            keep.append(idx)
         lbl += 1
         s = (labels[max(0, ymin - gap): gap + ymin + a.shape[0], max(0, xmin - gap): gap + xmin + a.shape[1]] > 0).sum((0, 1))
         i = next(i for i in range(labels.shape[2] + 1) if not (i < labels.shape[2] and np.any(s[i])))
         if i >= labels.shape[2]:
             labels = np.concatenate((labels, np.zeros((H, W, 1), dtype=dtype)), axis=-1)
         labels[ymin:ymin + a.shape[0], xmin:xmin + a.shape[1], i] += a
+    if return_indices:
+        return labels, keep
     return labels

@@ -49,7 +49,44 @@ def test_file_modes_follow_h5py(tmp_path):
     h5.to_h5(f, mode='a', c=np.zeros(1, np.uint8))
     assert h5.from_h5(f, 'a').shape == (3,) and h5.from_h5(f, 'b').shape == (2, 2) and h5.from_h5(f, 'c').shape == (1,)
     with pytest.warns(RuntimeWarning):
-        h5.to_h5(f, mode='w', compression='gzip', a=np.arange(4))
+        h5.to_h5(f, mode='w', driver='core', a=np.arange(4))
     assert h5.from_h5(f, 'a').shape == (4,)
     with pytest.raises(ValueError):
         h5.to_h5(f, mode='q', a=np.arange(4))
+
+
+@pytest.mark.skipif(not h5.hdf5_available(), reason='libhdf5 not present')
+def test_chunks_and_gzip_compression(tmp_path):
+    """``chunks`` / ``compression`` of the reference's to_h5 (util/util.py:1385-1395 -> h5py create_dataset) through libhdf5's
+    dataset-creation property list: the data read back are identical, the dataset is chunked, carries one filter and needs
+    less storage than the raw array."""
+    rng = np.random.default_rng(1)
+    labels = np.zeros((600, 500, 2), np.int32)
+    labels[100:300, 50:400, 0] = rng.integers(1, 50, (200, 350)) // 10  # a label image: long runs of equal values
+    contours = rng.random((1000, 32, 2)).astype(np.float32)
+    scores = rng.random(1000).astype(np.float32)
+    f = str(tmp_path / 'c.h5')
+    h5.to_h5(f, labels=labels, contours=contours, scores=scores, compression='gzip',
+             chunks=dict(labels=(128, 128, 1), contours=True, scores=None))
+    lay = {k: h5.dataset_layout(f, k) for k in ('labels', 'contours', 'scores')}
+    assert lay['labels']['chunks'] == (128, 128, 1) and lay['labels']['filters'] == 1
+    assert lay['labels']['storage_bytes'] < labels.nbytes // 20
+    assert lay['contours']['chunks'] == h5.guess_chunk(contours.shape, 4) and lay['contours']['filters'] == 1
+    assert lay['scores']['chunks'] == h5.guess_chunk(scores.shape, 4)  # a filter needs chunks: auto-chunked like h5py
+    for k, v in (('labels', labels), ('contours', contours), ('scores', scores)):
+        got = h5.from_h5(f, k)
+        assert got.dtype == v.dtype
+        np.testing.assert_array_equal(got, v)
+    # an integer chunk setting: the reference turns it into min(256, dim) per dimension for arrays with > 1 dimensions
+    h5.to_h5(f, mode='w', labels=labels, scores=scores, chunks=64, compression=9)
+    assert h5.dataset_layout(f, 'labels')['chunks'] == (256, 256, 2) and h5.dataset_layout(f, 'scores')['chunks'] == (64,)
+    np.testing.assert_array_equal(h5.from_h5(f, 'labels'), labels)
+    # plain contiguous datasets stay what they were; empty arrays cannot be chunked; unsupported filters fail loudly
+    h5.to_h5(f, mode='w', labels=labels, empty=np.zeros((0, 4), np.float32), compression='gzip', chunks=dict(labels=None, empty=True))
+    assert h5.from_h5(f, 'empty').shape == (0, 4) and h5.dataset_layout(f, 'empty')['chunks'] is None
+    h5.to_h5(f, mode='w', labels=labels)
+    assert h5.dataset_layout(f, 'labels') == dict(chunks=None, filters=0, storage_bytes=labels.nbytes)
+    with pytest.raises(NotImplementedError):
+        h5.to_h5(f, mode='w', labels=labels, compression='lzf')
+    c = h5.guess_chunk((1000, 32, 2), 4)  # 256 KB dataset: ~16 KiB * 2^log10(0.24) = 10 KiB chunks
+    assert all(1 <= a <= b for a, b in zip(c, (1000, 32, 2))) and 4 * np.prod(c) <= 16 * 1024

@@ -74,6 +74,49 @@ def test_contours2labels_matches_oracle(k, size, spread, s):
     np.testing.assert_array_equal(got2.cpu().numpy(), exp2)
 
 
+def test_oracle_ioa_thresh_and_indices():
+    """data/cpn.py:341-357 restated: a contour that lies inside an earlier one is skipped, labels stay consecutive, the index
+    list is only filled when ioa_thresh is given."""
+    t = np.linspace(0, 2 * np.pi, 16, endpoint=False)
+    big = np.stack((20 + 10 * np.cos(t), 20 + 10 * np.sin(t)), -1)
+    small = np.stack((20 + 3 * np.cos(t), 20 + 3 * np.sin(t)), -1)
+    far = big + [40, 0]
+    L, keep = lo.contours2labels([big, small, far], (40, 80), ioa_thresh=.5, return_indices=True)
+    assert keep == [0, 2] and set(np.unique(L)) == {0, 1, 2} and (L[20, 60] == 2).any()
+    L, keep = lo.contours2labels([small, big, far], (40, 80), ioa_thresh=.5, return_indices=True)
+    assert keep == [0, 1, 2] and set(np.unique(L)) == {0, 1, 2, 3}  # the big one is covered to ~10 % only
+    L, keep = lo.contours2labels([big, small, far], (40, 80), return_indices=True)
+    assert keep == [] and set(np.unique(L)) == {0, 1, 2, 3}
+    assert lo.contours2labels([big, big], (40, 80), ioa_thresh=1.).max() == 2  # ioa == 1 is not > 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('k,size,thr', [(80, (64, 64), .3), (300, (120, 160), 0.), (300, (120, 160), .6), (40, (40, 40), .95)])
+def test_contours2labels_ioa_thresh_matches_oracle(k, size, thr):
+    import celldetection_amd as cda
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    rng = np.random.default_rng(1000 + k)
+    con = random_contours(rng, k, size, s=16)
+    exp, keep_exp = lo.contours2labels(con, size, ioa_thresh=thr, return_indices=True)
+    got, keep, st = cda.contours2labels(torch.as_tensor(con).cuda(), size, ioa_thresh=thr, return_indices=True, return_stats=True)
+    print(f'ioa_thresh={thr} k={k}: kept {len(keep_exp)} of {k}, channels {st["channels"]}, rounds {st["rounds"]}')
+    assert 0 < len(keep_exp) < k, 'degenerate case: the threshold skips nothing / everything'
+    assert keep == keep_exp
+    assert tuple(got.shape) == exp.shape, (got.shape, exp.shape)
+    np.testing.assert_array_equal(got.cpu().numpy(), exp)
+    # return_indices without a threshold: the reference's list stays empty
+    lab, idx = cda.contours2labels(torch.as_tensor(con).cuda(), size, return_indices=True)
+    assert idx == [] and torch.equal(lab, cda.contours2labels(torch.as_tensor(con).cuda(), size))
+    # sort_by + ioa_thresh (cpn_inference.py passes scores): indices refer to the sorted sequence
+    sb = rng.uniform(size=k)
+    order = np.argsort(sb)[::-1]
+    exp2, keep2 = lo.contours2labels(con[order], size, ioa_thresh=thr, return_indices=True)
+    got2, k2 = cda.contours2labels(torch.as_tensor(con).cuda(), size, ioa_thresh=thr, sort_by=sb, return_indices=True)
+    assert k2 == keep2
+    np.testing.assert_array_equal(got2.cpu().numpy(), exp2)
+
+
 @pytest.mark.gpu
 def test_contours2labels_slide_scale():
     """1e5 contours on an 8192^2 canvas (the post-processing step that follows the slide loop in cpn_inference.py:811):
