@@ -106,38 +106,53 @@ int launch_maxpool_fp8(const PoolArgs &a, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// one workgroup per output row (n, oy): the vertical taps and weights are wave-uniform, a thread owns 16 channels (16 bytes)
+// of one output pixel -- 16-byte loads / stores and 32-bit index math (the round-1 kernel did 64-bit div / mod per 8 bytes
+// in a grid-stride loop and ran at 1.5 TB/s: 885 us for the 4 x 1024^2 x 256 map in front of the FPN refinement head)
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+__device__ __forceinline__ void decode4(unsigned r, float (&v)[4]) {
+    v[0] = __builtin_amdgcn_cvt_f32_fp8((int) r, 0); v[1] = __builtin_amdgcn_cvt_f32_fp8((int) r, 1);
+    v[2] = __builtin_amdgcn_cvt_f32_fp8((int) r, 2); v[3] = __builtin_amdgcn_cvt_f32_fp8((int) r, 3);
+}
 __global__ __launch_bounds__(256) void bilinear_fp8_kernel(const ResizeArgs a) {
-    const int groups = a.C >> 3;
-    const long total = (long) a.N * a.Hout * a.Wout * groups;
+    const int n = (int) (blockIdx.x / (unsigned) a.Hout), oy = (int) (blockIdx.x % (unsigned) a.Hout);
     const float sy = (float) a.Hin / (float) a.Hout, sx = (float) a.Win / (float) a.Wout;
-    for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < total; i += (long) gridDim.x * blockDim.x) {
-        const int gidx = (int) (i % groups);
-        long pix = i / groups;
-        const int ox = (int) (pix % a.Wout);
-        pix /= a.Wout;
-        const int oy = (int) (pix % a.Hout);
-        const int n = (int) (pix / a.Hout);
-        const float fy = fmaxf(sy * ((float) oy + 0.5f) - 0.5f, 0.f);
+    const float fy = fmaxf(sy * ((float) oy + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int) fy, y1 = y0 + (y0 < a.Hin - 1 ? 1 : 0);
+    const float ly = fy - (float) y0, hy = 1.f - ly;
+    const unsigned g16 = (unsigned) a.C >> 4;
+    const unsigned per_row = (unsigned) a.Wout * g16;
+    const unsigned char *r0 = (const unsigned char *) a.src + ((size_t) n * a.Hin + y0) * a.Win * (size_t) a.C;
+    const unsigned char *r1 = (const unsigned char *) a.src + ((size_t) n * a.Hin + y1) * a.Win * (size_t) a.C;
+    unsigned char *dr = (unsigned char *) a.dst + ((size_t) n * a.Hout + oy) * a.Wout * (size_t) a.C;
+    for (unsigned i = threadIdx.x; i < per_row; i += 256u) {
+        const unsigned ox = i / g16, c = (i - ox * g16) << 4;
         const float fx = fmaxf(sx * ((float) ox + 0.5f) - 0.5f, 0.f);
-        const int y0 = (int) fy, x0 = (int) fx;
-        const int y1 = y0 + (y0 < a.Hin - 1 ? 1 : 0), x1 = x0 + (x0 < a.Win - 1 ? 1 : 0);
-        const float ly = fy - (float) y0, lx = fx - (float) x0;
-        const float hy = 1.f - ly, hx = 1.f - lx;
-        const unsigned char *base = (const unsigned char *) a.src + (long) n * a.Hin * a.Win * a.C + gidx * 8;
-        float v00[8], v01[8], v10[8], v11[8], o[8];
-        decode8(*(const u32x2 *) (base + ((long) y0 * a.Win + x0) * a.C), v00);
-        decode8(*(const u32x2 *) (base + ((long) y0 * a.Win + x1) * a.C), v01);
-        decode8(*(const u32x2 *) (base + ((long) y1 * a.Win + x0) * a.C), v10);
-        decode8(*(const u32x2 *) (base + ((long) y1 * a.Win + x1) * a.C), v11);
+        const int x0 = (int) fx, x1 = x0 + (x0 < a.Win - 1 ? 1 : 0);
+        const float lx = fx - (float) x0, hx = 1.f - lx;
+        const u32x4 q00 = *(const u32x4 *) (r0 + (size_t) x0 * a.C + c), q01 = *(const u32x4 *) (r0 + (size_t) x1 * a.C + c);
+        const u32x4 q10 = *(const u32x4 *) (r1 + (size_t) x0 * a.C + c), q11 = *(const u32x4 *) (r1 + (size_t) x1 * a.C + c);
+        u32x4 out;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]);
-        *(u32x2 *) ((unsigned char *) a.dst + (((long) n * a.Hout + oy) * a.Wout + ox) * a.C + gidx * 8) = encode8(o);
+        for (int w = 0; w < 4; ++w) {
+            float v00[4], v01[4], v10[4], v11[4];
+            decode4(q00[w], v00); decode4(q01[w], v01); decode4(q10[w], v10); decode4(q11[w], v11);
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)  // (same expression as before: the rounding is unchanged)
+                o[e] = sat448(hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]));
+            int p = 0;
+            p = __builtin_amdgcn_cvt_pk_fp8_f32(o[0], o[1], p, false);
+            p = __builtin_amdgcn_cvt_pk_fp8_f32(o[2], o[3], p, true);
+            out[w] = (unsigned) p;
+        }
+        *(u32x4 *) (dr + (size_t) ox * a.C + c) = out;
     }
 }
 
 int launch_bilinear_fp8(const ResizeArgs &a, hipStream_t stream) {
-    const long total = (long) a.N * a.Hout * a.Wout * (a.C >> 3);
-    hipLaunchKernelGGL(bilinear_fp8_kernel, dim3(grid_for(total)), dim3(256), 0, stream, a);
+    if (a.C % 16 || a.N <= 0 || a.Hout <= 0 || a.Wout <= 0) return (int) hipErrorInvalidValue;
+    hipLaunchKernelGGL(bilinear_fp8_kernel, dim3((unsigned) a.N * (unsigned) a.Hout), dim3(256), 0, stream, a);
     return (int) hipGetLastError();
 }
 
