@@ -664,7 +664,12 @@ def slide_workload(args, model, dev, world, rank, dist):
     ntiles = len(list(util.get_tiling_slices((S, S), crop, stride)[0]))
     kw = dict(crop_size=crop, strides=stride, batch_size=args.batch)
     warm = slide[:, :min(S, 4 * args.tile), :min(S, 4 * args.tile)]
-    for _ in range(max(args.warmup, 1)):  # small slide: allocator / RCCL communicator / kernels warm
+    # warm-up: allocator / RCCL communicator / kernels / hipGraph slots.  A shape is captured when it is seen twice in a row
+    # (cpn._Engine._graph_slot), so the warm-up needs a slide with several full batches per rank (the small one only yields
+    # one full and one ragged batch: round 4 measured the three captures inside the first timed slide, 3 x 28 ms)
+    edge = min(S, args.tile + args.stride * (int((4 * args.batch * world) ** .5 + 1) - 1))
+    inference.tiled_inference(model, slide[:, :edge, :edge], **kw)
+    for _ in range(max(args.warmup, 1)):
         inference.tiled_inference(model, warm, **kw)
     torch.cuda.synchronize()
     if dist:
@@ -692,7 +697,7 @@ def slide_workload(args, model, dev, world, rank, dist):
     gated = None
     if not args.no_extras:
         model.sparse_heads = 'auto'
-        inference.tiled_inference(model, warm, **kw)  # (packs the gated plan, captures its graphs)
+        inference.tiled_inference(model, slide[:, :edge, :edge], **kw)  # (packs the gated plan, captures its graphs)
         inference.tiled_inference(model, warm, **kw)
         torch.cuda.synchronize()
         if dist:

@@ -243,6 +243,8 @@ def tiled_inference(model, img: torch.Tensor, crop_size=(1024, 1024), strides=(7
     pending = []  # (flat tensors of a batch, keep mask): rows are selected once, after the loop
     for flat, _ in results:
         idxs, offs, size = meta.pop(0)
+        if timings is not None:  # host time at which this batch's detections were handed over (no extra synchronisation)
+            timings.setdefault('batch_done_s', []).append(time.perf_counter() - t_start)
         samples, order = flat['contours'].shape[1], flat['fourier'].shape[1]
         if flat['scores'].shape[0] == 0:
             continue
