@@ -2,7 +2,7 @@
 # Round-end GPU pass (run on the MI355X box through gpurun, from the repo root):
 #   tools/gpu_round_pass.sh <tag> [tests] [bench] [profile] [sparse] [slide] [configs] [fp8]
 # writes everything under gpurun_out/ (the summaries that should be judged are then copied into profiles/).
-TAG=${1:-r03}; shift
+TAG=${1:-r04}; shift
 WHAT=${*:-tests bench profile}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
@@ -22,7 +22,7 @@ tests)
 bench)
   timeout 600 python bench.py --profile-layers > gpurun_out/${TAG}_bench_n1.json 2> gpurun_out/${TAG}_per_layer_timing.txt; cat gpurun_out/${TAG}_bench_n1.json | cut -c1-400;;
 profile)
-  (timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -o b -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline) > $P/trace.log 2>&1
+  (timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -o b -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras) > $P/trace.log 2>&1
   (timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $P/gtrace -o b -- python tools/run_graph_only.py 5) > $P/gtrace.log 2>&1
   pmc_traffic main CpnResNeXt101UNet/b16/t512/bf16
   (timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VALU SQ_WAIT_ANY --output-format csv -d $P/mfma -o b -- python tools/run_graph_only.py 5) > $P/mfma.log 2>&1
