@@ -7,9 +7,10 @@
 // Why this shape (MI355X-first, not a translation of anything):
 //   * a grouped conv needs, for an output channel, only the Cmid / 32 input channels of its own group -- so a workgroup that
 //     owns a SLAB of SL conv1 output channels (= whole groups) can run conv2 for those groups without any other slab;
-//     what it needs from conv1 is the slab on its output tile + a one-pixel halo.  Tiles are FULL-WIDTH ROW STRIPS of the
-//     image (W = 16 | 32 | 64 exactly): the left / right halo is the conv's zero padding, only the two halo ROWS are
-//     recomputed (10 rows for 8: 1.25 x conv1's MACs);
+//     what it needs from conv1 is the slab on its output tile + a one-pixel halo.  Images exactly 16 | 32 | 64 pixels wide are
+//     cut into FULL-WIDTH ROW STRIPS: the left / right halo is the conv's zero padding, only the two halo ROWS are recomputed
+//     (10 rows for 8: 1.25 x conv1's MACs); every other width takes GENERIC tiles of 16 x 32 output pixels with a real halo
+//     on all four sides (18 x 34 of 16 x 32: 1.2 x), 128-channel slabs;
 //   * stage 1 = conv1 as an implicit GEMM  D1[SL][halo px] += W1[SL][Cin] * X[Cin][halo px]  on v_mfma_f32_32x32x16_bf16:
 //     halo pixels flattened (a pixel fragment is ANY 32 consecutive pixels of the strip -- rows are contiguous in NHWC), wave
 //     tile 64 channels x 160 pixels (10 MFMAs per 7 fragment reads), operands staged by LDS-DMA through a 3-deep ring of
@@ -33,25 +34,30 @@ namespace {
 
 typedef bf16x8 frag_t;
 
+// WLOG > 0: full-width row strips of an image exactly 2^WLOG pixels wide.  WLOG == 0: GENERIC tiles of 16 x 32 output pixels
+// with a real one-pixel halo on all four sides (18 x 34 = 612 halo pixels, flattened with pitch 34) for any image size.
 template <int WLOG, int SL>
 struct PairCfg {
-    static constexpr int W = 1 << WLOG;                      // image width = row pitch of the strip
+    static constexpr bool GEN = WLOG == 0;
+    static constexpr int W = GEN ? 34 : (1 << WLOG);         // row pitch of the halo tile (strips: = image width)
     static constexpr int WC = SL / 64;                       // stage 1: waves along the channels (64 each)
     static constexpr int WP = 8 / WC;                        //          waves along the pixels (5 fragments each)
-    static constexpr int NF1 = 5 * WP;                       // pixel fragments of the halo strip
+    static constexpr int NF1 = 5 * WP;                       // pixel fragments of the halo tile
     static constexpr int NPXP = NF1 * 32;                    // pixels staged (incl. padding up to whole fragments)
-    static constexpr int ROWS = W == 16 ? 18 : NPXP / W;     // halo rows
+    static constexpr int ROWS = (GEN || W == 16) ? 18 : NPXP / W;  // halo rows
     static constexpr int NPX = ROWS * W;                     // real halo pixels
-    static constexpr int THO = ROWS - 2;                     // output rows per strip
-    static constexpr int OUTF = THO * W / 32;                // output fragments per strip
+    static constexpr int THO = ROWS - 2;                     // output rows per tile
+    static constexpr int TWO = GEN ? 32 : W;                 // output columns per tile
+    static constexpr int OUTF = THO * TWO / 32;              // output fragments per tile
     static constexpr int PQ = OUTF / 4;                      // stage 2: waves along the pixels (4 fragments each)
-    static constexpr int XBUF = NPXP * 64;                   // one 32-channel chunk of the strip
+    static constexpr int XBUF = NPXP * 64;                   // one 32-channel chunk of the tile
     static constexpr int WBUF = SL * 64;                     // one 32-channel chunk of the slab's weights
     static constexpr int XI = NPXP / 16;                     // 1-KiB DMA instructions per activation chunk
     static constexpr int XIW = (XI + 7) / 8;                 //   per wave (the last round may be partial)
     static constexpr int WIW = SL / 16 / 8;                  // weight DMA instructions per wave and chunk
     static constexpr int LDS = (SL / 32) * XBUF;             // the bf16 slab tile
     static_assert(SL == 128 || SL == 256, "slab");
+    static_assert(!GEN || SL == 128, "generic tiles: 128-channel slabs");
     static_assert(NPX <= NPXP && OUTF % 4 == 0 && (SL / 64) * PQ == 8, "eight stage-2 jobs");
     static_assert(LDS == 160 * 1024, "LDS budget");
 };
@@ -103,10 +109,28 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const PairArgs a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lhi = lane >> 5;
+    constexpr bool GEN = C::GEN;
+    const int Wimg = GEN ? a.W : W;   // image width (strips: a template constant)
     const int tiles_y = (a.H + C::THO - 1) / C::THO;
-    const int ty = blockIdx.x % tiles_y, n = blockIdx.x / tiles_y;
-    const int oy0 = ty * C::THO;      // first output row of the strip; halo row r is image row oy0 - 1 + r
+    const int tiles_x = GEN ? (a.W + C::TWO - 1) / C::TWO : 1;
+    const int tx = (int) (blockIdx.x % (unsigned) tiles_x), ty = (int) ((blockIdx.x / (unsigned) tiles_x) % (unsigned) tiles_y);
+    const int n = (int) (blockIdx.x / (unsigned) (tiles_x * tiles_y));
+    const int oy0 = ty * C::THO;      // first output row of the tile; halo row r is image row oy0 - 1 + r
+    const int ox0 = tx * C::TWO;      // generic tiles: halo column c is image column ox0 - 1 + c
     const int n0 = blockIdx.y * SL;   // first conv1 output channel of the slab
+    // halo pixel p of the flattened tile -> image coordinates; false outside the image (= conv2's zero padding)
+    auto halo_px = [&](int p, int &iy, int &ix) -> bool {
+        if constexpr (GEN) {
+            const int r = p / 34;
+            iy = oy0 - 1 + r;
+            ix = ox0 - 1 + (p - r * 34);
+            return p < C::NPX && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        } else {
+            iy = oy0 - 1 + (p >> WLOG);
+            ix = p & (W - 1);
+            return p < C::NPX && iy >= 0 && iy < a.H;
+        }
+    };
     const int nchunks = a.cin >> 5;
     const unsigned lds0 = (unsigned) (size_t) (lds_u8 *) smem;
 
@@ -116,16 +140,16 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const PairArgs a) {
     // activation DMA: instruction q covers halo pixels q*16 .. +15 (lane -> pixel q*16 + lane/4, 16-byte slot lane%4 which
     // holds channel part slot ^ ((pixel >> 2) & 3)); per-lane offsets are loop constants, the chunk travels in the scalar
     // offset.  Pixels of rows outside the image (and the padding behind the last real pixel) read zeros.
-    const rsrc_t rsx = make_rsrc(a.src, (unsigned) ((size_t) a.N * a.H * W * a.c_stride * 2));
+    const rsrc_t rsx = make_rsrc(a.src, (unsigned) ((size_t) a.N * a.H * Wimg * a.c_stride * 2));
     unsigned x_voff[C::XIW];
 #pragma unroll
     for (int it = 0; it < C::XIW; ++it) {
         const int q = wave + it * 8;
         const int p = q * 16 + (lane >> 2);
         const int part = (lane & 3) ^ ((p >> 2) & 3);
-        const int iy = oy0 - 1 + (p >> WLOG), ix = p & (W - 1);
-        const bool ok = p < C::NPX && iy >= 0 && iy < a.H;
-        x_voff[it] = ok ? (unsigned) ((((n * a.H + iy) * W + ix) * a.c_stride + part * 8) * 2) : OOB_LANE;
+        int iy, ix;
+        const bool ok = halo_px(p, iy, ix);
+        x_voff[it] = ok ? (unsigned) ((((n * a.H + iy) * Wimg + ix) * a.c_stride + part * 8) * 2) : OOB_LANE;
     }
     const bool x_extra = wave + (C::XIW - 1) * 8 < C::XI;  // (wave-uniform) this wave issues the last, partial round
     // weight DMA: instruction q covers rows q*16 .. +15 of the slab's chunk slab [SL][32] (same swizzle)
@@ -308,8 +332,8 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const PairArgs a) {
 #pragma unroll
         for (int f = 0; f < 5; ++f) {
             const int p = (wp * 5 + f) * 32 + l31;
-            const int iy = oy0 - 1 + (p >> WLOG);
-            const bool ok = p < C::NPX && iy >= 0 && iy < a.H;
+            int iy_, ix_;
+            const bool ok = halo_px(p, iy_, ix_);
             lds_u8 *rec = (lds_u8 *) smem + chunk * XB + p * 64 + lhi * 8;
             const int sw = (p >> 2) & 3;
 #pragma unroll
@@ -348,15 +372,29 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const PairArgs a) {
     // group g = (s, tap, khalf), s = row block (CB = 1) | chunk of the bundle (CB = 2): 4 pixel fragments, 4 | 8 MFMAs
     constexpr int NG = 36;
     frag_t P[2][4];
+    // generic tiles: output fragment f' = pq*4 + f is output ROW f' (32 columns), lane = column; its operand at tap (ky, kx)
+    // is halo pixel t = (f' + ky) * 34 + lane + kx -- the pitch is no multiple of 4, so the record's swizzle term (t >> 2) & 3 is
+    // recomputed per read (a handful of VALU next to 4 | 8 MFMAs)
+    const unsigned u_gen = (unsigned) (l31 + pq * 4 * 34);
+    const unsigned gen_base = lds0 + (unsigned) (jp * 2 * XB);
 #define PAIR_LOADP(G)                                                                                          \
     {                                                                                                          \
         constexpr int s_ = PAIR_G_S(G), t_ = PAIR_G_TAP(G), kh_ = PAIR_G_KH(G);                                \
         constexpr int ky_ = t_ / 3, kx_ = t_ % 3;                                                              \
-        const unsigned ad_ = (a_kx[kx_] + (unsigned) (s_ * XB)) ^ (unsigned) (kh_ * 32);                       \
-        ds_read16<0 * 2048 + ky_ * W * 64>(P[(G) & 1][0], ad_);                                                \
-        ds_read16<1 * 2048 + ky_ * W * 64>(P[(G) & 1][1], ad_);                                                \
-        ds_read16<2 * 2048 + ky_ * W * 64>(P[(G) & 1][2], ad_);                                                \
-        ds_read16<3 * 2048 + ky_ * W * 64>(P[(G) & 1][3], ad_);                                                \
+        if constexpr (GEN) {                                                                                   \
+            _Pragma("unroll") for (int f = 0; f < 4; ++f) {                                                    \
+                const unsigned tt_ = u_gen + (unsigned) ((f + ky_) * 34 + kx_);                                \
+                const unsigned ad_ = gen_base + (unsigned) (s_ * XB) + tt_ * 64u +                             \
+                                     ((((unsigned) lhi ^ ((tt_ >> 2) & 3u)) << 4) ^ (unsigned) (kh_ * 32));    \
+                ds_read16<0>(P[(G) & 1][f], ad_);                                                              \
+            }                                                                                                  \
+        } else {                                                                                               \
+            const unsigned ad_ = (a_kx[kx_] + (unsigned) (s_ * XB)) ^ (unsigned) (kh_ * 32);                   \
+            ds_read16<0 * 2048 + ky_ * W * 64>(P[(G) & 1][0], ad_);                                            \
+            ds_read16<1 * 2048 + ky_ * W * 64>(P[(G) & 1][1], ad_);                                            \
+            ds_read16<2 * 2048 + ky_ * W * 64>(P[(G) & 1][2], ad_);                                            \
+            ds_read16<3 * 2048 + ky_ * W * 64>(P[(G) & 1][3], ad_);                                            \
+        }                                                                                                      \
     }
     // columns beyond the left / right image edge (the conv's zero padding): output x = (fragment * 32 + l31) mod W
     const bool edge_l = (l31 & (W - 1)) == 0, edge_r = (l31 & (W - 1)) == ((W - 1) & 31);
@@ -376,8 +414,9 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const PairArgs a) {
         _Pragma("unroll") for (int f = 0; f < 4; ++f) {                                                        \
             frag_t pv = P[(G) & 1][f];                                                                         \
             /* W = 64: a fragment is half a row -- the left edge lies in even, the right edge in odd fragments */ \
-            if (kx_ == 0 && (W < 64 || (f & 1) == 0)) pv = edge_l ? zero_frag : pv;                  \
-            if (kx_ == 2 && (W < 64 || (f & 1) == 1)) pv = edge_r ? zero_frag : pv;                  \
+            /* (generic tiles carry a real halo column on both sides: nothing to mask) */                     \
+            if (!GEN && kx_ == 0 && (W < 64 || (f & 1) == 0)) pv = edge_l ? zero_frag : pv;                    \
+            if (!GEN && kx_ == 2 && (W < 64 || (f & 1) == 1)) pv = edge_r ? zero_frag : pv;                    \
             if constexpr (CB == 1) {                                                                           \
                 acc2[PAIR_G_S(G)][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[(G) % 3][0], pv, acc2[PAIR_G_S(G)][f], 0, 0, 0); \
             } else {                                                                                           \
@@ -408,7 +447,7 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const PairArgs a) {
         for (int q = 0; q < 4; ++q)
             b2[j][q] = a.b2 ? *(const float4 *) (a.b2 + n0 + jp * 64 + j * 32 + 8 * q + 4 * lhi) : make_float4(0.f, 0.f, 0.f, 0.f);
     const int px_l = lane >> 3, part_l = lane & 7;
-    const long img_px = (long) a.H * W;
+    const long img_px = (long) a.H * Wimg;
     unsigned char *const dst_n = (unsigned char *) a.dst + ((size_t) n * img_px * a.dst_stride + n0 + jp * 64 + part_l * 8) * 2;
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
@@ -425,17 +464,39 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const PairArgs a) {
         for (int it = 0; it < 4; ++it) {
             const int px = it * 8 + px_l;
             const u32x4 v = *(const lds_u32x4 *) (stg + px * SP + part_l * 16);
-            const long lin = (long) oy0 * W + (pq * 4 + f) * 32 + px;  // pixel index within the image
+            long lin;        // pixel index within the image
+            bool inside;
+            if constexpr (GEN) {  // fragment = output row oy0 + pq*4 + f, px = column
+                const int oy = oy0 + pq * 4 + f, ox = ox0 + px;
+                lin = (long) oy * Wimg + ox;
+                inside = oy < a.H && ox < a.W;
+            } else {
+                lin = (long) oy0 * W + (pq * 4 + f) * 32 + px;
+                inside = lin < img_px;
+            }
 #ifdef PAIR_EXP_NOEPI
             if (a.N < 0)
 #endif
-            if (lin < img_px) *(u32x4 *) (dst_n + (size_t) lin * a.dst_stride * 2) = v;
+            if (inside) *(u32x4 *) (dst_n + (size_t) lin * a.dst_stride * 2) = v;
         }
     }
 }
 
 constexpr size_t PAIR_LDS = 160 * 1024;
 constexpr int MAX_DEVICES = 64;
+
+// which tiling serves an image of width W with cmid conv1 output channels: 4 / 5 / 6 = full-width strips (W = 16 / 32 / 64),
+// 0 = generic 16 x 32 tiles (any larger width), -1 = none
+int pair_wlog(const PairArgs &a) {
+    if (a.W == 32 && a.cmid % 256 == 0) return 5;
+    if (a.W == 64 && a.cmid % 128 == 0) return 6;
+    if (a.W == 16 && a.cmid % 256 == 0) return 4;
+    if (a.W > 32 && a.cmid % 128 == 0 && a.cb2 == 32) return 0;  // (64-channel bundles on generic tiles spill registers)
+    return -1;
+}
+int pair_slab(int wlog) { return (wlog == 6 || wlog == 0) ? 128 : 256; }
+int pair_rows(int wlog) { return (wlog == 4 || wlog == 0) ? 16 : 8; }  // output rows per tile
+int pair_cols(int wlog, int W) { return wlog == 0 ? 32 : W; }         // output columns per tile
 
 template <int WLOG, int SL, int CB, int CPS>
 int launch_pair_cps(const PairArgs &a, hipStream_t stream) {
@@ -449,8 +510,8 @@ int launch_pair_cps(const PairArgs &a, hipStream_t stream) {
         if (e != hipSuccess) return (int) e;
         attr_set[dev].store(true, std::memory_order_release);
     }
-    const int tiles_y = (a.H + C::THO - 1) / C::THO;
-    dim3 grid((unsigned) (a.N * tiles_y), (unsigned) (a.cmid / SL), 1);
+    const int tiles_y = (a.H + C::THO - 1) / C::THO, tiles_x = C::GEN ? (a.W + C::TWO - 1) / C::TWO : 1;
+    dim3 grid((unsigned) (a.N * tiles_y * tiles_x), (unsigned) (a.cmid / SL), 1);
     hipLaunchKernelGGL(kern, grid, dim3(512), PAIR_LDS, stream, a);
     return (int) hipGetLastError();
 }
@@ -465,14 +526,10 @@ int launch_pair_cfg(const PairArgs &a, hipStream_t stream) {
     return launch_pair_cps<WLOG, SL, CB, 1>(a, stream);
 }
 
-int pair_slab(int W) { return W == 64 ? 128 : 256; }
-int pair_rows(int W) { return W == 16 ? 16 : 8; }  // output rows per strip
-
 }  // namespace
 
 bool conv_pair_supported(const PairArgs &a) {
-    if (a.W != 16 && a.W != 32 && a.W != 64) return false;
-    if (a.N <= 0 || a.H <= 0 || a.cin <= 0 || a.cin % 32 || a.cmid <= 0 || a.cmid % pair_slab(a.W)) return false;
+    if (a.N <= 0 || a.H <= 0 || a.W <= 0 || a.cin <= 0 || a.cin % 32 || a.cmid <= 0 || pair_wlog(a) < 0) return false;
     if (a.cb2 != 32 && a.cb2 != 64) return false;
     if (a.c_stride < a.cin || a.dst_stride < a.cmid || a.c_stride % 8 || a.dst_stride % 8) return false;
     // sources are read through raw buffer descriptors (2^31-byte limit), destinations with 32-bit element offsets
@@ -480,31 +537,36 @@ bool conv_pair_supported(const PairArgs &a) {
     return true;
 }
 
-// workgroups of the launch (strips x slabs): below ~3/4 of the 256 CUs the two plain convs, whose tiles shrink with the
+// workgroups of the launch (tiles x slabs): below ~3/4 of the 256 CUs the two plain convs, whose tiles shrink with the
 // problem, are as fast or faster (profiles/r04_pair_microbench.txt)
 long conv_pair_blocks(const PairArgs &a) {
-    const int tho = pair_rows(a.W);
-    return (long) a.N * ((a.H + tho - 1) / tho) * (a.cmid / pair_slab(a.W));
+    const int wl = pair_wlog(a);
+    if (wl < 0) return 0;
+    const int tho = pair_rows(wl), two = pair_cols(wl, a.W);
+    return (long) a.N * ((a.H + tho - 1) / tho) * ((a.W + two - 1) / two) * (a.cmid / pair_slab(wl));
 }
 
 int launch_conv_pair(const PairArgs &a, hipStream_t stream) {
     if (!conv_pair_supported(a) || !a.src || !a.dst || !a.w1 || !a.w2) return (int) hipErrorInvalidValue;
     const bool cb2 = a.cb2 == 64;
-    switch (a.W) {
-        case 16: return cb2 ? launch_pair_cfg<4, 256, 2>(a, stream) : launch_pair_cfg<4, 256, 1>(a, stream);
-        case 32: return cb2 ? launch_pair_cfg<5, 256, 2>(a, stream) : launch_pair_cfg<5, 256, 1>(a, stream);
-        default: return cb2 ? launch_pair_cfg<6, 128, 2>(a, stream) : launch_pair_cfg<6, 128, 1>(a, stream);
+    switch (pair_wlog(a)) {
+        case 4: return cb2 ? launch_pair_cfg<4, 256, 2>(a, stream) : launch_pair_cfg<4, 256, 1>(a, stream);
+        case 5: return cb2 ? launch_pair_cfg<5, 256, 2>(a, stream) : launch_pair_cfg<5, 256, 1>(a, stream);
+        case 6: return cb2 ? launch_pair_cfg<6, 128, 2>(a, stream) : launch_pair_cfg<6, 128, 1>(a, stream);
+        default: return launch_pair_cfg<0, 128, 1>(a, stream);
     }
 }
 
 // MFMA FLOPs the launch executes: conv1 on every staged halo pixel (incl. the recomputed halo rows and fragment padding) +
 // the block-diagonal conv2 bundles
 double conv_pair_executed_flops(const PairArgs &a) {
-    const int tho = pair_rows(a.W);
-    const int tiles_y = (a.H + tho - 1) / tho;
-    const double staged = a.W == 64 ? 640. : 320.;
-    const double s1 = 2.0 * a.N * tiles_y * staged * (double) a.cmid * a.cin;
-    const double s2 = 2.0 * a.N * tiles_y * (double) (tho * a.W) * (double) a.cmid * a.cb2 * 9.;
+    const int wl = pair_wlog(a);
+    if (wl < 0) return 0.;
+    const int tho = pair_rows(wl), two = pair_cols(wl, a.W);
+    const double tiles = (double) a.N * ((a.H + tho - 1) / tho) * ((a.W + two - 1) / two);
+    const double staged = pair_slab(wl) == 128 ? 640. : 320.;
+    const double s1 = 2.0 * tiles * staged * (double) a.cmid * a.cin;
+    const double s2 = 2.0 * tiles * (double) (tho * two) * (double) a.cmid * a.cb2 * 9.;
     return s1 + s2;
 }
 

@@ -690,8 +690,8 @@ int cpn_conv_pair(const cpn_op_desc *op, const void *src, int32_t c_stride, void
     a.b1 = (bias && op->bias_offset >= 0) ? bias + op->bias_offset : nullptr;
     a.b2 = (bias && op->fuse_bias_offset >= 0) ? bias + op->fuse_bias_offset : nullptr;
     if (!conv_pair_supported(a))
-        return fail(CPN_E_UNSUPPORTED, "cpn_conv_pair: needs W = 16 | 32 | 64, conv1 output channels a multiple of 256 (128 at "
-                                       "W = 64), conv2 bundles of 32 | 64 channels");
+        return fail(CPN_E_UNSUPPORTED, "cpn_conv_pair: needs W = 16 or W >= 32, conv1 output channels a multiple of 256 (128 at "
+                                       "W > 32), conv2 bundles of 32 | 64 channels (32 on generic tiles)");
     return check_hip((hipError_t) launch_conv_pair(a, (hipStream_t) stream), "cpn_conv_pair");
 }
 

@@ -77,8 +77,8 @@ double conv_executed_flops(const ConvArgs &a);
 struct PairArgs {
     const void *src;       // [N][H][W][c_stride] bf16
     int c_stride;
-    int N, H, W;           // W must be 16, 32 or 64 (full-width row strips)
-    int cin, cmid;         // multiples of 32 / of the slab width (256; 128 for W = 64)
+    int N, H, W;           // W = 16 | 32 | 64: full-width row strips; any W > 32: generic 16 x 32 tiles
+    int cin, cmid;         // multiples of 32 / of the slab width (256 at W = 16 | 32; 128 otherwise)
     const void *w1;        // [cin/32 items (+1 zero item if odd)][cmid][32] bf16
     const float *b1;       // [cmid] or nullptr
     const void *w2;        // [cmid/cb2 bundles][(cb2/32)*9 items (+1 zero item if odd)][cb2][32] bf16

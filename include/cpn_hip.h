@@ -64,9 +64,9 @@ typedef struct {
  * weights: src0 = conv1's source, dst = conv2's destination, cin_b / cout_b = conv1's input / output channels,
  * weight_offset / bias_offset = conv1's, fuse_weight_offset / fuse_bias_offset = conv2's, bundles = conv2's bundles,
  * fuse_cout = conv2's channels per bundle (32 | 64).  The executor runs it INSTEAD of the two convs at every input size at
- * which the block's feature map is exactly 16, 32 or 64 pixels wide (full-width row strips), conv1's output channels
- * are a multiple of the kernel's slab (256; 128 at width 64) and batch x strips x slabs give >= 192 workgroups; the two
- * convs run otherwise.  Same operands and per-conv
+ * which the kernel applies -- feature maps exactly 16 | 32 | 64 pixels wide as full-width row strips (conv1 output channels
+ * a multiple of 256; 128 at width 64), any other width > 32 as generic 16 x 32 tiles (multiple of 128, 32-channel bundles)
+ * -- and batch x tiles x slabs give >= 192 workgroups; the two convs run otherwise.  Same operands and per-conv
  * rounding (bf16 activations between the two convs) as the unfused pair; conv1 is recomputed on one halo row above and
  * below each 8-row strip. */
 enum { CPN_OP_INPUT = 0, CPN_OP_CONV = 1, CPN_OP_MAXPOOL = 2, CPN_OP_BILINEAR = 3, CPN_OP_CONV_DEFERRED = 4,
@@ -211,7 +211,7 @@ int cpn_stem7(const cpn_op_desc *op, const void *src, void *dst, int32_t dst_str
               const void *weights, const float *bias, float out_inv_scale, void *stream);
 /* Fused bottleneck head (see CPN_OP_CONV_PAIR; `op`: such a descriptor, `weights` / `bias`: the blobs its four offsets
  * index): src NHWC bf16 [N][H][W][c_stride] -> dst NHWC bf16 [N][H][W][dst_stride], channels [0, cout_b).  Returns
- * CPN_E_UNSUPPORTED when W is not 16 / 32 / 64 or cout_b is no multiple of the slab width (run the two convs instead). */
+ * CPN_E_UNSUPPORTED when W < 16 or between 17 and 31, or cout_b is no multiple of the slab width (run the two convs). */
 int cpn_conv_pair(const cpn_op_desc *op, const void *src, int32_t c_stride, void *dst, int32_t dst_stride, int32_t N,
                   int32_t H, int32_t W, const void *weights, const float *bias, void *stream);
 int cpn_maxpool2d(const void *src, void *dst, int32_t N, int32_t Hin, int32_t Win, int32_t C, int32_t k, int32_t stride,

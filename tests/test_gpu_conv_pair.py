@@ -87,6 +87,12 @@ PAIR_CASES = {
     'w16_cpg64_layer4': dict(n=2, h=16, w=16, cin=256, cmid=2048, groups=32, seed=8),
     'w16_cpg32_tall': dict(n=1, h=37, w=16, cin=64, cmid=256, groups=8, seed=9),
     'w16_one_chunk': dict(n=3, h=16, w=16, cin=32, cmid=256, groups=32, seed=10),
+    # generic 16 x 32 tiles with a real halo on all sides: any width > 32 that is not 64 (stage 1 at 512^2: 128 wide)
+    'gen_w128_cpg8_layer1': dict(n=2, h=128, w=128, cin=256, cmid=256, groups=32, seed=11),
+    'gen_w128_first_block': dict(n=1, h=48, w=128, cin=64, cmid=256, groups=32, seed=12),
+    'gen_w63_ragged': dict(n=2, h=37, w=63, cin=32, cmid=128, groups=16, seed=13),
+    'gen_w40_cpg16': dict(n=1, h=16, w=40, cin=96, cmid=512, groups=32, seed=14),
+    'gen_w100_tall': dict(n=1, h=70, w=100, cin=64, cmid=128, groups=4, seed=15),
 }
 
 
@@ -107,14 +113,14 @@ def test_conv_pair_unsupported_width(dev):
     from celldetection_amd import _lib, graph
     P, sd = _pair_plan(64, 256, 32, 0)
     tens, ops, wblob, bblob = graph.pack(P, sd, dev)
-    x = torch.zeros(1, 8, 40, 64, dtype=torch.bfloat16, device=dev)
-    y = torch.zeros(1, 8, 40, 256, dtype=torch.bfloat16, device=dev)
-    rc = _lib.load().cpn_conv_pair(ops[2], _lib.ptr(x), 64, _lib.ptr(y), 256, 1, 8, 40, _lib.ptr(wblob), _lib.ptr(bblob),
+    x = torch.zeros(1, 8, 24, 64, dtype=torch.bfloat16, device=dev)
+    y = torch.zeros(1, 8, 24, 256, dtype=torch.bfloat16, device=dev)
+    rc = _lib.load().cpn_conv_pair(ops[2], _lib.ptr(x), 64, _lib.ptr(y), 256, 1, 8, 24, _lib.ptr(wblob), _lib.ptr(bblob),
                                    _lib.stream_ptr())
-    assert rc == _lib.E_UNSUPPORTED
+    assert rc == _lib.E_UNSUPPORTED  # 24 pixels wide: neither a strip width nor wide enough for the generic tiles
 
 
-@pytest.mark.parametrize('size,fused', [((256, 256), True), ((200, 200), False), ((128, 512), True)])
+@pytest.mark.parametrize('size,fused', [((256, 256), True), ((200, 200), True), ((88, 96), False), ((128, 512), True)])
 def test_plan_picks_the_fused_pair_per_input_size(dev, size, fused, monkeypatch):
     """A ResNeXt encoder plan carries both statements of every stride-1 block head; the executor runs the fused op where the
     stage's feature map is 16 / 32 / 64 pixels wide -- head maps are identical to the plan without fused ops."""

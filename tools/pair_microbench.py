@@ -17,6 +17,7 @@ CASES = {  # ResNeXt101 32x8d stages at 16 x 512^2 (l2 / l3 / l4) and 16 x 256^2
     'l3': dict(n=16, h=32, w=32, cin=1024, cmid=1024, groups=32),
     'l2': dict(n=16, h=64, w=64, cin=512, cmid=512, groups=32),
     'l4': dict(n=16, h=16, w=16, cin=2048, cmid=2048, groups=32),
+    'l1': dict(n=16, h=128, w=128, cin=256, cmid=256, groups=32),  # generic 16 x 32 tiles
     'l1_256': dict(n=16, h=64, w=64, cin=256, cmid=256, groups=32),
     'l2_256': dict(n=16, h=32, w=32, cin=512, cmid=512, groups=32),
     'l3_256': dict(n=16, h=16, w=16, cin=1024, cmid=1024, groups=32),
