@@ -93,9 +93,12 @@ __device__ __forceinline__ void wait_p4(frag_t (&p)[4]) {
 
 // CPS = 32-channel chunks per stage-1 pipeline step: 1 = ring of three chunks (two chunks of prefetch distance), 2 = ring of
 // two steps x two chunks like conv_igemm's 1x1 loop (half the barriers; needs an even chunk count and 4 ring slots in LDS)
-template <int WLOG, int SL, int CB, int CPS>
+// STRIDE = conv2's stride.  2 (generic tiles only): the 18 x 34 halo tile of conv1's output is the input of an 8 x 16 OUTPUT
+// tile (output (oy, ox) reads halo pixels (2 oy + ky, 2 ox + kx)); stage 1 is unchanged, stage 2 has one fragment per wave
+template <int WLOG, int SL, int CB, int CPS, int STRIDE = 1>
 __global__ __launch_bounds__(512) void conv_pair_kernel(const PairArgs a) {
     using C = PairCfg<WLOG, SL>;
+    static_assert(STRIDE == 1 || (STRIDE == 2 && C::GEN), "stride-2 conv2: generic tiles");
     constexpr int NR = CPS == 2 ? 4 : 3;  // ring slots
     static_assert(NR * (C::XBUF + C::WBUF) <= C::LDS, "staging ring exceeds the LDS");
     constexpr int W = C::W;
@@ -111,8 +114,10 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const PairArgs a) {
     const int l31 = lane & 31, lhi = lane >> 5;
     constexpr bool GEN = C::GEN;
     const int Wimg = GEN ? a.W : W;   // image width (strips: a template constant)
-    const int tiles_y = (a.H + C::THO - 1) / C::THO;
-    const int tiles_x = GEN ? (a.W + C::TWO - 1) / C::TWO : 1;
+    // (stride 2: tiles are counted on the OUTPUT, 8 x 16 pixels each = 16 x 32 input pixels)
+    const int Ho = STRIDE == 2 ? (a.H - 1) / 2 + 1 : a.H, Wo = STRIDE == 2 ? (a.W - 1) / 2 + 1 : a.W;
+    const int tiles_y = (Ho + C::THO / STRIDE - 1) / (C::THO / STRIDE);
+    const int tiles_x = GEN ? (Wo + C::TWO / STRIDE - 1) / (C::TWO / STRIDE) : 1;
     const int tx = (int) (blockIdx.x % (unsigned) tiles_x), ty = (int) ((blockIdx.x / (unsigned) tiles_x) % (unsigned) tiles_y);
     const int n = (int) (blockIdx.x / (unsigned) (tiles_x * tiles_y));
     const int oy0 = ty * C::THO;      // first output row of the tile; halo row r is image row oy0 - 1 + r
@@ -354,6 +359,79 @@ __global__ __launch_bounds__(512) void conv_pair_kernel(const PairArgs a) {
     // j = 0, 1 of 32) on output fragments pq*4 .. +3.  CB = 1: row block j is the 32-channel bundle 2 jp + j and reads slab
     // chunk 2 jp + j; CB = 2: both row blocks belong to the 64-channel bundle jp and read chunks 2 jp, 2 jp + 1.
     // ------------------------------------------------------------------------------------------------------------
+    if constexpr (STRIDE == 2) {
+        // ---- stride-2 conv2: this wave = 64 output channels x ONE output fragment (output rows 2 pq, 2 pq + 1 of the 8 x 16
+        // tile, 16 columns each): lane -> (row 2 pq + (l31 >> 4), column l31 & 15), operand = halo pixel (2 row + ky) * 34 +
+        // 2 column + kx.  36 groups of 1 | 2 MFMAs -- a tenth of stage 1's work
+        f32x16 a2[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a2[j][r] = 0.f;
+        const unsigned u2 = (unsigned) ((4 * pq + 2 * (l31 >> 4)) * 34 + 2 * (l31 & 15));
+        const unsigned base2 = lds0 + (unsigned) (jp * 2 * XB);
+        frag_t P2[2];
+        auto p2_addr = [&](int g) -> unsigned {
+            const int s_ = g / 18, t_ = (g % 18) >> 1, kh_ = g & 1;
+            const unsigned tt = u2 + (unsigned) ((t_ / 3) * 34 + t_ % 3);
+            return base2 + (unsigned) (s_ * XB) + tt * 64u + ((((unsigned) lhi ^ ((tt >> 2) & 3u)) << 4) ^ (unsigned) (kh_ * 32));
+        };
+#ifndef PAIR_EXP_NOS2
+        ds_read16<0>(P2[0], p2_addr(0));
+#pragma unroll
+        for (int g = 0; g < 36; ++g) {
+            const int s_ = g / 18, t_ = (g % 18) >> 1, kh_ = g & 1;
+            if (g + 2 < 36) {
+                const int s2_ = (g + 2) / 18, t2_ = ((g + 2) % 18) >> 1, k2_ = (g + 2) & 1;
+                if constexpr (CB == 1) {
+                    Wr[(g + 2) % 3][0] = *(const frag_t *) (wrow[s2_] + t2_ * (COB * 64) + k2_ * 32);
+                } else {
+                    Wr[(g + 2) % 3][0] = *(const frag_t *) (wrow[0] + (s2_ * 9 + t2_) * (COB * 64) + k2_ * 32);
+                    Wr[(g + 2) % 3][1] = *(const frag_t *) (wrow[1] + (s2_ * 9 + t2_) * (COB * 64) + k2_ * 32);
+                }
+            }
+            if (g + 1 < 36) {
+                ds_read16<0>(P2[(g + 1) & 1], p2_addr(g + 1));
+                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(P2[g & 1]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(P2[g & 1]));
+            }
+            (void) t_; (void) kh_;
+            if constexpr (CB == 1) {
+                a2[s_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[g % 3][0], P2[g & 1], a2[s_], 0, 0, 0);
+            } else {
+                a2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[g % 3][0], P2[g & 1], a2[0], 0, 0, 0);
+                a2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wr[g % 3][1], P2[g & 1], a2[1], 0, 0, 0);
+            }
+        }
+#endif
+        __syncthreads();  // every wave is done reading the slab tile
+        constexpr int SP2 = 144;
+        lds_u8 *const stg2 = (lds_u8 *) smem + wave * (32 * SP2);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 b = a.b2 ? *(const float4 *) (a.b2 + n0 + jp * 64 + j * 32 + 8 * q + 4 * lhi) : make_float4(0.f, 0.f, 0.f, 0.f);
+                u32x2 o;
+                o.x = pack_bf16x2(fmaxf(a2[j][q * 4 + 0] + b.x, 0.f), fmaxf(a2[j][q * 4 + 1] + b.y, 0.f));
+                o.y = pack_bf16x2(fmaxf(a2[j][q * 4 + 2] + b.z, 0.f), fmaxf(a2[j][q * 4 + 3] + b.w, 0.f));
+                *(lds_u32x2 *) (stg2 + l31 * SP2 + j * 64 + q * 16 + lhi * 8) = o;
+            }
+        const int px_l2 = lane >> 3, part_l2 = lane & 7;
+        unsigned char *const dst2 = (unsigned char *) a.dst + ((size_t) n * Ho * Wo * a.dst_stride + n0 + jp * 64 + part_l2 * 8) * 2;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int px = it * 8 + px_l2;
+            const u32x4 v = *(const lds_u32x4 *) (stg2 + px * SP2 + part_l2 * 16);
+            const int oy = ty * 8 + 2 * pq + (px >> 4), ox = tx * 16 + (px & 15);
+#ifdef PAIR_EXP_NOEPI
+            if (a.N < 0)
+#endif
+            if (oy < Ho && ox < Wo) *(u32x4 *) (dst2 + ((size_t) oy * Wo + ox) * a.dst_stride * 2) = v;
+        }
+        return;
+    }
     f32x16 acc2[2][4];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -488,6 +566,7 @@ constexpr int MAX_DEVICES = 64;
 // which tiling serves an image of width W with cmid conv1 output channels: 4 / 5 / 6 = full-width strips (W = 16 / 32 / 64),
 // 0 = generic 16 x 32 tiles (any larger width), -1 = none
 int pair_wlog(const PairArgs &a) {
+    if (a.stride == 2) return (a.W >= 32 && a.cmid % 128 == 0) ? 0 : -1;  // stride-2 conv2: generic tiles only
     if (a.W == 32 && a.cmid % 256 == 0) return 5;
     if (a.W == 64 && a.cmid % 128 == 0) return 6;
     if (a.W == 16 && a.cmid % 256 == 0) return 4;
@@ -498,11 +577,11 @@ int pair_slab(int wlog) { return (wlog == 6 || wlog == 0) ? 128 : 256; }
 int pair_rows(int wlog) { return (wlog == 4 || wlog == 0) ? 16 : 8; }  // output rows per tile
 int pair_cols(int wlog, int W) { return wlog == 0 ? 32 : W; }         // output columns per tile
 
-template <int WLOG, int SL, int CB, int CPS>
+template <int WLOG, int SL, int CB, int CPS, int STRIDE = 1>
 int launch_pair_cps(const PairArgs &a, hipStream_t stream) {
     using C = PairCfg<WLOG, SL>;
     static std::atomic<bool> attr_set[MAX_DEVICES];
-    auto kern = conv_pair_kernel<WLOG, SL, CB, CPS>;
+    auto kern = conv_pair_kernel<WLOG, SL, CB, CPS, STRIDE>;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return (int) hipErrorInvalidDevice;
     if (!attr_set[dev].load(std::memory_order_acquire)) {
@@ -510,25 +589,28 @@ int launch_pair_cps(const PairArgs &a, hipStream_t stream) {
         if (e != hipSuccess) return (int) e;
         attr_set[dev].store(true, std::memory_order_release);
     }
-    const int tiles_y = (a.H + C::THO - 1) / C::THO, tiles_x = C::GEN ? (a.W + C::TWO - 1) / C::TWO : 1;
+    const int Ho = STRIDE == 2 ? (a.H - 1) / 2 + 1 : a.H, Wo = STRIDE == 2 ? (a.W - 1) / 2 + 1 : a.W;
+    const int tiles_y = (Ho + C::THO / STRIDE - 1) / (C::THO / STRIDE);
+    const int tiles_x = C::GEN ? (Wo + C::TWO / STRIDE - 1) / (C::TWO / STRIDE) : 1;
     dim3 grid((unsigned) (a.N * tiles_y * tiles_x), (unsigned) (a.cmid / SL), 1);
     hipLaunchKernelGGL(kern, grid, dim3(512), PAIR_LDS, stream, a);
     return (int) hipGetLastError();
 }
 
-template <int WLOG, int SL, int CB>
+template <int WLOG, int SL, int CB, int STRIDE = 1>
 int launch_pair_cfg(const PairArgs &a, hipStream_t stream) {
     // two chunks per pipeline step wherever four ring slots fit the LDS (the 256-channel slabs) and the chunk count is even
     if constexpr (4 * (PairCfg<WLOG, SL>::XBUF + PairCfg<WLOG, SL>::WBUF) <= PairCfg<WLOG, SL>::LDS) {
         const char *e = getenv("CPN_PAIR_CPS");  // kernel A/B switch
-        if ((a.cin & 63) == 0 && !(e && atoi(e) == 1)) return launch_pair_cps<WLOG, SL, CB, 2>(a, stream);
+        if ((a.cin & 63) == 0 && !(e && atoi(e) == 1)) return launch_pair_cps<WLOG, SL, CB, 2, STRIDE>(a, stream);
     }
-    return launch_pair_cps<WLOG, SL, CB, 1>(a, stream);
+    return launch_pair_cps<WLOG, SL, CB, 1, STRIDE>(a, stream);
 }
 
 }  // namespace
 
 bool conv_pair_supported(const PairArgs &a) {
+    if (a.stride != 1 && a.stride != 2) return false;
     if (a.N <= 0 || a.H <= 0 || a.W <= 0 || a.cin <= 0 || a.cin % 32 || a.cmid <= 0 || pair_wlog(a) < 0) return false;
     if (a.cb2 != 32 && a.cb2 != 64) return false;
     if (a.c_stride < a.cin || a.dst_stride < a.cmid || a.c_stride % 8 || a.dst_stride % 8) return false;
@@ -542,7 +624,7 @@ bool conv_pair_supported(const PairArgs &a) {
 long conv_pair_blocks(const PairArgs &a) {
     const int wl = pair_wlog(a);
     if (wl < 0) return 0;
-    const int tho = pair_rows(wl), two = pair_cols(wl, a.W);
+    const int tho = pair_rows(wl), two = pair_cols(wl, a.W);  // (stride 2: 16 x 32 input pixels = 8 x 16 outputs per tile)
     return (long) a.N * ((a.H + tho - 1) / tho) * ((a.W + two - 1) / two) * (a.cmid / pair_slab(wl));
 }
 
@@ -553,7 +635,9 @@ int launch_conv_pair(const PairArgs &a, hipStream_t stream) {
         case 4: return cb2 ? launch_pair_cfg<4, 256, 2>(a, stream) : launch_pair_cfg<4, 256, 1>(a, stream);
         case 5: return cb2 ? launch_pair_cfg<5, 256, 2>(a, stream) : launch_pair_cfg<5, 256, 1>(a, stream);
         case 6: return cb2 ? launch_pair_cfg<6, 128, 2>(a, stream) : launch_pair_cfg<6, 128, 1>(a, stream);
-        default: return launch_pair_cfg<0, 128, 1>(a, stream);
+        default:
+            if (a.stride == 2) return cb2 ? launch_pair_cfg<0, 128, 2, 2>(a, stream) : launch_pair_cfg<0, 128, 1, 2>(a, stream);
+            return launch_pair_cfg<0, 128, 1>(a, stream);
     }
 }
 
@@ -566,7 +650,7 @@ double conv_pair_executed_flops(const PairArgs &a) {
     const double tiles = (double) a.N * ((a.H + tho - 1) / tho) * ((a.W + two - 1) / two);
     const double staged = pair_slab(wl) == 128 ? 640. : 320.;
     const double s1 = 2.0 * tiles * staged * (double) a.cmid * a.cin;
-    const double s2 = 2.0 * tiles * (double) (tho * two) * (double) a.cmid * a.cb2 * 9.;
+    const double s2 = 2.0 * tiles * (double) (tho * two / (a.stride * a.stride)) * (double) a.cmid * a.cb2 * 9.;
     return s1 + s2;
 }
 

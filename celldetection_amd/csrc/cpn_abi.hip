@@ -73,7 +73,7 @@ static int64_t tensor_bytes(const cpn_tensor_desc &t, int N, int h, int w, int e
 static PairArgs pair_args(const cpn_plan *p, const cpn_op_desc &o, int N, int H, int W) {
     PairArgs a{};
     a.N = N; a.H = H; a.W = W;
-    a.cin = o.cin_b; a.cmid = o.cout_b; a.cb2 = o.fuse_cout;
+    a.cin = o.cin_b; a.cmid = o.cout_b; a.cb2 = o.fuse_cout; a.stride = o.stride;
     a.c_stride = o.src0 >= 0 && p ? p->tensors[o.src0].channels : o.cin_b;
     a.dst_stride = o.dst >= 0 && p ? p->tensors[o.dst].channels : o.cout_b;
     if (p) {
@@ -123,7 +123,8 @@ static void propagate_dims(const cpn_plan *p, int N, int H, int W, ShapePlan &sp
                 // and its strips x slabs fill the chip (CPN_PAIR=0 / 2: never / wherever supported -- kernel A/B and tests)
                 const char *e = getenv("CPN_PAIR");
                 const int mode = e ? atoi(e) : 1;
-                const PairArgs pa = pair_args(p, o, N, sp.th[o.dst], sp.tw[o.dst]);
+                const int mid = p->ops[oi - 2].dst;  // conv1's output: the kernel's H x W (conv2 may stride it down)
+                const PairArgs pa = pair_args(p, o, N, sp.th[mid], sp.tw[mid]);
                 const bool fused = mode != 0 && p->precision == CPN_PRECISION_BF16 && conv_pair_supported(pa) &&
                                    (mode == 2 || conv_pair_blocks(pa) >= 192);
                 sp.skip[oi] = !fused;
@@ -387,7 +388,8 @@ int cpn_plan_create(cpn_plan **plan, const cpn_tensor_desc *tensors, int32_t n_t
             if (precision != CPN_PRECISION_BF16 || !c1 || c1->op != CPN_OP_CONV || c2->op != CPN_OP_CONV || c1->kh != 1 ||
                 c1->kw != 1 || c1->stride != 1 || c1->pad != 0 || c1->bundles != 1 || c1->src1 >= 0 || c1->res >= 0 ||
                 c1->up0 || c1->act != CPN_ACT_RELU || c1->subpixel || c1->alt || c1->dst < 0 || c2->src0 != c1->dst ||
-                c2->src1 >= 0 || c2->res >= 0 || c2->up0 || c2->kh != 3 || c2->kw != 3 || c2->stride != 1 || c2->pad != 1 ||
+                c2->src1 >= 0 || c2->res >= 0 || c2->up0 || c2->kh != 3 || c2->kw != 3 || (c2->stride != 1 && c2->stride != 2) ||
+                c2->pad != 1 || o.stride != c2->stride ||
                 c2->act != CPN_ACT_RELU || c2->subpixel || c2->alt || c2->dst < 0 || c2->cin_b != c2->cout_b ||
                 (c2->cout_b != 32 && c2->cout_b != 64) || c2->bundles * c2->cout_b != c1->cout_b || o.src0 != c1->src0 ||
                 o.dst != c2->dst || o.cin_b != c1->cin_b || o.cout_b != c1->cout_b || o.fuse_cout != c2->cout_b ||
@@ -398,7 +400,7 @@ int cpn_plan_create(cpn_plan **plan, const cpn_tensor_desc *tensors, int32_t n_t
                 (size_t) o.fuse_weight_offset + (size_t) o.bundles * (it2 + (it2 & 1)) * o.fuse_cout * 64 > weight_bytes) {
                 delete p;
                 return fail(CPN_E_INVALID, "cpn_plan_create: a CPN_OP_CONV_PAIR op must follow the 1x1 conv + ReLU and the grouped "
-                                           "3x3 stride-1 conv + ReLU (bundles of 32 | 64 channels) it restates and share their offsets");
+                                           "3x3 conv + ReLU (stride 1 | 2, bundles of 32 | 64 channels) it restates and share their offsets");
             }
         }
         if (o.alt < 0 || o.alt > 2) {
@@ -547,7 +549,8 @@ static int run_or_count(cpn_plan *plan, const void *input, int32_t in_dtype, int
                 break;
             }
             case CPN_OP_CONV_PAIR: {
-                PairArgs a = pair_args(plan, o, N, sp.th[o.dst], sp.tw[o.dst]);
+                const int mid = plan->ops[i - 2].dst;
+                PairArgs a = pair_args(plan, o, N, sp.th[mid], sp.tw[mid]);
                 a.src = tptr(o.src0);
                 a.dst = tptr(o.dst);
                 const double fl = conv_pair_executed_flops(a);
@@ -691,7 +694,7 @@ int cpn_conv_pair(const cpn_op_desc *op, const void *src, int32_t c_stride, void
     a.b2 = (bias && op->fuse_bias_offset >= 0) ? bias + op->fuse_bias_offset : nullptr;
     if (!conv_pair_supported(a))
         return fail(CPN_E_UNSUPPORTED, "cpn_conv_pair: needs W = 16 or W >= 32, conv1 output channels a multiple of 256 (128 at "
-                                       "W > 32), conv2 bundles of 32 | 64 channels (32 on generic tiles)");
+                                       "W > 32 and for a stride-2 conv2), conv2 bundles of 32 | 64 channels (32 on stride-1 generic tiles)");
     return check_hip((hipError_t) launch_conv_pair(a, (hipStream_t) stream), "cpn_conv_pair");
 }
 

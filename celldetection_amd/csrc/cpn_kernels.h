@@ -84,8 +84,9 @@ struct PairArgs {
     const void *w2;        // [cmid/cb2 bundles][(cb2/32)*9 items (+1 zero item if odd)][cb2][32] bf16
     const float *b2;       // [cmid] or nullptr
     int cb2;               // channels per conv2 bundle: 32 | 64
-    void *dst;             // [N][H][W][dst_stride] bf16
+    void *dst;             // [N][Ho][Wo][dst_stride] bf16, Ho = (H - 1) / stride + 1 (3x3, pad 1)
     int dst_stride;
+    int stride;            // conv2's stride: 1 | 2 (2: generic tiles, W >= 32)
 };
 bool conv_pair_supported(const PairArgs &a);
 int launch_conv_pair(const PairArgs &a, hipStream_t stream);

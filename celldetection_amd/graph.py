@@ -87,16 +87,16 @@ class Plan:
         return dst
 
     def conv_pair(self):
-        """Restates the last two conv ops -- conv1 1x1 + BN + ReLU -> grouped conv2 3x3 stride 1 + BN + ReLU, the head of a
+        """Restates the last two conv ops -- conv1 1x1 + BN + ReLU -> grouped conv2 3x3 (stride 1 | 2) + BN + ReLU, the head of a
         ResNeXt bottleneck block (models/resnet.py:88-116,119-193) -- as ONE fused op (include/cpn_hip.h CPN_OP_CONV_PAIR,
-        csrc/conv_pair.hip).  The executor runs it instead of the pair wherever the feature map is 16 / 32 / 64 pixels wide;
+        csrc/conv_pair.hip).  The executor runs it instead of the pair wherever the kernel's tiles fit and fill the chip;
         no state-dict entries, no weights of its own.  Returns False (and adds nothing) when the pair does not qualify."""
         c1, c2 = self.ops[-2], self.ops[-1]
         cpg = c2['cin'] // c2['groups']
         bw = cpg if cpg % 32 == 0 else (32 if 32 % cpg == 0 else 0)  # channels per packed bundle (_bundle_geometry)
         ok = (c1['op'] == c2['op'] == 'conv' and c1['k'] == 1 and c1['stride'] == 1 and c1['groups'] == 1 and
               c1['src1'] is None and c1['res'] is None and not c1['up0'] and c1['act'] == 'relu' and c1.get('sub') is None and
-              c2['src0'] == c1['dst'] and c2['k'] == 3 and c2['stride'] == 1 and c2['pad'] == 1 and c2['groups'] > 1 and
+              c2['src0'] == c1['dst'] and c2['k'] == 3 and c2['stride'] in (1, 2) and c2['pad'] == 1 and c2['groups'] > 1 and
               c2['src1'] is None and c2['res'] is None and not c2['up0'] and c2['act'] == 'relu' and c2['cin'] == c2['cout'] and
               bw in (32, 64) and c2['cout'] % 128 == 0 and c1['dst'] is not None and c2['dst'] is not None)
         if ok:
@@ -246,7 +246,7 @@ def _resnet(P, x, in_channels, prefix, kind, base_channel=64, stem_fast=False, f
                 width = int(planes * (base_width / 64.0)) * groups
                 t = P.conv(x, width, 1, w=p + 'conv1.', bn=p + 'bn1.', act='relu')
                 t = P.conv(t, width, 3, w=p + 'conv2.', bn=p + 'bn2.', stride=stride, groups=groups, act='relu')
-                if fuse_blocks and groups > 1 and stride == 1:
+                if fuse_blocks and groups > 1:
                     P.conv_pair()  # (bf16 plans) conv1 -> grouped conv2 as one kernel where the feature map allows it
                 # key order in the reference: conv3, bn3, then downsample -> emit conv3 keys before downsample keys
                 n_before = len(P.entries)
@@ -404,8 +404,8 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
     sub-pixel decomposition; the executor picks it wherever the top-down map is upsampled by exactly 2.
     ``stem_fast`` (bf16 plans, ResNet-family encoders with <= 4 input channels): the 7x7 stride-2 stem additionally carries
     its dedicated kernel on a padded 4-channel input layout (``Plan.stem_fast_path``).
-    ``fuse_blocks`` (bf16 plans, ResNeXt encoders): every stride-1 bottleneck block additionally carries conv1 -> grouped
-    conv2 as one fused op (``Plan.conv_pair``)."""
+    ``fuse_blocks`` (bf16 plans, ResNeXt encoders): every bottleneck block additionally carries conv1 -> grouped conv2 as
+    one fused op (``Plan.conv_pair``)."""
     if contour_head_stride not in (1, 2) or refinement_head_stride not in (1, 2):
         raise NotImplementedError('head strides other than 1 and 2 are not supported by the HIP conv kernel')
     feats_cfg = dict(score='1', location='1', contour='1', uncertainty='1', refinement='0')
@@ -624,7 +624,7 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=Non
             assert op['first'] == i - 2 and c2.bundles * c2.cout_b == c1.cout_b and c2.cin_b == c2.cout_b
             d.op, d.src0, d.dst = _lib.OP_CONV_PAIR, op['src0'], op['dst']
             d.kh = d.kw = 3
-            d.stride, d.pad = 1, 1
+            d.stride, d.pad = c2.stride, 1
             d.bundles, d.cin_b, d.cout_b, d.c0_used = c2.bundles, c1.cin_b, c1.cout_b, c1.cin_b
             d.weight_offset, d.bias_offset = c1.weight_offset, c1.bias_offset
             d.fuse_weight_offset, d.fuse_bias_offset, d.fuse_cout = c2.weight_offset, c2.bias_offset, c2.cout_b

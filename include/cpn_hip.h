@@ -58,15 +58,16 @@ typedef struct {
  * Both carry `alt` = 2 and stand next to the generic CPN_OP_INPUT / CPN_OP_CONV pair (`alt` = 1): the executor runs the
  * fast pair at every input size the layout fits into the tensor, the generic pair otherwise. */
 /* CPN_OP_CONV_PAIR (bf16 plans; csrc/conv_pair.hip): the head of a grouped bottleneck block -- conv1 1x1 + BN + ReLU ->
- * conv2 3x3 (groups, stride 1, pad 1) + BN + ReLU, torchvision Bottleneck.forward as built by
+ * conv2 3x3 (groups, stride 1 | 2, pad 1) + BN + ReLU, torchvision Bottleneck.forward as built by
  * celldetection/models/resnet.py:88-116,119-193 for the ResNeXt encoders -- as ONE kernel: conv1's output stays in LDS.
  * The op stands directly BEHIND the two CPN_OP_CONV ops it restates (conv1 at index i - 2, conv2 at i - 1) and adds no
  * weights: src0 = conv1's source, dst = conv2's destination, cin_b / cout_b = conv1's input / output channels,
  * weight_offset / bias_offset = conv1's, fuse_weight_offset / fuse_bias_offset = conv2's, bundles = conv2's bundles,
  * fuse_cout = conv2's channels per bundle (32 | 64).  The executor runs it INSTEAD of the two convs at every input size at
  * which the kernel applies -- feature maps exactly 16 | 32 | 64 pixels wide as full-width row strips (conv1 output channels
- * a multiple of 256; 128 at width 64), any other width > 32 as generic 16 x 32 tiles (multiple of 128, 32-channel bundles)
- * -- and batch x tiles x slabs give >= 192 workgroups; the two convs run otherwise.  Same operands and per-conv
+ * a multiple of 256; 128 at width 64), any other width > 32 as generic 16 x 32 tiles (multiple of 128, 32-channel bundles);
+ * a stride-2 conv2 (`stride` = 2: the first block of a stage) on generic tiles at any width >= 32 -- and batch x tiles x
+ * slabs give >= 192 workgroups; the two convs run otherwise.  Same operands and per-conv
  * rounding (bf16 activations between the two convs) as the unfused pair; conv1 is recomputed on one halo row above and
  * below each 8-row strip. */
 enum { CPN_OP_INPUT = 0, CPN_OP_CONV = 1, CPN_OP_MAXPOOL = 2, CPN_OP_BILINEAR = 3, CPN_OP_CONV_DEFERRED = 4,
@@ -210,7 +211,8 @@ int cpn_convert_input_stem(const void *src, int32_t in_dtype, void *dst, int32_t
 int cpn_stem7(const cpn_op_desc *op, const void *src, void *dst, int32_t dst_stride, int32_t N, int32_t H, int32_t W,
               const void *weights, const float *bias, float out_inv_scale, void *stream);
 /* Fused bottleneck head (see CPN_OP_CONV_PAIR; `op`: such a descriptor, `weights` / `bias`: the blobs its four offsets
- * index): src NHWC bf16 [N][H][W][c_stride] -> dst NHWC bf16 [N][H][W][dst_stride], channels [0, cout_b).  Returns
+ * index): src NHWC bf16 [N][H][W][c_stride] -> dst NHWC bf16 [N][Ho][Wo][dst_stride], channels [0, cout_b), Ho = (H - 1) /
+ * op->stride + 1.  Returns
  * CPN_E_UNSUPPORTED when W < 16 or between 17 and 31, or cout_b is no multiple of the slab width (run the two convs). */
 int cpn_conv_pair(const cpn_op_desc *op, const void *src, int32_t c_stride, void *dst, int32_t dst_stride, int32_t N,
                   int32_t H, int32_t W, const void *weights, const float *bias, void *stream);

@@ -26,13 +26,13 @@ def _pad32(c):
     return (c + 31) // 32 * 32
 
 
-def _pair_plan(cin, cmid, groups, seed):
+def _pair_plan(cin, cmid, groups, seed, stride=1):
     from celldetection_amd import graph
     g = torch.Generator().manual_seed(seed)
     P = graph.Plan()
     x = P.tensor(cin, 1)
     t = P.conv(x, cmid, 1, w='conv1.', bn='bn1.', act='relu')
-    P.conv(t, cmid, 3, w='conv2.', bn='bn2.', groups=groups, act='relu')
+    P.conv(t, cmid, 3, w='conv2.', bn='bn2.', groups=groups, stride=stride, act='relu')
     assert P.conv_pair()
     sd = {}
     for key, shape, kind in P.entries:
@@ -47,9 +47,10 @@ def _pair_plan(cin, cmid, groups, seed):
     return P, sd
 
 
-def run_pair(dev, *, n, h, w, cin, cmid, groups=32, seed=0):
+def run_pair(dev, *, n, h, w, cin, cmid, groups=32, seed=0, stride=1):
     from celldetection_amd import _lib, graph
-    P, sd = _pair_plan(cin, cmid, groups, seed)
+    P, sd = _pair_plan(cin, cmid, groups, seed, stride)
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
     tens, ops, wblob, bblob = graph.pack(P, sd, dev)
     g = torch.Generator().manual_seed(seed + 1)
     x = torch.randn(n, cin, h, w, generator=g).to(torch.bfloat16).float()
@@ -58,11 +59,11 @@ def run_pair(dev, *, n, h, w, cin, cmid, groups=32, seed=0):
     d0[..., :cin] = x.permute(0, 2, 3, 1).to(torch.bfloat16).to(dev)
     lib = _lib.load()
     cm = _pad32(cmid)
-    fused = torch.full((n, h, w, cm), float('nan'), dtype=torch.bfloat16, device=dev)
+    fused = torch.full((n, ho, wo, cm), float('nan'), dtype=torch.bfloat16, device=dev)
     _lib.check(lib.cpn_conv_pair(ops[2], _lib.ptr(d0), cs, _lib.ptr(fused), cm, n, h, w, _lib.ptr(wblob), _lib.ptr(bblob),
                                  _lib.stream_ptr()), 'conv_pair')
     mid = torch.full((n, h, w, cm), float('nan'), dtype=torch.bfloat16, device=dev)
-    two = torch.full((n, h, w, cm), float('nan'), dtype=torch.bfloat16, device=dev)
+    two = torch.full((n, ho, wo, cm), float('nan'), dtype=torch.bfloat16, device=dev)
     for op, src, dst, ss in ((ops[0], d0, mid, cs), (ops[1], mid, two, cm)):
         _lib.check(lib.cpn_conv2d(op, _lib.ptr(src), ss, None, 0, None, 0, _lib.ptr(dst), cm, n, h, w, _lib.ptr(wblob),
                                   _lib.ptr(bblob), _lib.stream_ptr()), 'conv2d')
@@ -70,7 +71,7 @@ def run_pair(dev, *, n, h, w, cin, cmid, groups=32, seed=0):
     w1, b1 = graph._fold(sd, P.ops[0])
     w2, b2 = graph._fold(sd, P.ops[1])
     r = F.relu(F.conv2d(x, w1.float().to(torch.bfloat16).float(), b1.float())).to(torch.bfloat16).float()
-    ref = F.relu(F.conv2d(r, w2.float().to(torch.bfloat16).float(), b2.float(), 1, 1, 1, groups))
+    ref = F.relu(F.conv2d(r, w2.float().to(torch.bfloat16).float(), b2.float(), stride, 1, 1, groups))
     nchw = lambda t: t[..., :cmid].permute(0, 3, 1, 2).float().cpu()
     return nchw(fused), nchw(two), ref
 
@@ -93,6 +94,12 @@ PAIR_CASES = {
     'gen_w63_ragged': dict(n=2, h=37, w=63, cin=32, cmid=128, groups=16, seed=13),
     'gen_w40_cpg16': dict(n=1, h=16, w=40, cin=96, cmid=512, groups=32, seed=14),
     'gen_w100_tall': dict(n=1, h=70, w=100, cin=64, cmid=128, groups=4, seed=15),
+    # stride-2 conv2 (the first block of a stage): 16 x 32 input tiles -> 8 x 16 outputs
+    's2_w128_layer2_first': dict(n=2, h=128, w=128, cin=256, cmid=512, groups=32, stride=2, seed=16),
+    's2_w64_layer3_first': dict(n=1, h=64, w=64, cin=128, cmid=1024, groups=32, stride=2, seed=17),
+    's2_w32_cpg64_layer4_first': dict(n=2, h=32, w=32, cin=64, cmid=256, groups=4, stride=2, seed=18),
+    's2_odd_sizes': dict(n=1, h=37, w=63, cin=32, cmid=128, groups=16, stride=2, seed=19),
+    's2_w50_cpg8': dict(n=3, h=20, w=50, cin=64, cmid=256, groups=32, stride=2, seed=20),
 }
 
 
@@ -133,7 +140,7 @@ def test_plan_picks_the_fused_pair_per_input_size(dev, size, fused, monkeypatch)
     x = torch.rand(1, 3, *size, generator=torch.Generator().manual_seed(0)).to(dev)
     eng = m.engine(dev)
     n_pair = sum(o['op'] == 'conv_pair' for o in eng.plan.ops)
-    assert n_pair == 3 + 4 + 6 + 3 - 3  # every block of the four stages except the three stride-2 ones
+    assert n_pair == 3 + 4 + 6 + 3  # every block of the four stages (the three stride-2 ones included)
     prof = eng.profile(x, m.core.order, True)
     ran = [p for p in prof if p['op'] == 'conv_pair' and p['gflop'] > 0]
     assert bool(ran) == fused, [(p['name'], p['gflop']) for p in prof if p['op'] == 'conv_pair']
@@ -150,7 +157,8 @@ def test_plan_picks_the_fused_pair_per_input_size(dev, size, fused, monkeypatch)
 
 def test_fused_pairs_run_by_default_where_they_fill_the_chip(dev):
     """Batch 16 of 256^2 tiles through a ResNeXt101 (32x8d) encoder: stage 1 (64 pixels wide, 256 channels) gives 16 x 8 x 2 =
-    256 workgroups -> fused by default; the deeper stages (128 / 64 workgroups) keep the two convs.  Same head maps either way."""
+    256 workgroups -> fused by default, like the stride-2 block heads of stages 2 / 3; the stride-1 blocks of the deeper stages
+    (128 / 64 workgroups) keep the two convs.  Same head maps either way."""
     import os
     import celldetection_amd as cda
     from celldetection_amd.synth import synth_state_dict
@@ -161,7 +169,9 @@ def test_fused_pairs_run_by_default_where_they_fill_the_chip(dev):
     x = torch.rand(16, 3, 256, 256, generator=torch.Generator().manual_seed(0)).to(dev)
     prof = m.engine(dev).profile(x, m.core.order, True)
     ran = [p['name'] for p in prof if p['op'] == 'conv_pair' and p['gflop'] > 0]
-    assert len(ran) == 3 and all('body.1.1.' in r for r in ran), ran
+    # stage 1 (three blocks, strips) + the stride-2 heads of stages 2 and 3 (generic tiles: 512 / 256 workgroups)
+    assert len(ran) == 5 and sum('body.1.1.' in r for r in ran) == 3 and any('body.2.0.' in r for r in ran) and \
+        any('body.3.0.' in r for r in ran), ran
     got = [t.clone() for t in m.core_forward(x)]
     os.environ['CPN_PAIR'] = '0'
     try:

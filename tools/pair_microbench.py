@@ -18,6 +18,9 @@ CASES = {  # ResNeXt101 32x8d stages at 16 x 512^2 (l2 / l3 / l4) and 16 x 256^2
     'l2': dict(n=16, h=64, w=64, cin=512, cmid=512, groups=32),
     'l4': dict(n=16, h=16, w=16, cin=2048, cmid=2048, groups=32),
     'l1': dict(n=16, h=128, w=128, cin=256, cmid=256, groups=32),  # generic 16 x 32 tiles
+    'l2s': dict(n=16, h=128, w=128, cin=256, cmid=512, groups=32, stride=2),   # first blocks of stages 2 / 3 / 4: stride-2 conv2
+    'l3s': dict(n=16, h=64, w=64, cin=512, cmid=1024, groups=32, stride=2),
+    'l4s': dict(n=16, h=32, w=32, cin=1024, cmid=2048, groups=32, stride=2),
     'l1_256': dict(n=16, h=64, w=64, cin=256, cmid=256, groups=32),
     'l2_256': dict(n=16, h=32, w=32, cin=512, cmid=512, groups=32),
     'l3_256': dict(n=16, h=16, w=16, cin=1024, cmid=1024, groups=32),
@@ -31,11 +34,13 @@ def main():
     for name in (sys.argv[1:] or list(CASES)):
         c = CASES[name]
         n, h, w, cin, cmid = c['n'], c['h'], c['w'], c['cin'], c['cmid']
-        P, sd = _pair_plan(cin, cmid, c['groups'], 0)
+        st = c.get('stride', 1)
+        P, sd = _pair_plan(cin, cmid, c['groups'], 0, st)
+        ho, wo = (h - 1) // st + 1, (w - 1) // st + 1
         tens, ops, wblob, bblob = graph.pack(P, sd, dev)
         x = torch.randn(n, h, w, _pad32(cin), device=dev).to(torch.bfloat16)
         mid = torch.empty(n, h, w, cmid, dtype=torch.bfloat16, device=dev)
-        out = torch.empty(n, h, w, cmid, dtype=torch.bfloat16, device=dev)
+        out = torch.empty(n, ho, wo, cmid, dtype=torch.bfloat16, device=dev)
         out2 = torch.empty_like(out)
 
         def fused():
@@ -62,7 +67,7 @@ def main():
         t_2 = timed(lambda: conv(1, mid, out2))
         t_12 = timed(lambda: (conv(0, x, mid), conv(1, mid, out2)))
         same = torch.equal(out, out2)
-        gf = 2. * n * h * w * cmid * (cin + cmid // c['groups'] * 9) / 1e9
+        gf = 2. * n * cmid * (h * w * cin + ho * wo * cmid // c['groups'] * 9) / 1e9
         print(f'{name:8s} fused {t_f:7.1f} us   conv1 {t_1:6.1f} + conv2 {t_2:6.1f} = {t_1 + t_2:6.1f} (back to back {t_12:6.1f}) us   '
               f'x{t_12 / t_f:.2f}   {gf / t_f * 1e3:7.1f} TF/s algorithmic   identical={same}', flush=True)
 
