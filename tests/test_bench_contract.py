@@ -8,7 +8,7 @@ import os
 import pytest
 
 P = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles')
-LINES = sorted(glob.glob(os.path.join(P, 'r03_bench_*.json')))
+LINES = sorted(glob.glob(os.path.join(P, 'r03_bench_*.json')) + glob.glob(os.path.join(P, 'r04_bench_*.json')))
 
 
 def _load(path):
@@ -70,3 +70,44 @@ def test_score_gated_line_prices_executed_flops():
     assert r['frac'] < r['algorithmic_frac']  # never the reference graph's FLOPs over the gated time
     dense = _load(os.path.join(P, 'r03_bench_n1.json'))
     assert d['value'] > 1.25 * dense['value'] and ex < 0.7 * dense['roofline']['executed_gflop_per_launch']
+
+
+def test_round_four_lines_are_committed():
+    names = {os.path.basename(p) for p in LINES}
+    for want in ('r04_bench_n1.json', 'r04_bench_slide_n1.json', 'r04_bench_slide_4096_rccl_1rank.json',
+                 'r04_bench_configs1_resnet18fpn.json', 'r04_bench_configs4_resnet50fpn_bf16.json',
+                 'r04_bench_configs4_resnet50fpn_fp8.json', 'r04_bench_fp8_n1.json'):
+        assert want in names, want
+
+
+def test_round_four_headline_carries_the_gated_default_and_the_synchronous_rate():
+    """the dense reference graph stays the headline `value`; the product default (score-gated heads)
+    is timed in the SAME run at two stated proposal densities with the roofline on executed FLOPs, and so is the rate a
+    forward()-per-batch caller gets."""
+    d = _load(os.path.join(P, 'r04_bench_n1.json'))
+    assert 'configs[2]' in d['config']['workload'] and d['config']['heads'] == 'dense (reference graph)' and d['steps'] >= 50
+    assert 'cpu_baseline' in d and d['cpu_baseline']['kind'] == 'port'
+    dense_exec = d['roofline']['executed_gflop_per_launch']
+    g = d['gated']
+    assert "'auto'" in g['mode'] and len(g['lines']) == 2
+    for line, target in zip(g['lines'], (.01, .10)):
+        assert line['target_density'] == target and abs(line['density'] - target) < 1e-3
+        tiles = d['config']['tiles_per_gpu_per_step']
+        assert abs(line['value'] - tiles / (line['ms_per_step'] / 1e3)) / line['value'] < 1e-6
+        ex = line['executed_gflop_per_step']
+        assert abs(line['roofline_frac_executed'] - ex / line['ms_per_step'] / 2500.) < 1e-9
+        assert line['sparse_kernel_gflop_per_step'] < ex < 0.7 * dense_exec        # two of the three 7x7 heads are gone
+        assert line['roofline_frac_executed'] < line['algorithmic_frac'] < 0.9    # never the dense FLOPs over the gated time
+        assert line['value'] > 1.25 * d['value'] and line['conv_graph_ms'] <= line['ms_per_step'] * 1.01
+    assert g['lines'][0]['value'] > g['lines'][1]['value']  # more proposals, more gathered work
+    sf = d['sync_forward']
+    assert 0.9 * d['value'] < sf['value'] <= d['value'] * 1.02 and sf['conv_graph_ms'] < sf['ms_per_step']
+
+
+def test_round_four_slide_lines():
+    for name, floor in (('r04_bench_slide_n1.json', 480.), ('r04_bench_slide_4096_rccl_1rank.json', 480.)):
+        d = _load(os.path.join(P, name))
+        assert d['scaling'] == 'strong' and d['value'] > floor, (name, d['value'])
+        g = d['gated']
+        assert g['identical_to_dense'] is True and g['value'] > 1.2 * d['value']
+    assert _load(os.path.join(P, 'r04_bench_slide_4096_rccl_1rank.json'))['config']['world_size_seen_by_rccl'] == 1
