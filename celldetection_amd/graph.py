@@ -51,11 +51,13 @@ class Plan:
 
     def conv(self, src0, cout, k, *, w, bn=None, bias=False, stride=1, pad=None, groups=1, act='none', act_scale=0.,
              src1=None, up0=False, up1=False, res=None, res_up=False, out_index=None, fuse=None, deferred=False,
-             sub=None, dst=None):
+             sub=None, dst=None, share=None):
         """Adds conv(+BN)(+residual)(+act); returns the destination tensor id (None for external outputs).
         ``sub``: member of a sub-pixel triple (``_subpixel_pair``): 'head' = the conv as the reference states it, ('phase',
         c0) / ('lateral', c0) = its decomposition (they share the head's state-dict entries and add none); ``dst``: write
-        into an existing tensor (the lateral op writes the head's destination)."""
+        into an existing tensor (the lateral op writes the head's destination).  ``share`` = (first, last input channel of
+        the conv stated by the keys ``w`` / ``bn``, with_bias): the op applies only that channel range of a conv whose state-dict
+        entries the caller registers itself (``_head_input``: Fuse2d over three features as two partial 1x1 convs)."""
         pad = k // 2 if pad is None else pad
         t0 = self.tensors[src0]
         if up0 == 'bilinear':  # source read through a bilinear resize to the input size (nominal down factor 1)
@@ -72,9 +74,9 @@ class Plan:
         if scatter:
             assert t0['down'] % 2 == 0 and src1 is None and not up0 and k == 2
             down_out = t0['down'] // 2
-        member = isinstance(sub, tuple) and not scatter  # phase / lateral op of a triple: no state-dict entries of its own
+        member = (isinstance(sub, tuple) and not scatter) or share is not None  # no state-dict entries of its own
         if dst is None:
-            dst = self.tensor(cout, down_out, phases=4 if (member and sub[0] == 'phase') else 1) if out_index is None else None
+            dst = self.tensor(cout, down_out, phases=4 if (isinstance(sub, tuple) and sub[0] == 'phase') else 1) if out_index is None else None
         if not member:
             self.conv_keys(w, cout, cin // groups, 3 if scatter else k, bias)
             if bn is not None:
@@ -83,7 +85,8 @@ class Plan:
                 self.conv_keys(fuse['w'], fuse['cout'], cout, 1, True)
         self.ops.append(dict(op='conv', src0=src0, src1=src1, res=res, dst=dst, up0=up0, up1=up1, res_up=res_up, k=k,
                              stride=stride, pad=pad, groups=groups, cin=cin, cout=cout, w=w, bn=bn, bias=bias, act=act,
-                             act_scale=act_scale, out_index=out_index, fuse=fuse, deferred=bool(deferred), sub=sub))
+                             act_scale=act_scale, out_index=out_index, fuse=fuse, deferred=bool(deferred), sub=sub,
+                             share=share))
         return dst
 
     def conv_pair(self):
@@ -394,8 +397,8 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
     (the reference's ``kernel_size_<head>`` kwargs, default 7).  ``contour_head_stride`` / ``refinement_head_stride``: stride
     (1 or 2) of the k x k conv of the ReadOut heads (commons.py:494).  ``features``: optional {'score'|'location'|
     'contour'|'uncertainty'|'refinement': key or [key, key]} = the reference's ``<head>_features`` kwargs (cpn.py:135-139):
-    decoder level '0', '1', ... or 'encoder.<k>' (UNet family); two keys are fused like ``Fuse2d`` (commons.py:640-674:
-    the second feature nearest-resized to the first one's size, concat, 1x1 conv + BN + ReLU).
+    decoder level '0', '1', ... or 'encoder.<k>' (UNet family); two or three keys are fused like ``Fuse2d``
+    (commons.py:640-674: the other features nearest-resized to the first one's size, concat, 1x1 conv + BN + ReLU).
     ``sparse_heads``: score-gated location / Fourier heads -- CPN.forward reads their maps at the proposal pixels only
     (cpn.py:613-637), so the two convs are packed but not executed by the graph (``deferred`` ops) and evaluated at the
     proposals by ``ops.sparse_heads``; needs both heads fused, on the same plain feature, stride 1, same kernel size
@@ -458,11 +461,22 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
         (t0, ch0) = level[keys[0]]
         if len(keys) == 1:
             return t0, ch0
-        if len(keys) > 2:
-            raise NotImplementedError('Fuse2d over more than two features is not supported on the HIP path')
-        (t1, _) = level[keys[1]]
-        t = P.conv(t0, ch0, 1, w=fuse_prefix + 'block.0.', bn=fuse_prefix + 'block.1.', bias=True, act='relu', src1=t1,
-                   up1=True)
+        if len(keys) > 3:
+            raise NotImplementedError('Fuse2d over more than three features is not supported on the HIP path')
+        (t1, ch1) = level[keys[1]]
+        w_, bn_ = fuse_prefix + 'block.0.', fuse_prefix + 'block.1.'
+        if len(keys) == 2:
+            t = P.conv(t0, ch0, 1, w=w_, bn=bn_, bias=True, act='relu', src1=t1, up1=True)
+            return t, ch0
+        # three features: conv1x1(cat(f0, f1^, f2^)) = conv1x1 over [f0 | f1^] + (conv1x1 over f2)^ -- a 1x1 conv commutes with
+        # the nearest resize, so the third feature's share runs at ITS resolution (no bias, BN scale folded) and joins as a
+        # nearest-resized residual in front of bias + ReLU (the conv kernel reads two concat sources and one residual)
+        (t2, ch2) = level[keys[2]]
+        P.conv_keys(w_, ch0, ch0 + ch1 + ch2, 1, True)
+        P.bn_keys(bn_, ch0)
+        part = P.conv(t2, ch0, 1, w=w_, bn=bn_, bias=True, share=(ch0 + ch1, ch0 + ch1 + ch2, False))
+        t = P.conv(t0, ch0, 1, w=w_, bn=bn_, bias=True, act='relu', src1=t1, up1=True, res=part, res_up=True,
+                   share=(0, ch0 + ch1, True))
         return t, ch0
 
     f1s, c1 = _head_input('score', 'core.score_fuse.')
@@ -646,6 +660,11 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=Non
             raise ValueError('sub-pixel conv triples are a bf16-plan feature')
         if isinstance(sub, tuple) and sub[0] == 'lateral':  # the lateral's share of the head conv's weights (+ its bias)
             w = w[:, :sub[1]]
+        if op.get('share') is not None:  # a channel range of the stated conv; its (BN-folded) bias travels with ONE of the parts
+            lo, hi, with_bias = op['share']
+            w = w[:, lo:hi]
+            if not with_bias:
+                b = torch.zeros_like(b)
         phase = isinstance(sub, tuple) and sub[0] in ('phase', 'scatter')
         if phase:  # four 2 x 2 kernels on the low-resolution map (tap sums in float64, rounded to bf16 once)
             from .subpixel import collapse_upsampled_taps

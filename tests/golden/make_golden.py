@@ -90,6 +90,12 @@ MODEL_SPECS = {
                                                    location_features=['1', '2'], backbone_kwargs={
                                                        'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}),
                             (1, 3, 64, 96)),
+    # Fuse2d over THREE features (the HIP plan splits the 1x1 conv: two concat sources + one nearest-resized residual)
+    'CpnResNet18FPN_fuse3': ('CpnResNet18FPN', dict(in_channels=3, score_features=['1', '2', '3'],
+                                                    contour_features=['1', '2', '3'], location_features=['1', '3', '2'],
+                                                    refinement_features=['0', '1', '2'], backbone_kwargs={
+                                                        'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}),
+                             (1, 3, 64, 96)),
     'CpnResNet50UNet_feats': ('CpnResNet50UNet', dict(in_channels=3, score_features='2', contour_features='2',
                                                       location_features='2', refinement_features=['0', 'encoder.0'],
                                                       backbone_kwargs={'backbone_kwargs': {'base_channel': 8}}),
@@ -249,7 +255,8 @@ MODEL_CALIBRATION = {'CpnU22_classes4': dict(score_shift=-3.5),
                      'CpnU22_strided': dict(score_shift=0., fourier_std=.12, location_std=.3),
                      'CpnU22_odd': dict(score_shift=-1.5, fourier_std=.25, location_std=.4),
                      'CpnResNet50UNet_feats': dict(score_shift=-.3, fourier_std=.25, location_std=.4),
-                     'CpnResNet18FPN_fuse': dict(score_shift=-.5, fourier_std=.4, location_std=.4)}
+                     'CpnResNet18FPN_fuse': dict(score_shift=-.5, fourier_std=.4, location_std=.4),
+                     'CpnResNet18FPN_fuse3': dict(score_shift=.5, fourier_std=.4, location_std=.4, refinement_raw_std=.3)}
 
 
 def gen_model(name, seed=0):

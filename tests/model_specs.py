@@ -65,6 +65,12 @@ HEAD_SPECS = {
         in_channels=3, score_features=['1', '2'], contour_features=['1', '2'], location_features=['1', '2'],
         backbone_kwargs={'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}), cpn_kwargs=dict(_DEF),
         core_kwargs=dict(features=dict(score=['1', '2'], contour=['1', '2'], location=['1', '2']))),
+    'CpnResNet18FPN_fuse3': dict(cls='CpnResNet18FPN', kwargs=dict(
+        in_channels=3, score_features=['1', '2', '3'], contour_features=['1', '2', '3'], location_features=['1', '3', '2'],
+        refinement_features=['0', '1', '2'],
+        backbone_kwargs={'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}), cpn_kwargs=dict(_DEF),
+        core_kwargs=dict(features=dict(score=['1', '2', '3'], contour=['1', '2', '3'], location=['1', '3', '2'],
+                                       refinement=['0', '1', '2']))),
     'CpnResNet50UNet_feats': dict(cls='CpnResNet50UNet', kwargs=dict(
         in_channels=3, score_features='2', contour_features='2', location_features='2',
         refinement_features=['0', 'encoder.0'], backbone_kwargs=_R8), cpn_kwargs=dict(_DEF),
