@@ -17,6 +17,7 @@ E_INVALID, E_UNSUPPORTED, E_WORKSPACE = -1, -2, -3
 OP_INPUT, OP_CONV, OP_MAXPOOL, OP_BILINEAR, OP_CONV_DEFERRED, OP_INPUT_STEM, OP_STEM7, OP_CONV_PAIR = 0, 1, 2, 3, 4, 5, 6, 7
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH_SCALED = 0, 1, 2, 3
 SUBPIXEL_NONE, SUBPIXEL_HEAD, SUBPIXEL_PHASE, SUBPIXEL_LATERAL, SUBPIXEL_SCATTER = 0, 1, 2, 3, 4
+SUBPIXEL_BL_HEAD, SUBPIXEL_BL_PHASE, SUBPIXEL_BL_FRAME = 5, 6, 7
 OUT_SCORES, OUT_LOCATIONS, OUT_FOURIER, OUT_REFINEMENT, OUT_UNCERTAINTY = 0, 1, 2, 3, 4
 NUM_OUTPUTS = 5
 

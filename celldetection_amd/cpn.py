@@ -398,12 +398,13 @@ class CPN(nn.Module):
         #   False             the reference's dense graph everywhere
         self.sparse_heads = 'auto'
         self._fp8_scales = None
-        # sub-pixel decomposition of the UNet decoder convs over x2-upsampled maps (bf16 plans; graph._two_conv_norm_relu):
-        # 4/9 of the MACs on the upsampled channels, taken wherever the upsampling is an exact x2.  A run-time switch.
+        # sub-pixel decompositions (bf16 plans), taken wherever the resize is an exact x2; ONE run-time switch for both:
+        # * UNet decoder convs over nearest-upsampled maps (graph._two_conv_norm_relu): 4/9 of the MACs on the upsampled channels
+        # * the refinement head over the bilinear-resized feature map of the FPN models (graph._readout): 25 instead of 49 taps
         self.subpixel = True
         # bf16: fused ReadOut tails + fused bilinear head source + sub-pixel decoder convs + stem kernel + fused bottleneck
         # heads (conv1 -> grouped conv2 of the ResNeXt blocks, csrc/conv_pair.hip; the executor picks per input size)
-        self._plan = graph.build_plan(**self._plan_kwargs, subpixel=True, stem_fast=True, fuse_blocks=True)
+        self._plan = graph.build_plan(**self._plan_kwargs, subpixel=True, stem_fast=True, fuse_blocks=True, bilinear_phases=True)
         self._alt_plans = {}
         for key, shape, kind in self._plan.entries:
             _register(self, key, shape, kind)
@@ -454,7 +455,7 @@ class CPN(nn.Module):
                 return self._plan
             if key not in self._alt_plans:
                 self._alt_plans[key] = graph.build_plan(**self._plan_kwargs, sparse_heads=key[0], subpixel=key[1],
-                                                        stem_fast=True, fuse_blocks=True)
+                                                        stem_fast=True, fuse_blocks=True, bilinear_phases=key[1])
             return self._alt_plans[key]
         if precision not in self._alt_plans:
             # fp8: the resize stays its own op and the ResNet stem takes its bf16 fast path (e4m3 output); fp32: nothing fused

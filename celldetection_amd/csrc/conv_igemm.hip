@@ -358,7 +358,12 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
                                                       // the K loop has no conditional tail)
     const int cout_b = a.cout_b;
     const int cin0 = a.phase ? 0 : g * a.cin_b;  // (sub-pixel phase conv: the four phases read the same channels)
-    const int pad_y = a.pad - (a.phase ? (g >> 1) : 0), pad_x = a.pad - (a.phase ? (g & 1) : 0);
+    const bool shift_pad = a.phase == 1 || a.phase == 2;  // (phase 3, bilinear phases: one symmetric support for all four)
+    const int pad_y = a.pad - (shift_pad ? (g >> 1) : 0), pad_x = a.pad - (shift_pad ? (g & 1) : 0);
+    if (a.region == 2) {  // frame-only launch: a tile inside the box another op produces has nothing to do
+        const int m = a.region_margin;
+        if (oy0 >= m && oy0 + TH <= a.Hout - m && ox0 >= m && ox0 + TW <= a.Wout - m) return;
+    }
     const int c0_used = a.c0_used;
     constexpr int WITEM = BN * REC;   // one item's weight slab tile
     constexpr int WBUF = 2 * WITEM;   // one step's weights
@@ -946,6 +951,8 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
         constexpr int SW = SPR >= 16 ? 16 : SPR;           // swizzle period
         constexpr int PSH = SPR >= 16 ? 0 : (SPR == 8 ? 1 : 2);
         constexpr int RPW = TH / C::NWAVES;                // pixel rows per wave in the second GEMM
+        const bool hscat = a.phase == 3;                   // bilinear phases: shared bias / multipliers, scattered planes
+        const int gb = hscat ? 0 : g * cout_b;
         __syncthreads();
 #pragma unroll
         for (int f = 0; f < WM; ++f) {
@@ -959,8 +966,8 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[j][f][q * 4 + e] * (CPN_FP8 && a.mult ? a.mult[g * cout_b + cb + e] : 1.f) +
-                               (a.bias ? a.bias[g * cout_b + cb + e] : 0.f);
+                        v[e] = acc[j][f][q * 4 + e] * (CPN_FP8 && a.mult ? a.mult[gb + cb + e] : 1.f) +
+                               (a.bias ? a.bias[gb + cb + e] : 0.f);
                         if (a.act == ACT_RELU) v[e] = fmaxf(v[e], 0.f);
                     }
                     u32x2 o;
@@ -988,6 +995,14 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
             }
             const int oy = oy0 + row, ox = ox0 + l31;
             if (oy >= a.Hout || ox >= a.Wout) continue;
+            if (a.region) {  // 1: only inside the box [m, H - m) x [m, W - m); 2: only outside it
+                const int m = a.region_margin;
+                const bool inside = oy >= m && oy < a.Hout - m && ox >= m && ox < a.Wout - m;
+                if (inside != (a.region == 1)) continue;
+            }
+            // (bilinear phases: phase g = (py, px) owns pixel (2 oy + py, 2 ox + px) of the [2 Hout][2 Wout] planes)
+            const int ph = hscat ? 2 * a.Hout : a.Hout, pw = hscat ? 2 * a.Wout : a.Wout;
+            const int py_ = hscat ? 2 * oy + (g >> 1) : oy, px_ = hscat ? 2 * ox + (g & 1) : ox;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int c2 = (e & 3) + 8 * (e >> 2) + 4 * lhi;
@@ -996,7 +1011,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
                 if (a.fuse_act == ACT_RELU) x = fmaxf(x, 0.f);
                 else if (a.fuse_act == ACT_SIGMOID) x = 1.f / (1.f + expf(-x));
                 else if (a.fuse_act == ACT_TANH_SCALED) x = tanhf(x) * a.fuse_scale;
-                ((float *) a.dst)[(((size_t) n * a.fuse_cout + c2) * a.Hout + oy) * a.Wout + ox] = x;
+                ((float *) a.dst)[(((size_t) n * a.fuse_cout + c2) * ph + py_) * pw + px_] = x;
             }
         }
       }
@@ -1041,7 +1056,7 @@ struct TileChoice {
 // but the output and a same-size residual
 static bool narrow_ok(const ConvArgs &a) {
     return !CPN_FP8 && a.Wout == 16 && a.Hout % 2 == 0 && a.stride == 1 && !(a.KH == 1 && a.KW == 1 && a.pad == 0) &&
-           a.up0 != 2 && a.res_up == 0 && a.phase != 2 && a.KW <= 17;
+           a.up0 != 2 && a.res_up == 0 && a.phase != 2 && a.phase != 3 && a.region == 0 && a.KW <= 17;
 }
 
 static int conv_mode(const ConvArgs &a) {
@@ -1155,13 +1170,16 @@ int launch_conv(const ConvArgs &a_in, hipStream_t stream) {
         a.Wout = 32;
     }
     if (a.cin_b % CH || a.cout_b % 32 || a.c0_used % CH) return (int) hipErrorInvalidValue;
+    if (a.phase == 3 && (a.out_mode != OUT_FUSED_HEAD || a.bundles != 4 || a.stride != 1)) return (int) hipErrorInvalidValue;
+    if ((a.region == 1 || a.region == 2) ? (a.out_mode != OUT_FUSED_HEAD || a.region_margin < 0) : a.region != 0)
+        return (int) hipErrorInvalidValue;  // (region masks live in the fused-head epilogue)
     if (a.stride != 1 && a.stride != 2) return (int) hipErrorInvalidValue;
     if (a.up0 == 2 && (CPN_FP8 || a.stride != 1 || a.src1 || a.up1 || (a.KH == 1 && a.KW == 1)))
         return (int) hipErrorInvalidValue;  // bilinear source: single-source KxK stride-1 convs of the bf16 path only
     if ((a.stride == 1 && a.KW > 17) || (a.stride == 2 && a.KW > 18)) return (int) hipErrorInvalidValue;
     TileChoice c = choose_tile(a);
     if (a.out_mode == OUT_FUSED_HEAD) {  // the block must own all output channels; TH multiple of the wave count
-        if (a.bundles != 1 || (a.cout_b != 256 && a.cout_b != 128 && a.cout_b != 64 && a.cout_b != 32))
+        if (a.bundles != (a.phase == 3 ? 4 : 1) || (a.cout_b != 256 && a.cout_b != 128 && a.cout_b != 64 && a.cout_b != 32))
             return (int) hipErrorInvalidValue;
         c.BN = a.cout_b;
         c.TH = (a.cout_b == 64 && c.TH == 16) ? 16 : 8;
@@ -1186,7 +1204,14 @@ int launch_conv(const ConvArgs &a_in, hipStream_t stream) {
 }
 
 double conv_executed_flops(const ConvArgs &a) {
-    return 2.0 * a.N * a.Hout * a.Wout * (double) a.bundles * a.cout_b * a.cin_b * a.KH * a.KW;
+    double px = (double) a.Hout * a.Wout;
+    if (a.region == 2) {  // frame-only launch: the tiles inside the box exit at once (8 x 32 tiles of the fused-head kernels)
+        const int m = a.region_margin;
+        const int ty0 = (m + 7) / 8, ty1 = (a.Hout - m) / 8, tx0 = (m + 31) / 32, tx1 = (a.Wout - m) / 32;  // tiles fully inside
+        const double inner = (double) std::max(ty1 - ty0, 0) * std::max(tx1 - tx0, 0) * 256.;
+        px = (double) ((a.Hout + 7) / 8) * ((a.Wout + 31) / 32) * 256. - inner;
+    }
+    return 2.0 * a.N * px * (double) a.bundles * a.cout_b * a.cin_b * a.KH * a.KW;
 }
 
 }  // namespace CPN_NS

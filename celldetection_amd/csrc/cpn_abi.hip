@@ -103,6 +103,26 @@ static void propagate_dims(const cpn_plan *p, int N, int H, int W, ShapePlan &sp
             sp.skip[oi] = exact;
             sp.skip[oi + 1] = sp.skip[oi + 2] = !exact;
         }
+        if (o.op == CPN_OP_CONV && o.subpixel == CPN_SUBPIXEL_BL_HEAD) {
+            // bilinear phases + frame instead of the conv over the resized map wherever the resize is an exact x2
+            // (CPN_BLPHASE=0: kernel A/B switch, read when a shape is planned)
+            // ... and the decomposition executes fewer MACs than the conv it replaces: the frame is whole 8 x 32 tiles of the
+            // k x k conv, most of a small image (CPN_BLPHASE=0 / 2: never / wherever exact -- kernel A/B and tests)
+            const char *e = getenv("CPN_BLPHASE");
+            const int mode = e ? atoi(e) : 1;
+            bool exact = mode != 0 && p->precision == CPN_PRECISION_BF16 && o.up0 == 2 && 2 * sp.th[o.src0] == H &&
+                         2 * sp.tw[o.src0] == W && sp.th[o.src0] >= o.kh && sp.tw[o.src0] >= o.kw;
+            if (exact && mode != 2) {
+                const int k2 = (o.kh + 3) / 2, m = 2 * ((o.kh / 2 + 1) / 2);
+                auto tiles = [](int h, int w) { return (double) ((h + 7) / 8) * ((w + 31) / 32); };
+                const double inner = (double) std::max((H - m) / 8 - (m + 7) / 8, 0) * std::max((W - m) / 32 - (m + 31) / 32, 0);
+                const double head = tiles(H, W) * o.kh * o.kh;
+                const double parts = 4. * tiles(H / 2, W / 2) * k2 * k2 + (tiles(H, W) - inner) * o.kh * o.kh;
+                exact = parts <= 0.85 * head;
+            }
+            sp.skip[oi] = exact;
+            sp.skip[oi + 1] = sp.skip[oi + 2] = !exact;
+        }
         if (o.alt == 1 || o.alt == 2) {
             // stem alternatives: the fast pair (padded 4-channel input layout inside the input tensor's storage + the
             // dedicated 7x7 stride-2 kernel) wherever that layout fits, the generic pair otherwise
@@ -152,6 +172,7 @@ static void propagate_dims(const cpn_plan *p, int N, int H, int W, ShapePlan &sp
                     sp.th[o.dst] = sp.th[o.src0]; sp.tw[o.dst] = sp.tw[o.src0];
                     break;
                 }
+                if (o.subpixel == CPN_SUBPIXEL_BL_PHASE) break;  // (writes the BL_HEAD op's external output: sized there)
                 if (o.subpixel == CPN_SUBPIXEL_SCATTER) {  // conv over the x2-upsampled source (scale_factor = 2)
                     if (o.dst < 0) { bad("conv: a sub-pixel scatter conv needs a tensor destination"); break; }
                     sp.th[o.dst] = 2 * sp.th[o.src0]; sp.tw[o.dst] = 2 * sp.tw[o.src0];
@@ -264,7 +285,24 @@ static int build_conv_args(const cpn_plan *p, const cpn_op_desc &o, int N, ConvA
     a.Hout = (Hin + 2 * o.pad - o.kh) / o.stride + 1;
     a.Wout = (Win + 2 * o.pad - o.kw) / o.stride + 1;
     a.phase = o.subpixel == CPN_SUBPIXEL_PHASE ? 1 : (o.subpixel == CPN_SUBPIXEL_SCATTER ? 2 : 0);
-    if (a.phase) {  // four 2 x 2 convs (one per output phase, padding (1 - py, 1 - px)) on the low-resolution map
+    if (o.subpixel == CPN_SUBPIXEL_BL_PHASE) {
+        // four k2 x k2 convs on the low-resolution map, one symmetric support (pad k2 / 2) and one bias for all phases, fused
+        // ReadOut tail scattered to the [2 Hin][2 Win] planes; the frame of k2 / 2 low-resolution pixels belongs to BL_FRAME
+        if (o.kh != o.kw || o.kh % 2 == 0 || o.pad != o.kh / 2 || o.stride != 1 || o.bundles != 4 || s1 || o.up0 || res ||
+            o.fuse_cout <= 0 || o.dst >= 0)
+            return fail(CPN_E_INVALID, "conv: a bilinear phase conv is k2 x k2, pad k2 / 2, stride 1, 4 bundles, one plain source, "
+                                       "fused ReadOut tail");
+        a.phase = 3;
+        a.region = 1;
+        a.region_margin = o.kh / 2;
+        a.Hout = Hin; a.Wout = Win;
+    }
+    if (o.subpixel == CPN_SUBPIXEL_BL_FRAME) {  // the conv over the resized map, frame only: k = 2 k2 - 3 -> F = 2 (k2 / 2)
+        if (o.up0 != 2 || o.fuse_cout <= 0 || o.dst >= 0) return fail(CPN_E_INVALID, "conv: a bilinear frame conv is a fused ReadOut head over a bilinear source");
+        a.region = 2;
+        a.region_margin = 2 * ((o.kh / 2 + 1) / 2);
+    }
+    if (a.phase == 1 || a.phase == 2) {  // four 2 x 2 convs (one per output phase, padding (1 - py, 1 - px)) on the low-resolution map
         if (o.kh != 2 || o.kw != 2 || o.pad != 1 || o.stride != 1 || o.bundles != 4 || s1 || o.up0 || res)
             return fail(CPN_E_INVALID, "conv: a sub-pixel phase conv is 2x2, pad 1, stride 1, 4 bundles, one plain source");
         a.Hout = Hin; a.Wout = Win;
@@ -367,6 +405,21 @@ int cpn_plan_create(cpn_plan **plan, const cpn_tensor_desc *tensors, int32_t n_t
             delete p;
             return fail(CPN_E_INVALID, "cpn_plan_create: malformed sub-pixel triple (HEAD, PHASE, LATERAL)");
         }
+        if (o.subpixel == CPN_SUBPIXEL_BL_HEAD &&
+            (o.op != CPN_OP_CONV || precision != CPN_PRECISION_BF16 || oi_ + 2 >= p->ops.size() || o.up0 != 2 || o.dst >= 0 ||
+             o.fuse_cout <= 0 || o.kh != o.kw || o.kh % 4 != 3 || p->ops[oi_ + 1].subpixel != CPN_SUBPIXEL_BL_PHASE ||
+             p->ops[oi_ + 2].subpixel != CPN_SUBPIXEL_BL_FRAME || p->ops[oi_ + 1].op != CPN_OP_CONV || p->ops[oi_ + 2].op != CPN_OP_CONV ||
+             p->ops[oi_ + 1].src0 != o.src0 || p->ops[oi_ + 2].src0 != o.src0 || p->ops[oi_ + 1].out_index != o.out_index ||
+             p->ops[oi_ + 2].out_index != o.out_index || p->ops[oi_ + 1].kh != (o.kh + 3) / 2 || p->ops[oi_ + 2].kh != o.kh ||
+             p->ops[oi_ + 2].up0 != 2 || p->ops[oi_ + 1].fuse_cout != o.fuse_cout || p->ops[oi_ + 2].fuse_cout != o.fuse_cout)) {
+            delete p;
+            return fail(CPN_E_INVALID, "cpn_plan_create: malformed bilinear sub-pixel triple (BL_HEAD, BL_PHASE, BL_FRAME)");
+        }
+        if ((o.subpixel == CPN_SUBPIXEL_BL_PHASE && (oi_ < 1 || p->ops[oi_ - 1].subpixel != CPN_SUBPIXEL_BL_HEAD)) ||
+            (o.subpixel == CPN_SUBPIXEL_BL_FRAME && (oi_ < 2 || p->ops[oi_ - 2].subpixel != CPN_SUBPIXEL_BL_HEAD))) {
+            delete p;
+            return fail(CPN_E_INVALID, "cpn_plan_create: bilinear PHASE / FRAME ops must follow their BL_HEAD op");
+        }
         if ((o.subpixel == CPN_SUBPIXEL_PHASE && (oi_ < 1 || p->ops[oi_ - 1].subpixel != CPN_SUBPIXEL_HEAD)) ||
             (o.subpixel == CPN_SUBPIXEL_LATERAL && (oi_ < 2 || p->ops[oi_ - 2].subpixel != CPN_SUBPIXEL_HEAD))) {
             delete p;
@@ -430,7 +483,9 @@ int cpn_plan_create(cpn_plan **plan, const cpn_tensor_desc *tensors, int32_t n_t
                 return fail(CPN_E_INVALID, "cpn_plan_create: fused heads are a bf16-only feature");
             }
             if (o.weight_offset < 0 || (size_t) o.weight_offset + wbytes > weight_bytes ||
-                (o.bias_offset >= 0 && (size_t) o.bias_offset + (size_t) o.bundles * o.cout_b > bias_count)) {
+                (o.bias_offset >= 0 && (size_t) o.bias_offset + (size_t) ((o.subpixel == CPN_SUBPIXEL_SCATTER ||
+                                                                              o.subpixel == CPN_SUBPIXEL_BL_PHASE) ? 1 : o.bundles) *
+                                                                     o.cout_b > bias_count)) {  // (the four phases share one bias)
                 delete p;
                 return fail(CPN_E_INVALID, "cpn_plan_create: weight/bias offset out of range");
             }

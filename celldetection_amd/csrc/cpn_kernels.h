@@ -34,6 +34,13 @@ struct ConvArgs {
                                 // (g >> 1, g & 1) read the SAME cin_b input channels with padding (pad - py, pad - px);
                                 // 2 (CPN_SUBPIXEL_SCATTER): additionally phase g writes channels [0, cout_b) of pixel
                                 // (2 oy + py, 2 ox + px) of a [2 Hout][2 Wout] destination and all phases share one bias
+                                // 3 (CPN_SUBPIXEL_BL_PHASE): the four phases of a k x k conv over a x2 BILINEAR-upsampled map as
+                                // k2 x k2 convs on the low-resolution map (k2 = (k + 3) / 2, the SAME padding for every phase,
+                                // one shared bias); OUT_FUSED_HEAD only: phase g writes pixel (2 oy + py, 2 ox + px) of the
+                                // [2 Hout][2 Wout] planes
+    int region, region_margin;  // region 1: store only outputs with oy in [m, Hout - m) and ox in [m, Wout - m) (m = margin);
+                                // region 2: store only outputs OUTSIDE that box, workgroups whose tile lies inside it exit at
+                                // once (the frame the bilinear phase convs leave to the conv over the resized map)
     int narrow;                 // set by launch_conv (MODE_N): Hout / Wout hold the virtual [H/2][32] view of a 16-column output
     const void *res;            // residual NHWC bf16 (added before activation) or nullptr
     int res_stride, res_up;     // res_up 1: stored at Hr x Wr, nearest-resized to Hout x Wout (FPN top-down path)

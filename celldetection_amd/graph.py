@@ -71,6 +71,8 @@ class Plan:
             assert self.tensors[src1]['down'] == down_in
         down_out = down_in * stride
         scatter = isinstance(sub, tuple) and sub[0] == 'scatter'  # stands for a 3x3 conv over the x2-upsampled source
+        if isinstance(sub, tuple) and sub[0] == 'blphase':  # bilinear phases: low-resolution source, full-resolution output
+            down_out = max(t0['down'] // 2, 1)
         if scatter:
             assert t0['down'] % 2 == 0 and src1 is None and not up0 and k == 2
             down_out = t0['down'] // 2
@@ -372,13 +374,21 @@ for _k in _RESNETS:
 BACKBONES['U22'] = ('unet', 'U22')
 
 
-def _readout(P, x, cmid, cout, prefix, act, act_scale, out_index, k=7, fuse=True, up0=False, stride=1, deferred=False):
-    """ReadOut (commons.py:461-511): conv kxk(bias) -> BN -> ReLU -> Dropout2d(eval: identity) -> conv 1x1(bias)."""
+def _readout(P, x, cmid, cout, prefix, act, act_scale, out_index, k=7, fuse=True, up0=False, stride=1, deferred=False,
+             bilinear_phases=False):
+    """ReadOut (commons.py:461-511): conv kxk(bias) -> BN -> ReLU -> Dropout2d(eval: identity) -> conv 1x1(bias).
+    ``bilinear_phases`` (fused heads over a bilinear source, k = 3 (mod 4)): the op additionally carries its decomposition for
+    the exact x2 case (include/cpn_hip.h CPN_SUBPIXEL_BL_*): four k2 x k2 phase convs on the low-resolution map + the same
+    conv restricted to the image frame."""
     if fuse and FUSE_READOUT and _pad32(cmid) in (32, 64, 128, 256) and cout <= 32:
         # one kernel: conv kxk + BN + ReLU -> (bf16, LDS) -> 1x1 conv + final activation -> fp32 NCHW head map
-        P.conv(x, cmid, k, w=prefix + 'block.0.', bn=prefix + 'block.1.', bias=True, act='relu', out_index=out_index,
-               fuse=dict(w=prefix + 'block.4.', cout=cout, act=act, act_scale=act_scale), up0=up0, stride=stride,
-               deferred=deferred)
+        kw = dict(w=prefix + 'block.0.', bn=prefix + 'block.1.', bias=True, act='relu', out_index=out_index,
+                  fuse=dict(w=prefix + 'block.4.', cout=cout, act=act, act_scale=act_scale))
+        triple = bool(bilinear_phases) and up0 == 'bilinear' and k % 4 == 3 and stride == 1 and not deferred
+        P.conv(x, cmid, k, up0=up0, stride=stride, deferred=deferred, sub='blhead' if triple else None, **kw)
+        if triple:
+            P.conv(x, cmid, (k + 3) // 2, sub=('blphase', k), **kw)
+            P.conv(x, cmid, k, up0=up0, sub=('blframe', k), **kw)
         return
     assert not deferred, 'only fused ReadOut heads can be deferred'
     t = P.conv(x, cmid, k, w=prefix + 'block.0.', bn=prefix + 'block.1.', bias=True, act='relu', up0=up0, stride=stride)
@@ -391,7 +401,8 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
                contour_head_channels: int = None, refinement_head_channels: int = None,
                kernel_sizes: dict = None, fuse_bilinear: bool = True, contour_head_stride: int = 1,
                refinement_head_stride: int = 1, features: dict = None, sparse_heads: bool = False,
-               subpixel: bool = False, stem_fast: bool = False, fuse_blocks: bool = False) -> Plan:
+               subpixel: bool = False, stem_fast: bool = False, fuse_blocks: bool = False,
+               bilinear_phases: bool = False) -> Plan:
     """Plan of ``Cpn<backbone>`` (celldetection/models/cpn.py:287-439,771-2061; heads: CPNCore.__init__
     cpn.py:125-236).  ``kernel_sizes``: optional {'score'|'location'|'fourier'|'uncertainty'|'refinement': k}
     (the reference's ``kernel_size_<head>`` kwargs, default 7).  ``contour_head_stride`` / ``refinement_head_stride``: stride
@@ -408,7 +419,9 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
     ``stem_fast`` (bf16 plans, ResNet-family encoders with <= 4 input channels): the 7x7 stride-2 stem additionally carries
     its dedicated kernel on a padded 4-channel input layout (``Plan.stem_fast_path``).
     ``fuse_blocks`` (bf16 plans, ResNeXt encoders): every bottleneck block additionally carries conv1 -> grouped conv2 as
-    one fused op (``Plan.conv_pair``)."""
+    one fused op (``Plan.conv_pair``).
+    ``bilinear_phases`` (bf16 plans): the refinement head over the bilinear-resized feature map (FPN models) additionally
+    carries its sub-pixel decomposition (``_readout``)."""
     if contour_head_stride not in (1, 2) or refinement_head_stride not in (1, 2):
         raise NotImplementedError('head strides other than 1 and 2 are not supported by the HIP conv kernel')
     feats_cfg = dict(score='1', location='1', contour='1', uncertainty='1', refinement='0')
@@ -519,7 +532,7 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
             r = P.bilinear_to_input(r)
         _readout(P, r, cm0, 2 * refinement_buckets, 'core.refinement_head.', 'tanh_scaled', float(refinement_margin),
                  _lib.OUT_REFINEMENT, k=kr, fuse=fuse_readout, up0='bilinear' if fused_resize else False,
-                 stride=refinement_head_stride)
+                 stride=refinement_head_stride, bilinear_phases=bilinear_phases and fused_resize)
     P.meta = dict(backbone=backbone, order=order, head_down=scale, refinement=refinement, in_channels=in_channels,
                   score_channels=score_channels, refinement_buckets=refinement_buckets,
                   uncertainty_head=bool(uncertainty_head), sparse_heads=sparse_meta)
@@ -665,8 +678,11 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=Non
             w = w[:, lo:hi]
             if not with_bias:
                 b = torch.zeros_like(b)
-        phase = isinstance(sub, tuple) and sub[0] in ('phase', 'scatter')
-        if phase:  # four 2 x 2 kernels on the low-resolution map (tap sums in float64, rounded to bf16 once)
+        phase = isinstance(sub, tuple) and sub[0] in ('phase', 'scatter', 'blphase')
+        if isinstance(sub, tuple) and sub[0] == 'blphase':  # four k2 x k2 kernels on the low-resolution map (float64 sums)
+            from .subpixel import collapse_bilinear_taps
+            w = collapse_bilinear_taps(w).reshape(4, cout, cin, k, k)
+        elif phase:  # four 2 x 2 kernels on the low-resolution map (tap sums in float64, rounded to bf16 once)
             from .subpixel import collapse_upsampled_taps
             w = collapse_upsampled_taps(w[:, sub[1]:]).reshape(4, cout, cin, 2, 2)
         c0 = plan.tensors[op['src0']]['c']
@@ -684,11 +700,12 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=Non
         geo = _bundle_geometry(cin, cout, groups, KC)
         if phase:
             bundles, cin_b, cout_b = 4, cinp, coutp
-            dense = torch.zeros(4, coutp, cinp, 2, 2, dtype=torch.float64)
+            kk = w.shape[-1]  # 2 (nearest phases) | k2 (bilinear phases)
+            dense = torch.zeros(4, coutp, cinp, kk, kk, dtype=torch.float64)
             dense[:, :cout, :cin] = w
-            packed = dense.reshape(4, coutp, cinp // KC, KC, 4).permute(0, 2, 4, 1, 3)
+            packed = dense.reshape(4, coutp, cinp // KC, KC, kk * kk).permute(0, 2, 4, 1, 3)
             bias = None  # (partial sums; the lateral op of the triple adds the bias)
-            if sub[0] == 'scatter':  # one bias shared by the four phases
+            if sub[0] in ('scatter', 'blphase'):  # one bias shared by the four phases
                 bias = torch.zeros(coutp, dtype=torch.float64)
                 bias[:cout] = b
         elif geo is None:
@@ -757,7 +774,8 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=Non
             bparts.append(bias.to(torch.float32))
         d.op = _lib.OP_CONV_DEFERRED if op.get('deferred') else _lib.OP_CONV
         d.subpixel = {None: _lib.SUBPIXEL_NONE, 'head': _lib.SUBPIXEL_HEAD, 'phase': _lib.SUBPIXEL_PHASE,
-                      'lateral': _lib.SUBPIXEL_LATERAL, 'scatter': _lib.SUBPIXEL_SCATTER}[sub[0] if isinstance(sub, tuple) else sub]
+                      'lateral': _lib.SUBPIXEL_LATERAL, 'scatter': _lib.SUBPIXEL_SCATTER, 'blhead': _lib.SUBPIXEL_BL_HEAD,
+                      'blphase': _lib.SUBPIXEL_BL_PHASE, 'blframe': _lib.SUBPIXEL_BL_FRAME}[sub[0] if isinstance(sub, tuple) else sub]
         d.src0 = op['src0']
         d.src1 = -1 if op['src1'] is None else op['src1']
         d.res = -1 if op['res'] is None else op['res']
@@ -820,7 +838,7 @@ def reference_flops(plan: Plan, H, W, only=None):
         sub = op.get('sub')
         if only is not None and op['op'] == 'conv' and not only(op):
             continue
-        if op['op'] != 'conv' or (isinstance(sub, tuple) and sub[0] != 'scatter'):  # (phase / lateral ops restate their head)
+        if op['op'] != 'conv' or (isinstance(sub, tuple) and sub[0] != 'scatter'):  # (phase / lateral / bl ops restate their head)
             continue
         t0 = plan.tensors[op['src0']]
         scatter = isinstance(sub, tuple)  # stands for the reference's 3x3 conv over the x2-upsampled source

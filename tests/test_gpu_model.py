@@ -771,3 +771,62 @@ def test_head_options(dev, name):
             print(name, precision, key, f'relL2 {rel:.3e}')
             assert rel < tol, (name, precision, key, rel)
     check_exact('nms', model(x), g, n, raw_atol=5e-4, flip_frac=1e-3)  # fp32 path, whole forward
+
+
+@pytest.mark.parametrize('name', ['CpnResNet18FPN', 'CpnResNet50FPN', 'CpnResNet18FPN_heads'])
+def test_bilinear_phase_refinement_head_on_golden_models(dev, name, monkeypatch):
+    """The refinement head over the x2 bilinear-resized level-0 map (cpn.py:277-278 + ReadOut, commons.py:461-511) as four
+    5 x 5 (k = 5: 4 x 4 ... k = 7: 5 x 5) phase convs on the low-resolution map + the frame of the conv over the resized map
+    (CPN_SUBPIXEL_BL_*; forced here with CPN_BLPHASE=2 -- by default the executor takes it only where it saves MACs, which
+    these 64 x 96 fixtures are too small for): the refinement map stays within the bf16 tolerance of the reference's fp32 map,
+    is no farther from it than the conv over the resized map, and the two statements agree closely with each other."""
+    spec = ALL_SPECS[name]
+    if spec['kwargs'].get('kernel_size_refinement', 7) % 4 != 3:
+        pytest.skip('k = 5: the two output phases have different supports -> the plan keeps the conv over the resized map')
+    monkeypatch.setenv('CPN_BLPHASE', '0')
+    m0, g = build(name, dev)
+    x = torch.as_tensor(g['x']).to(dev)
+    ref = torch.as_tensor(g['core.refinement'])
+    old = m0.core_forward(x)[2].cpu()
+    assert not any(p['gflop'] > 0 for p in m0.engine(dev).profile(x, m0.core.order, True) if isinstance(p.get('name'), str)
+                   and 'refinement' in p['name'] and p['k'] == 5)
+    monkeypatch.setenv('CPN_BLPHASE', '2')
+    m1, _ = build(name, dev)
+    new = m1.core_forward(x)[2].cpu()
+    prof = m1.engine(dev).profile(x, m1.core.order, True)
+    ran = [(p['k'], p['gflop'] > 0) for p in prof if 'refinement_head.block.0' in (p['name'] or '')]
+    assert ran == [(7, False), (5, True), (7, True)], ran  # HEAD skipped, PHASE + FRAME executed
+    rel = lambda a, b: ((a - b).norm() / (b.norm() + 1e-12)).item()
+    e_old, e_new, e_pair = rel(old, ref), rel(new, ref), rel(new, old)
+    print(f'{name}: refinement map relL2 vs fp32 reference: resized-map conv {e_old:.3e}, phases + frame {e_new:.3e}; '
+          f'between the two {e_pair:.3e}')
+    assert e_new < 6e-2 and e_new < 1.25 * e_old + 1e-3 and e_pair < 2e-2
+    for a, b in zip(m1.core_forward(x)[:2], m0.core_forward(x)[:2]):  # the other head maps are untouched
+        assert torch.equal(a, b)
+    # the frame really comes from the frame op and the interior from the phase convs: both regions carry finite, distinct values
+    assert torch.isfinite(new).all() and new[..., 8:-8, 8:-8].abs().sum() > 0 and new[..., :4, :].abs().sum() > 0
+
+
+def test_bilinear_phase_refinement_head_at_configs1_size(dev, monkeypatch):
+    """BASELINE configs[1] shape (CpnResNet18FPN, 512^2 tiles, 256-channel FPN): the executor picks the decomposition by itself
+    (15 % frame tiles) and the refinement map agrees with the conv over the resized map to bf16 accuracy."""
+    import celldetection_amd as cda
+    from celldetection_amd.synth import synth_state_dict
+    x = torch.rand(2, 3, 512, 512, generator=torch.Generator().manual_seed(0)).to(dev)
+    outs = {}
+    for mode in ('0', None):
+        if mode is None:
+            monkeypatch.delenv('CPN_BLPHASE', raising=False)
+        else:
+            monkeypatch.setenv('CPN_BLPHASE', mode)
+        m = cda.models.CpnResNet18FPN(3)
+        m.load_state_dict(synth_state_dict(m.state_dict(), seed=3))
+        m = m.to(dev)
+        outs[mode] = m.core_forward(x)[2].float().cpu()
+        prof = m.engine(dev).profile(x, m.core.order, True)
+        ran = [(p['k'], p['gflop'] > 0) for p in prof if 'refinement_head.block.0' in (p['name'] or '')]
+        assert ran == ([(7, True), (5, False), (7, False)] if mode == '0' else [(7, False), (5, True), (7, True)]), (mode, ran)
+    a, b = outs[None], outs['0']
+    rel = ((a - b).norm() / (b.norm() + 1e-12)).item()
+    print('configs[1] shape: refinement map, phases + frame vs conv over the resized map: relL2', rel)
+    assert rel < 2e-2 and torch.isfinite(a).all()

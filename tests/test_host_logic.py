@@ -337,7 +337,7 @@ def test_stem_fast_path_plan_and_packing():
     from celldetection_amd.synth import synth_state_dict
     m = cda.models.CpnResNet18FPN(3, backbone_kwargs={'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}})
     assert [(o['op'], o.get('alt')) for o in m._plan.ops[:4]] == [('input', 1), ('input_stem', 2), ('conv', 1), ('stem7', 2)]
-    generic = graph.build_plan(**m._plan_kwargs, subpixel=True)
+    generic = graph.build_plan(**m._plan_kwargs, subpixel=True, fuse_blocks=True, bilinear_phases=True)
     assert generic.entries == m._plan.entries
     assert all(not o.get('alt') for o in m.plan_for('fp32').ops)
     assert [(o['op'], o.get('alt')) for o in m.plan_for('fp8').ops[:4]] == [('input', 1), ('input_stem', 2), ('conv', 1), ('stem7', 2)]
@@ -376,3 +376,60 @@ def test_stem_fast_path_plan_and_packing():
         lib.cpn_plan_destroy(hdl)
     stem_generic = 2. * 32 * 48 * 32 * 32 * 49
     assert abs((fl['generic'] - fl['fast']) - stem_generic * (1 - 7 / 49.)) < 1.
+
+
+@pytest.mark.parametrize('k', [3, 7])
+def test_bilinear_subpixel_decomposition_is_exact(k):
+    """k x k conv over a x2 BILINEAR-resized map (cpn.py:277-278 + the ReadOut conv) == four k2 x k2 convs on the low-resolution
+    map (celldetection_amd/subpixel.py) wherever the conv window stays inside the resized image; the frame differs (there the
+    conv's zero padding applies, not the resize's edge clamp) and is exactly ``bilinear_frame(k)`` pixels wide."""
+    import torch.nn.functional as F
+    from celldetection_amd import subpixel as sp
+    g = torch.Generator().manual_seed(k)
+    x = torch.randn(2, 5, 13, 17, generator=g, dtype=torch.float64)
+    w = torch.randn(6, 5, k, k, generator=g, dtype=torch.float64)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False), w, padding=k // 2)
+    got = sp.bilinear_conv_by_phases(x, w)
+    f = sp.bilinear_frame(k)
+    assert f == {3: 2, 7: 4}[k] and sp.collapse_bilinear_taps(w).shape == (2, 2, 6, 5, (k + 3) // 2, (k + 3) // 2)
+    d = (got - ref).abs()
+    assert d[:, :, f:-f, f:-f].max() < 1e-12
+    assert d[:, :, f - 1:d.shape[2] - f + 1, f - 1:d.shape[3] - f + 1].max() > 1e-3  # one pixel further out it is NOT the same
+    with pytest.raises(ValueError):
+        sp.collapse_bilinear_taps(torch.zeros(1, 1, 5, 5))
+
+
+def test_bilinear_triple_in_fpn_plans():
+    """FPN models: the refinement ReadOut head over the bilinear-resized level-0 map carries its decomposition (BL_HEAD,
+    BL_PHASE, BL_FRAME); the native plan accepts it and executes fewer MACs where the resize is an exact x2."""
+    import celldetection_amd as cda
+    from celldetection_amd import _lib, graph
+    from ctypes import c_void_p
+    from celldetection_amd.synth import synth_state_dict
+    m = cda.models.CpnResNet18FPN(3, backbone_kwargs={'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}})
+    subs = [op.get('sub') for op in m._plan.ops if op.get('sub') is not None]
+    assert subs == ['blhead', ('blphase', 7), ('blframe', 7)]
+    plain = graph.build_plan(**m._plan_kwargs, fuse_blocks=True, stem_fast=True)
+    assert plain.entries == m._plan.entries and graph.reference_flops(plain, 64, 96) == graph.reference_flops(m._plan, 64, 96)
+    assert all(op.get('sub') is None for p_ in ('fp8', 'fp32') for op in m.plan_for(p_).ops)
+    sd = synth_state_dict(m.state_dict(), seed=0)
+    lib = _lib.load()
+    fl = {}
+    for name, plan in (('bl', m._plan), ('plain', plain)):
+        tens, ops, wblob, bblob = graph.pack(plan, sd, 'cpu')
+        if name == 'bl':
+            i = next(j for j, o in enumerate(ops) if o.subpixel == _lib.SUBPIXEL_BL_HEAD)
+            assert (ops[i + 1].subpixel, ops[i + 1].kh, ops[i + 1].pad, ops[i + 1].bundles, ops[i + 1].up0) == (_lib.SUBPIXEL_BL_PHASE, 5, 2, 4, 0)
+            assert (ops[i + 2].subpixel, ops[i + 2].kh, ops[i + 2].up0, ops[i + 2].out_index) == (_lib.SUBPIXEL_BL_FRAME, 7, 2, ops[i].out_index)
+            assert ops[i + 1].fuse_cout == ops[i].fuse_cout == 2
+        hdl = c_void_p()
+        _lib.check(lib.cpn_plan_create(hdl, tens, len(tens), ops, len(ops), c_void_p(wblob.data_ptr()), wblob.numel() * 2,
+                                       c_void_p(bblob.data_ptr()), bblob.numel(), _lib.PRECISION_BF16), 'create')
+        fl[name] = [lib.cpn_plan_executed_flops(hdl, 1, h, w) for h, w in ((512, 512), (75, 101), (64, 96))]
+        lib.cpn_plan_destroy(hdl)
+    assert fl['bl'][1] == fl['plain'][1]  # odd size: the resize is no exact x2 -> the conv over the resized map
+    assert fl['bl'][2] == fl['plain'][2]  # 64 x 96: exact, but the frame (whole 8 x 32 tiles) is most of the image -> no gain
+    # 512^2: the head's 49 taps become 4 x 25 taps on 256^2 + 15 % frame tiles of the 7 x 7 conv
+    head = 2. * 512 * 512 * 32 * 32 * 49
+    saved = fl['plain'][0] - fl['bl'][0]
+    assert 0.3 * head < saved < 0.5 * head, (saved / head)
