@@ -294,6 +294,27 @@ __device__ __forceinline__ void wait_pfrags(frag_t (&p)[WM]) {
     else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(p[0]), "+v"(p[1]) : "n"(N));
 }
 
+// tiles (th x tw) of an H x W output that are NOT entirely inside the box [m, H - m) x [m, W - m) (region 2 launches)
+struct FrameTiles {
+    int ty0, ty1, tx0, tx1;  // tile rows / columns [ty0, ty1) x [tx0, tx1) lie entirely inside the box
+    int top, side, mid, total;
+};
+__host__ __device__ inline FrameTiles frame_tiles(int H, int W, int m, int th, int tw) {
+    FrameTiles f;
+    const int tiles_x = (W + tw - 1) / tw, tiles_y = (H + th - 1) / th;
+    f.ty0 = (m + th - 1) / th; f.tx0 = (m + tw - 1) / tw;
+    f.ty1 = (H - m) / th; f.tx1 = (W - m) / tw;
+    if (f.ty1 < f.ty0) f.ty1 = f.ty0;
+    if (f.tx1 < f.tx0) f.tx1 = f.tx0;
+    if (f.ty0 > tiles_y) f.ty0 = f.ty1 = tiles_y;
+    if (f.tx1 == f.tx0) f.ty1 = f.ty0;  // no inner column: every row is a full row
+    f.top = f.ty0 * tiles_x;
+    f.side = f.tx0 + (tiles_x - f.tx1);
+    f.mid = (f.ty1 - f.ty0) * f.side;
+    f.total = f.top + f.mid + (tiles_y - f.ty1) * tiles_x;
+    return f;
+}
+
 struct ItemState {  // one K item = (32-channel chunk c, filter tap (ky, kx)); wave-uniform scalars
     int c, ky, kx;
 };
@@ -334,10 +355,32 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     const int tiles_x = (a.Wout + TW - 1) / TW;
     const int tiles_y = (a.Hout + TH - 1) / TH;
     int bid = blockIdx.x;
-    const int tx = bid % tiles_x;
-    bid /= tiles_x;
-    const int ty = bid % tiles_y;
-    const int n = bid / tiles_y;
+    int tx, ty, n;
+    if (a.region == 2) {
+        // frame-only launch: the grid holds ONLY the tiles that reach outside the box [m, H - m) x [m, W - m), enumerated rows
+        // above the box | the two sides of the rows that cross it | rows below.  (A dense grid whose inner workgroups exit at
+        // once put every left- and right-edge tile -- block ids = 0 / tiles_x - 1 mod tiles_x -- on TWO of the eight XCDs: 8.6
+        // ms instead of 1.6 for the frame of 8 x 512^2.)
+        const FrameTiles F = frame_tiles(a.Hout, a.Wout, a.region_margin, TH, TW);
+        n = bid / F.total;
+        int r = bid - n * F.total;
+        if (r < F.top) {
+            ty = r / tiles_x; tx = r - ty * tiles_x;
+        } else if (r < F.top + F.mid) {
+            r -= F.top;
+            const int q = r / F.side, c = r - q * F.side;
+            ty = F.ty0 + q; tx = c < F.tx0 ? c : F.tx1 + (c - F.tx0);
+        } else {
+            r -= F.top + F.mid;
+            const int q = r / tiles_x;
+            ty = F.ty1 + q; tx = r - q * tiles_x;
+        }
+    } else {
+        tx = bid % tiles_x;
+        bid /= tiles_x;
+        ty = bid % tiles_y;
+        n = bid / tiles_y;
+    }
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int n0 = blockIdx.y * BN;  // first output channel (within the bundle) of this block
     const int g = blockIdx.z;        // bundle
@@ -360,10 +403,6 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     const int cin0 = a.phase ? 0 : g * a.cin_b;  // (sub-pixel phase conv: the four phases read the same channels)
     const bool shift_pad = a.phase == 1 || a.phase == 2;  // (phase 3, bilinear phases: one symmetric support for all four)
     const int pad_y = a.pad - (shift_pad ? (g >> 1) : 0), pad_x = a.pad - (shift_pad ? (g & 1) : 0);
-    if (a.region == 2) {  // frame-only launch: a tile inside the box another op produces has nothing to do
-        const int m = a.region_margin;
-        if (oy0 >= m && oy0 + TH <= a.Hout - m && ox0 >= m && ox0 + TW <= a.Wout - m) return;
-    }
     const int c0_used = a.c0_used;
     constexpr int WITEM = BN * REC;   // one item's weight slab tile
     constexpr int WBUF = 2 * WITEM;   // one step's weights
@@ -1112,7 +1151,8 @@ static int launch_mode(const ConvArgs &a, hipStream_t stream) {
         attr_set[dev].store(true, std::memory_order_release);
     }
     const int tiles_x = (a.Wout + TW - 1) / TW, tiles_y = (a.Hout + TH - 1) / TH;
-    dim3 grid((unsigned) (tiles_x * tiles_y * a.N), (unsigned) ((a.cout_b + BN - 1) / BN), (unsigned) a.bundles);
+    const int ntiles = a.region == 2 ? frame_tiles(a.Hout, a.Wout, a.region_margin, TH, TW).total : tiles_x * tiles_y;
+    dim3 grid((unsigned) (ntiles * a.N), (unsigned) ((a.cout_b + BN - 1) / BN), (unsigned) a.bundles);
     hipLaunchKernelGGL(kern, grid, dim3(C::THREADS), lds, stream, a);
     return (int) hipGetLastError();
 }
@@ -1205,12 +1245,8 @@ int launch_conv(const ConvArgs &a_in, hipStream_t stream) {
 
 double conv_executed_flops(const ConvArgs &a) {
     double px = (double) a.Hout * a.Wout;
-    if (a.region == 2) {  // frame-only launch: the tiles inside the box exit at once (8 x 32 tiles of the fused-head kernels)
-        const int m = a.region_margin;
-        const int ty0 = (m + 7) / 8, ty1 = (a.Hout - m) / 8, tx0 = (m + 31) / 32, tx1 = (a.Wout - m) / 32;  // tiles fully inside
-        const double inner = (double) std::max(ty1 - ty0, 0) * std::max(tx1 - tx0, 0) * 256.;
-        px = (double) ((a.Hout + 7) / 8) * ((a.Wout + 31) / 32) * 256. - inner;
-    }
+    if (a.region == 2)  // frame-only launch: only the tiles that reach outside the box run (8 x 32 tiles of the fused-head kernels)
+        px = (double) frame_tiles(a.Hout, a.Wout, a.region_margin, 8, TW).total * 256.;
     return 2.0 * a.N * px * (double) a.bundles * a.cout_b * a.cin_b * a.KH * a.KW;
 }
 
