@@ -457,11 +457,14 @@ class CPN(nn.Module):
                 self._alt_plans[key] = graph.build_plan(**self._plan_kwargs, sparse_heads=key[0], subpixel=key[1],
                                                         stem_fast=True, fuse_blocks=True, bilinear_phases=key[1])
             return self._alt_plans[key]
-        if precision not in self._alt_plans:
-            # fp8: the resize stays its own op and the ResNet stem takes its bf16 fast path (e4m3 output); fp32: nothing fused
-            extra = dict(fuse_bilinear=False, stem_fast=True) if precision == 'fp8' else dict(fuse_readout=False, fuse_bilinear=False)
-            self._alt_plans[precision] = graph.build_plan(**self._plan_kwargs, **extra)
-        return self._alt_plans[precision]
+        key = (precision, bool(self.subpixel)) if precision == 'fp8' else precision
+        if key not in self._alt_plans:
+            # fp8: the resize stays its own op (the refinement head over it carries the bilinear phase decomposition: same
+            # tensors either way) and the ResNet stem takes its bf16 fast path (e4m3 output); fp32: nothing fused
+            extra = dict(fuse_bilinear=False, stem_fast=True, bilinear_phases=bool(self.subpixel)) if precision == 'fp8' else \
+                dict(fuse_readout=False, fuse_bilinear=False)
+            self._alt_plans[key] = graph.build_plan(**self._plan_kwargs, **extra)
+        return self._alt_plans[key]
 
     def _gate_requested(self, forward_path: bool) -> bool:
         sh = self.sparse_heads

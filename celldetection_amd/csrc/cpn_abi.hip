@@ -36,6 +36,7 @@ struct ShapePlan {
     std::vector<int64_t> offsets;  // per tensor (arena byte offsets)
     std::vector<int> th, tw;       // per tensor spatial size for this input size (propagated op by op: any H x W)
     std::vector<char> skip;        // per op: not executed at this input size (sub-pixel triples: HEAD or PHASE + LATERAL)
+    std::vector<int> ring;         // per op: bilinear resize ops that write only a border ring of their output (0: whole map)
     int out_h[CPN_NUM_OUTPUTS], out_w[CPN_NUM_OUTPUTS];  // sizes of the external fp32 outputs (0 = absent)
     int64_t total = 0;
     int64_t max_elems = 0;         // largest tensor of the graph, elements per image
@@ -92,6 +93,7 @@ static void propagate_dims(const cpn_plan *p, int N, int H, int W, ShapePlan &sp
     for (int i = 0; i < CPN_NUM_OUTPUTS; ++i) sp.out_h[i] = sp.out_w[i] = 0;
     auto bad = [&](const char *m) { sp.error = CPN_E_INVALID; sp.message = m; };
     sp.skip.assign(p->ops.size(), 0);
+    sp.ring.assign(p->ops.size(), 0);
     for (size_t oi = 0; oi < p->ops.size(); ++oi) {
         const cpn_op_desc &o = p->ops[oi];
         if (sp.error) return;
@@ -110,8 +112,12 @@ static void propagate_dims(const cpn_plan *p, int N, int H, int W, ShapePlan &sp
             // k x k conv, most of a small image (CPN_BLPHASE=0 / 2: never / wherever exact -- kernel A/B and tests)
             const char *e = getenv("CPN_BLPHASE");
             const int mode = e ? atoi(e) : 1;
-            bool exact = mode != 0 && p->precision == CPN_PRECISION_BF16 && o.up0 == 2 && 2 * sp.th[o.src0] == H &&
-                         2 * sp.tw[o.src0] == W && sp.th[o.src0] >= o.kh && sp.tw[o.src0] >= o.kw;
+            // bf16 plans: head and frame conv resize their source in the halo loader (up0 == 2, all three ops read the
+            // low-resolution map); fp8 plans: the resize is an op of its own, head and frame conv read its output
+            const int lo = p->ops[oi + 1].src0;
+            const bool hi_ok = o.up0 == 2 ? lo == o.src0 : (sp.th[o.src0] == H && sp.tw[o.src0] == W);
+            bool exact = mode != 0 && p->precision != CPN_PRECISION_F32 && hi_ok && 2 * sp.th[lo] == H && 2 * sp.tw[lo] == W &&
+                         sp.th[lo] >= o.kh && sp.tw[lo] >= o.kw;
             if (exact && mode != 2) {
                 const int k2 = (o.kh + 3) / 2, m = 2 * ((o.kh / 2 + 1) / 2);
                 auto tiles = [](int h, int w) { return (double) ((h + 7) / 8) * ((w + 31) / 32); };
@@ -119,6 +125,18 @@ static void propagate_dims(const cpn_plan *p, int N, int H, int W, ShapePlan &sp
                 const double head = tiles(H, W) * o.kh * o.kh;
                 const double parts = 4. * tiles(H / 2, W / 2) * k2 * k2 + (tiles(H, W) - inner) * o.kh * o.kh;
                 exact = parts <= 0.85 * head;
+            }
+            if (exact && o.up0 != 2) {
+                // the materialised resized map is read by the frame conv alone: its resize op writes only the pixels the
+                // frame's outputs reach (frame width + conv padding from the border)
+                int producer = -1;
+                bool shared = false;
+                for (size_t j = 0; j < p->ops.size(); ++j) {
+                    const cpn_op_desc &q = p->ops[j];
+                    if (j < oi && q.op == CPN_OP_BILINEAR && q.dst == o.src0 && q.subpixel == CPN_SUBPIXEL_BL_FRAME) producer = (int) j;
+                    if (j != oi && j != oi + 2 && (q.src0 == o.src0 || q.src1 == o.src0 || q.res == o.src0)) shared = true;
+                }
+                if (producer >= 0 && !shared) sp.ring[producer] = 2 * ((o.kh / 2 + 1) / 2) + o.kh / 2;
             }
             sp.skip[oi] = exact;
             sp.skip[oi + 1] = sp.skip[oi + 2] = !exact;
@@ -298,7 +316,7 @@ static int build_conv_args(const cpn_plan *p, const cpn_op_desc &o, int N, ConvA
         a.Hout = Hin; a.Wout = Win;
     }
     if (o.subpixel == CPN_SUBPIXEL_BL_FRAME) {  // the conv over the resized map, frame only: k = 2 k2 - 3 -> F = 2 (k2 / 2)
-        if (o.up0 != 2 || o.fuse_cout <= 0 || o.dst >= 0) return fail(CPN_E_INVALID, "conv: a bilinear frame conv is a fused ReadOut head over a bilinear source");
+        if (o.fuse_cout <= 0 || o.dst >= 0) return fail(CPN_E_INVALID, "conv: a bilinear frame conv is a fused ReadOut head over a bilinear-resized source");
         a.region = 2;
         a.region_margin = 2 * ((o.kh / 2 + 1) / 2);
     }
@@ -406,17 +424,21 @@ int cpn_plan_create(cpn_plan **plan, const cpn_tensor_desc *tensors, int32_t n_t
             return fail(CPN_E_INVALID, "cpn_plan_create: malformed sub-pixel triple (HEAD, PHASE, LATERAL)");
         }
         if (o.subpixel == CPN_SUBPIXEL_BL_HEAD &&
-            (o.op != CPN_OP_CONV || precision != CPN_PRECISION_BF16 || oi_ + 2 >= p->ops.size() || o.up0 != 2 || o.dst >= 0 ||
+            (o.op != CPN_OP_CONV || precision == CPN_PRECISION_F32 || oi_ + 2 >= p->ops.size() || o.dst >= 0 ||
+             (o.up0 != 2 && o.up0 != 0) || (o.up0 == 2 && precision == CPN_PRECISION_FP8) ||  // (fp8: the resize is its own op)
              o.fuse_cout <= 0 || o.kh != o.kw || o.kh % 4 != 3 || p->ops[oi_ + 1].subpixel != CPN_SUBPIXEL_BL_PHASE ||
              p->ops[oi_ + 2].subpixel != CPN_SUBPIXEL_BL_FRAME || p->ops[oi_ + 1].op != CPN_OP_CONV || p->ops[oi_ + 2].op != CPN_OP_CONV ||
-             p->ops[oi_ + 1].src0 != o.src0 || p->ops[oi_ + 2].src0 != o.src0 || p->ops[oi_ + 1].out_index != o.out_index ||
+             (o.up0 == 2 && p->ops[oi_ + 1].src0 != o.src0) || p->ops[oi_ + 1].src0 < 0 ||
+             p->tensors[p->ops[oi_ + 1].src0].channels != p->tensors[o.src0].channels ||
+             p->ops[oi_ + 2].src0 != o.src0 || p->ops[oi_ + 1].out_index != o.out_index ||
              p->ops[oi_ + 2].out_index != o.out_index || p->ops[oi_ + 1].kh != (o.kh + 3) / 2 || p->ops[oi_ + 2].kh != o.kh ||
-             p->ops[oi_ + 2].up0 != 2 || p->ops[oi_ + 1].fuse_cout != o.fuse_cout || p->ops[oi_ + 2].fuse_cout != o.fuse_cout)) {
+             p->ops[oi_ + 2].up0 != o.up0 || p->ops[oi_ + 1].fuse_cout != o.fuse_cout || p->ops[oi_ + 2].fuse_cout != o.fuse_cout)) {
             delete p;
             return fail(CPN_E_INVALID, "cpn_plan_create: malformed bilinear sub-pixel triple (BL_HEAD, BL_PHASE, BL_FRAME)");
         }
+        // (a resize op flagged BL_FRAME feeds the frame conv of a triple: propagate_dims)
         if ((o.subpixel == CPN_SUBPIXEL_BL_PHASE && (oi_ < 1 || p->ops[oi_ - 1].subpixel != CPN_SUBPIXEL_BL_HEAD)) ||
-            (o.subpixel == CPN_SUBPIXEL_BL_FRAME && (oi_ < 2 || p->ops[oi_ - 2].subpixel != CPN_SUBPIXEL_BL_HEAD))) {
+            (o.subpixel == CPN_SUBPIXEL_BL_FRAME && o.op != CPN_OP_BILINEAR && (oi_ < 2 || p->ops[oi_ - 2].subpixel != CPN_SUBPIXEL_BL_HEAD))) {
             delete p;
             return fail(CPN_E_INVALID, "cpn_plan_create: bilinear PHASE / FRAME ops must follow their BL_HEAD op");
         }
@@ -473,7 +495,7 @@ int cpn_plan_create(cpn_plan **plan, const cpn_tensor_desc *tensors, int32_t n_t
             if (precision == CPN_PRECISION_FP8) {  // [bundle][items (+1 zero slab if odd)][cout_b][64] bytes
                 const size_t items = (size_t) (o.cin_b / 64) * o.kh * o.kw;
                 wbytes = (size_t) o.bundles * (items + (items & 1)) * o.cout_b * 64;
-                if (o.cin_b % 64 || (o.mult_offset >= 0 && (size_t) o.mult_offset + (size_t) o.bundles * o.cout_b > bias_count)) {
+                if (o.cin_b % 64 || (o.mult_offset >= 0 && (size_t) o.mult_offset + (size_t) (o.subpixel == CPN_SUBPIXEL_BL_PHASE ? 1 : o.bundles) * o.cout_b > bias_count)) {
                     delete p;
                     return fail(CPN_E_INVALID, "cpn_plan_create: fp8 conv needs cin_b % 64 == 0 and a valid mult_offset");
                 }
@@ -598,7 +620,7 @@ static int run_or_count(cpn_plan *plan, const void *input, int32_t in_dtype, int
                 if (flops) break;
                 if (sp.offsets[o.src0] == sp.offsets[o.dst]) break;  // same size: the planner aliased dst to src
                 ResizeArgs a{tptr(o.src0), tptr(o.dst), N, sp.th[o.src0], sp.tw[o.src0], sp.th[o.dst], sp.tw[o.dst],
-                             tch(o.src0)};
+                             tch(o.src0), fp8 ? sp.ring[i] : 0};  // (ring: see propagate_dims, bilinear sub-pixel triple)
                 rc = check_hip((hipError_t) (f32 ? launch_bilinear_f32(a, st) : fp8 ? launch_bilinear_fp8(a, st)
                                                                                    : launch_bilinear(a, st)), "bilinear kernel");
                 break;

@@ -110,6 +110,7 @@ int launch_maxpool(const PoolArgs &a, hipStream_t stream);
 struct ResizeArgs {
     const void *src; void *dst;
     int N, Hin, Win, Hout, Wout, C;
+    int ring;  // fp8 kernel only: > 0 -> write just the pixels within `ring` of the output's border (0: the whole map)
 };
 int launch_bilinear(const ResizeArgs &a, hipStream_t stream);
 

@@ -121,12 +121,16 @@ __global__ __launch_bounds__(256) void bilinear_fp8_kernel(const ResizeArgs a) {
     const int y0 = (int) fy, y1 = y0 + (y0 < a.Hin - 1 ? 1 : 0);
     const float ly = fy - (float) y0, hy = 1.f - ly;
     const unsigned g16 = (unsigned) a.C >> 4;
-    const unsigned per_row = (unsigned) a.Wout * g16;
+    // ring mode: rows within `ring` of the top / bottom border are written whole, the others at their first and last `ring` pixels
+    const bool whole = a.ring <= 0 || 2 * a.ring >= a.Wout || oy < a.ring || oy >= a.Hout - a.ring;
+    const unsigned per_row = (unsigned) (whole ? a.Wout : 2 * a.ring) * g16;
+    const unsigned skip = whole ? 0u : (unsigned) (a.Wout - 2 * a.ring);
     const unsigned char *r0 = (const unsigned char *) a.src + ((size_t) n * a.Hin + y0) * a.Win * (size_t) a.C;
     const unsigned char *r1 = (const unsigned char *) a.src + ((size_t) n * a.Hin + y1) * a.Win * (size_t) a.C;
     unsigned char *dr = (unsigned char *) a.dst + ((size_t) n * a.Hout + oy) * a.Wout * (size_t) a.C;
     for (unsigned i = threadIdx.x; i < per_row; i += 256u) {
-        const unsigned ox = i / g16, c = (i - ox * g16) << 4;
+        const unsigned oi = i / g16, c = (i - oi * g16) << 4;
+        const unsigned ox = oi + (oi >= (unsigned) a.ring ? skip : 0u);
         const float fx = fmaxf(sx * ((float) ox + 0.5f) - 0.5f, 0.f);
         const int x0 = (int) fx, x1 = x0 + (x0 < a.Win - 1 ? 1 : 0);
         const float lx = fx - (float) x0, hx = 1.f - lx;

@@ -375,19 +375,21 @@ BACKBONES['U22'] = ('unet', 'U22')
 
 
 def _readout(P, x, cmid, cout, prefix, act, act_scale, out_index, k=7, fuse=True, up0=False, stride=1, deferred=False,
-             bilinear_phases=False):
+             bilinear_phases=False, bl_source=None):
     """ReadOut (commons.py:461-511): conv kxk(bias) -> BN -> ReLU -> Dropout2d(eval: identity) -> conv 1x1(bias).
     ``bilinear_phases`` (fused heads over a bilinear source, k = 3 (mod 4)): the op additionally carries its decomposition for
     the exact x2 case (include/cpn_hip.h CPN_SUBPIXEL_BL_*): four k2 x k2 phase convs on the low-resolution map + the same
-    conv restricted to the image frame."""
+    conv restricted to the image frame.  ``bl_source`` (fp8 plans, whose resize is an op of its own): the tensor in front of
+    that resize -- the phase convs read it, head and frame conv read ``x``, the materialised resized map."""
     if fuse and FUSE_READOUT and _pad32(cmid) in (32, 64, 128, 256) and cout <= 32:
         # one kernel: conv kxk + BN + ReLU -> (bf16, LDS) -> 1x1 conv + final activation -> fp32 NCHW head map
         kw = dict(w=prefix + 'block.0.', bn=prefix + 'block.1.', bias=True, act='relu', out_index=out_index,
                   fuse=dict(w=prefix + 'block.4.', cout=cout, act=act, act_scale=act_scale))
-        triple = bool(bilinear_phases) and up0 == 'bilinear' and k % 4 == 3 and stride == 1 and not deferred
+        triple = bool(bilinear_phases) and (up0 == 'bilinear' or bl_source is not None) and k % 4 == 3 and stride == 1 and \
+            not deferred
         P.conv(x, cmid, k, up0=up0, stride=stride, deferred=deferred, sub='blhead' if triple else None, **kw)
         if triple:
-            P.conv(x, cmid, (k + 3) // 2, sub=('blphase', k), **kw)
+            P.conv(x if bl_source is None else bl_source, cmid, (k + 3) // 2, sub=('blphase', k), **kw)
             P.conv(x, cmid, k, up0=up0, sub=('blframe', k), **kw)
         return
     assert not deferred, 'only fused ReadOut heads can be deferred'
@@ -420,7 +422,7 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
     its dedicated kernel on a padded 4-channel input layout (``Plan.stem_fast_path``).
     ``fuse_blocks`` (bf16 plans, ResNeXt encoders): every bottleneck block additionally carries conv1 -> grouped conv2 as
     one fused op (``Plan.conv_pair``).
-    ``bilinear_phases`` (bf16 plans): the refinement head over the bilinear-resized feature map (FPN models) additionally
+    ``bilinear_phases`` (bf16 / fp8 plans): the refinement head over the bilinear-resized feature map (FPN models) additionally
     carries its sub-pixel decomposition (``_readout``)."""
     if contour_head_stride not in (1, 2) or refinement_head_stride not in (1, 2):
         raise NotImplementedError('head strides other than 1 and 2 are not supported by the HIP conv kernel')
@@ -528,11 +530,17 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
         resize = family == 'fpn' or enc != 'U22' or _keys(feats_cfg['refinement']) != ['0']
         kr = ks.get('refinement', 7)
         fused_resize = resize and fuse_bilinear and kr > 1 and refinement_head_stride == 1
+        r_low = None
         if resize and not fused_resize:
+            r_low = r
             r = P.bilinear_to_input(r)
+            resize_op = P.ops[-1]
         _readout(P, r, cm0, 2 * refinement_buckets, 'core.refinement_head.', 'tanh_scaled', float(refinement_margin),
                  _lib.OUT_REFINEMENT, k=kr, fuse=fuse_readout, up0='bilinear' if fused_resize else False,
-                 stride=refinement_head_stride, bilinear_phases=bilinear_phases and fused_resize)
+                 stride=refinement_head_stride, bilinear_phases=bilinear_phases and (fused_resize or r_low is not None),
+                 bl_source=r_low if (bilinear_phases and kr > 1 and refinement_head_stride == 1) else None)
+        if r_low is not None and any(op.get('sub') == 'blhead' for op in P.ops[-3:]):
+            resize_op['ring_for_bl'] = True  # (the executor writes only the frame's neighbourhood of that map when the phases run)
     P.meta = dict(backbone=backbone, order=order, head_down=scale, refinement=refinement, in_channels=in_channels,
                   score_channels=score_channels, refinement_buckets=refinement_buckets,
                   uncertainty_head=bool(uncertainty_head), sparse_heads=sparse_meta)
@@ -664,13 +672,16 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=Non
             continue
         if op['op'] == 'bilinear':
             d.op, d.src0, d.dst = _lib.OP_BILINEAR, op['src0'], op['dst']
+            # feeds a bilinear sub-pixel triple: only the frame's neighbourhood of the map is needed when the phase convs run
+            d.subpixel = _lib.SUBPIXEL_BL_FRAME if op.get('ring_for_bl') else _lib.SUBPIXEL_NONE
             continue
         # conv
         w, b = _fold(state_dict, op)
         k, groups, cin, cout = op['k'], op['groups'], op['cin'], op['cout']
         sub = op.get('sub')
-        if sub is not None and (f32 or fp8):
-            raise ValueError('sub-pixel conv triples are a bf16-plan feature')
+        bl = sub == 'blhead' or (isinstance(sub, tuple) and sub[0] in ('blphase', 'blframe'))
+        if sub is not None and (f32 or (fp8 and not bl)):
+            raise ValueError('sub-pixel conv triples are a bf16-plan feature (the bilinear phases: bf16 / fp8)')
         if isinstance(sub, tuple) and sub[0] == 'lateral':  # the lateral's share of the head conv's weights (+ its bias)
             w = w[:, :sub[1]]
         if op.get('share') is not None:  # a channel range of the stated conv; its (BN-folded) bias travels with ONE of the parts
@@ -736,14 +747,18 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=Non
         if fp8:
             packed = packed.contiguous().reshape(bundles, -1, cout_b, KC)  # [bundle][item][cout][64]
             wscale = (packed.abs().amax((1, 3)) / 448.).clamp_min(1e-30)      # [bundle][cout]
+            if isinstance(sub, tuple) and sub[0] == 'blphase':  # the four phases share ONE bias and ONE multiplier per channel
+                wscale = wscale.amax(0, keepdim=True).expand(bundles, -1)
             codes = (packed / wscale[:, None, :, None]).to(torch.float32).to(torch.float8_e4m3fn).view(torch.uint8)
             if codes.shape[1] % 2:  # the kernel's pipeline step holds two items
                 codes = torch.cat((codes, torch.zeros_like(codes[:, :1])), 1)
             wparts.append(codes.contiguous().reshape(-1))
-            mparts.append(wscale.reshape(-1).to(torch.float32))
+            mparts.append((wscale[:1] if (isinstance(sub, tuple) and sub[0] == 'blphase') else wscale).reshape(-1).to(torch.float32))
             op_scales[-1] = (float(act_scales[op['res']]) if op['res'] is not None else 0.,
                              1. / float(act_scales[op['dst']]) if op['dst'] is not None else 0.)
-            if effective_weights is not None:
+            if effective_weights is not None and phase:  # (a member op: the simulator follows the head op it restates)
+                effective_weights.append(dict(w=None, b=None))
+            elif effective_weights is not None:
                 dq = codes[:, :packed.shape[1]].view(torch.float8_e4m3fn).to(torch.float64) * wscale[:, None, :, None]
                 dq = dq.reshape(bundles, cin_b // KC, k * k, cout_b, KC).permute(0, 3, 1, 4, 2)  # [B][cout][chunk][64][tap]
                 dq = dq.reshape(bundles, cout_b, cin_b, k, k)

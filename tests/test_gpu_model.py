@@ -835,3 +835,36 @@ def test_bilinear_phase_refinement_head_at_configs1_size(dev, monkeypatch):
     print(f'configs[1] shape: refinement map relL2 vs the fp32 oracle: resized-map conv {e_old:.3e}, phases + frame {e_new:.3e}; '
           f'between the two {rel(a, b):.3e}')
     assert torch.isfinite(a).all() and e_new < 1.25 * e_old + 1e-3 and rel(a, b) < 2.5 * e_old
+
+
+@pytest.mark.parametrize('name', ['CpnResNet18FPN', 'CpnResNet50FPN'])
+def test_bilinear_phase_refinement_head_fp8(dev, name, monkeypatch):
+    """fp8 plans: the resize in front of the refinement head is an op of its own (e4m3 codes); with the phase decomposition the
+    four 5 x 5 phase convs read the map in FRONT of that resize, the resize writes only the border ring the frame conv reads.
+    Frame pixels: same kernel, same inputs as the conv over the whole resized map -> same values; interior: no farther from
+    the reference's fp32 map than the old path (one e4m3 rounding fewer: the resized map is never quantised there)."""
+    maps = {}
+    for mode in ('0', '2'):
+        monkeypatch.setenv('CPN_BLPHASE', mode)
+        m, g = build(name, dev)
+        x = torch.as_tensor(g['x']).to(dev)
+        m.precision = 'fp8'
+        m.calibrate_fp8(x)
+        maps[mode] = [t.cpu() for t in m.core_forward(x)]
+        prof = m.engine(dev).profile(x, m.core.order, True)
+        ran = [(p['k'], p['gflop'] > 0) for p in prof if 'refinement_head.block.0' in (p['name'] or '')]
+        assert ran == ([(7, True), (5, False), (7, False)] if mode == '0' else [(7, False), (5, True), (7, True)]), (mode, ran)
+    old, new = maps['0'][2], maps['2'][2]
+    ref = torch.as_tensor(g['core.refinement'])
+    rel = lambda a, b: ((a - b).norm() / (b.norm() + 1e-12)).item()
+    e_old, e_new = rel(old, ref), rel(new, ref)
+    print(f'{name} fp8: refinement map relL2 vs fp32 reference: resized-map conv {e_old:.3e}, phases + frame {e_new:.3e}; '
+          f'between the two {rel(new, old):.3e}')
+    assert torch.isfinite(new).all() and e_new < 1.1 * e_old + 1e-2
+    f = 4  # bilinear_frame(7)
+    for sl in ((..., slice(0, f), slice(None)), (..., slice(-f, None), slice(None)), (..., slice(None), slice(0, f)),
+               (..., slice(None), slice(-f, None))):
+        assert (new[sl] - old[sl]).abs().max().item() < 1e-5, sl  # the ring-only resize feeds the frame conv the same codes
+    assert (new[..., f:-f, f:-f] - old[..., f:-f, f:-f]).abs().max() > 0
+    for a, b in zip(maps['0'][:2] + maps['0'][3:], maps['2'][:2] + maps['2'][3:]):
+        assert torch.equal(a, b)

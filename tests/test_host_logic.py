@@ -399,7 +399,7 @@ def test_bilinear_subpixel_decomposition_is_exact(k):
         sp.collapse_bilinear_taps(torch.zeros(1, 1, 5, 5))
 
 
-def test_bilinear_triple_in_fpn_plans():
+def test_bilinear_triple_in_fpn_plans(monkeypatch):
     """FPN models: the refinement ReadOut head over the bilinear-resized level-0 map carries its decomposition (BL_HEAD,
     BL_PHASE, BL_FRAME); the native plan accepts it and executes fewer MACs where the resize is an exact x2."""
     import celldetection_amd as cda
@@ -411,7 +411,13 @@ def test_bilinear_triple_in_fpn_plans():
     assert subs == ['blhead', ('blphase', 7), ('blframe', 7)]
     plain = graph.build_plan(**m._plan_kwargs, fuse_blocks=True, stem_fast=True)
     assert plain.entries == m._plan.entries and graph.reference_flops(plain, 64, 96) == graph.reference_flops(m._plan, 64, 96)
-    assert all(op.get('sub') is None for p_ in ('fp8', 'fp32') for op in m.plan_for(p_).ops)
+    assert all(op.get('sub') is None for op in m.plan_for('fp32').ops)
+    # fp8 plans keep the resize as an op of its own: head and frame conv read its output, the phases the map in front of it
+    p8 = m.plan_for('fp8')
+    i8 = next(j for j, op in enumerate(p8.ops) if op.get('sub') == 'blhead')
+    rz = next(op for op in p8.ops if op['op'] == 'bilinear')
+    assert rz.get('ring_for_bl') and p8.ops[i8]['src0'] == p8.ops[i8 + 2]['src0'] == rz['dst'] and p8.ops[i8 + 1]['src0'] == rz['src0']
+    assert [p8.ops[i8 + j].get('sub') for j in (1, 2)] == [('blphase', 7), ('blframe', 7)] and not p8.ops[i8]['up0']
     sd = synth_state_dict(m.state_dict(), seed=0)
     lib = _lib.load()
     fl = {}
@@ -433,3 +439,18 @@ def test_bilinear_triple_in_fpn_plans():
     head = 2. * 512 * 512 * 32 * 32 * 49
     saved = fl['plain'][0] - fl['bl'][0]
     assert 0.3 * head < saved < 0.5 * head, (saved / head)
+    # the fp8 plan takes the same decision (kernel A/B switch CPN_BLPHASE=0: the conv over the resized map everywhere)
+    tens, ops, wblob, bblob, mblob, _ = graph.pack(p8, sd, 'cpu', precision='fp8', act_scales=[.02] * len(p8.tensors))
+    f8 = {}
+    for env in ('0', None):
+        if env is not None:
+            monkeypatch.setenv('CPN_BLPHASE', env)
+        else:
+            monkeypatch.delenv('CPN_BLPHASE')
+        hdl = c_void_p()
+        _lib.check(lib.cpn_plan_create(hdl, tens, len(tens), ops, len(ops), _lib.ptr(wblob), wblob.numel(), _lib.ptr(bblob),
+                                       bblob.numel(), _lib.PRECISION_FP8), 'create')
+        f8[env] = [lib.cpn_plan_executed_flops(hdl, 1, h, w) for h, w in ((512, 512), (75, 101))]
+        lib.cpn_plan_destroy(hdl)
+    head8 = 2. * 512 * 512 * 64 * 32 * 49  # (fp8 plans pad channels to 64)
+    assert f8['0'][1] == f8[None][1] and 0.3 * head8 < f8['0'][0] - f8[None][0] < 0.5 * head8
