@@ -1198,9 +1198,16 @@ static TileChoice choose_tile(const ConvArgs &a) {
     if (blocks(TH, BN) < MIN_BLOCKS && BN > 64) BN = 64;
     while (lds_bytes(a, TH, BN) > LDS_MAX && BN > 32) BN >>= 1;
     // narrow-channel layers at high resolution (64 -> 64 @ 512^2): 16-row tiles keep 8 waves per CU busy
-    if (BN == 64 && TH == 8 && a.Hout >= 16 && lds_bytes(a, 16, 64) <= LDS_MAX && blocks(16, 64) >= 2 * MIN_BLOCKS) TH = 16;
+    // (CPN_TH64=8: kernel A/B switch, read per call -- 8-row tiles, two workgroups per CU where their LDS fits twice)
+    const char *e64 = getenv("CPN_TH64");
+    if (BN == 64 && TH == 8 && a.Hout >= 16 && lds_bytes(a, 16, 64) <= LDS_MAX && blocks(16, 64) >= 2 * MIN_BLOCKS &&
+        !(e64 && atoi(e64) == 8))
+        TH = 16;
     return TileChoice{TH, BN};
 }
+
+// fused ReadOut heads: the block owns all output channels; tile rows = a multiple of the wave count
+static int fused_head_rows(const ConvArgs &a, const TileChoice &c) { return (a.cout_b == 64 && c.TH == 16) ? 16 : 8; }
 
 int launch_conv(const ConvArgs &a_in, hipStream_t stream) {
     ConvArgs a = a_in;
@@ -1222,7 +1229,7 @@ int launch_conv(const ConvArgs &a_in, hipStream_t stream) {
         if (a.bundles != (a.phase == 3 ? 4 : 1) || (a.cout_b != 256 && a.cout_b != 128 && a.cout_b != 64 && a.cout_b != 32))
             return (int) hipErrorInvalidValue;
         c.BN = a.cout_b;
-        c.TH = (a.cout_b == 64 && c.TH == 16) ? 16 : 8;
+        c.TH = fused_head_rows(a, c);
     }
     if (lds_bytes(a, c.TH, c.BN) > LDS_MAX) return (int) hipErrorInvalidValue;
     if (c.TH == 16) return launch_cfg<16, 64, 2, 2>(a, stream);
@@ -1245,8 +1252,10 @@ int launch_conv(const ConvArgs &a_in, hipStream_t stream) {
 
 double conv_executed_flops(const ConvArgs &a) {
     double px = (double) a.Hout * a.Wout;
-    if (a.region == 2)  // frame-only launch: only the tiles that reach outside the box run (8 x 32 tiles of the fused-head kernels)
-        px = (double) frame_tiles(a.Hout, a.Wout, a.region_margin, 8, TW).total * 256.;
+    if (a.region == 2) {  // frame-only launch: only the tiles that reach outside the box run (the fused-head kernels' tiles)
+        const int th = fused_head_rows(a, choose_tile(a));
+        px = (double) frame_tiles(a.Hout, a.Wout, a.region_margin, th, TW).total * th * TW;
+    }
     return 2.0 * a.N * px * (double) a.bundles * a.cout_b * a.cin_b * a.KH * a.KW;
 }
 

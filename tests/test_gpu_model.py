@@ -773,7 +773,7 @@ def test_head_options(dev, name):
     check_exact('nms', model(x), g, n, raw_atol=5e-4, flip_frac=1e-3)  # fp32 path, whole forward
 
 
-@pytest.mark.parametrize('name', ['CpnResNet18FPN', 'CpnResNet50FPN', 'CpnResNet18FPN_heads'])
+@pytest.mark.parametrize('name', ['CpnResNet18FPN', 'CpnResNet50FPN', 'CpnResNet18FPN_heads', 'CpnResNet18FPN_fuse'])
 def test_bilinear_phase_refinement_head_on_golden_models(dev, name, monkeypatch):
     """The refinement head over the x2 bilinear-resized level-0 map (cpn.py:277-278 + ReadOut, commons.py:461-511) as four
     5 x 5 (k = 5: 4 x 4 ... k = 7: 5 x 5) phase convs on the low-resolution map + the frame of the conv over the resized map
