@@ -26,6 +26,10 @@ CASES = {
     'grp': dict(n=16, h=32, w=32, cin=1024, cout=1024, k=3, groups=32),
     'head7x3': dict(n=16, h=256, w=256, cin=256, cout=768, k=7),  # the three contour heads as ONE 256 -> 768 launch
     'bl7': dict(n=8, h=512, w=512, cin=256, cout=256, k=7, bilinear=True),  # FPN refinement head: bilinear-resized source
+    'k3': dict(n=8, h=256, w=256, cin=256, cout=256, k=3),  # tap count at fixed shape (bilinear phase convs are k = 5)
+    'k5': dict(n=8, h=256, w=256, cin=256, cout=256, k=5),
+    'k7': dict(n=8, h=256, w=256, cin=256, cout=256, k=7),
+    'k9': dict(n=8, h=256, w=256, cin=256, cout=256, k=9),
     'bl7s': dict(n=2, h=256, w=256, cin=256, cout=256, k=7, bilinear=True),
 }
 
