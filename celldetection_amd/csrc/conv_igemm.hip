@@ -144,8 +144,14 @@ struct Cfg {
 
 struct HaloGeo {
     int n, iy0, ix0, sub, Hin, Win, Hs0, Ws0, Hs1, Ws1, up0, up1, c0_stride, c1_stride, HH, HWreal;
+    int wseg, wx0, wx1;  // wrap tile (frame launches): halo columns [0, wseg) start at input column wx0, [wseg, 2 wseg) at wx1
     float sy0, sx0, sy1, sx1;
 };
+// input column of halo column hx
+__device__ __forceinline__ int halo_ix(const HaloGeo &G, int hx) {
+    if (G.wseg) return hx >= G.wseg ? G.wx1 + (hx - G.wseg) : G.wx0 + hx;
+    return G.ix0 + hx * G.sub;
+}
 
 // source element offsets (src0 / src1 variants; -1 = zero padding) of this lane's 16 B of halo DMA instruction q:
 // lane -> (pixel, 16-B slot); the slot holds channel part (slot ^ ((pixel>>2)&3)) of the pixel record
@@ -183,7 +189,7 @@ __device__ __forceinline__ void halo_bilinear_store(const HaloGeo &G, int q, int
     const int pix = idx >> 2;
     const int part = (idx & 3) ^ ((pix >> 2) & 3);
     const int hy_ = pix / PITCH, hx_ = pix - hy_ * PITCH;
-    const int iy = G.iy0 + hy_, ix = G.ix0 + hx_;
+    const int iy = G.iy0 + hy_, ix = halo_ix(G, hx_);
     if (!(hy_ < G.HH && hx_ < G.HWreal && iy >= 0 && iy < G.Hin && ix >= 0 && ix < G.Win)) {
         const u32x4 z = {0u, 0u, 0u, 0u};
         *(lds_u32x4 *) dst = z;
@@ -295,11 +301,15 @@ __device__ __forceinline__ void wait_pfrags(frag_t (&p)[WM]) {
 }
 
 // tiles (th x tw) of an H x W output that are NOT entirely inside the box [m, H - m) x [m, W - m) (region 2 launches)
+// kw > 0 (stride-1 k x k convs, k <= 9, m <= 16): the two sides of a row that crosses the box are ONE wrap tile -- output
+// columns W - 16 .. W - 1 and 0 .. 15 (two halo segments of 16 + kw - 1 columns in the 48-column halo pitch) -- instead of a
+// whole 32-column tile per side for a frame that is m columns wide
 struct FrameTiles {
     int ty0, ty1, tx0, tx1;  // tile rows / columns [ty0, ty1) x [tx0, tx1) lie entirely inside the box
-    int top, side, mid, total;
+    int top, side, mid, total, wrap;
 };
-__host__ __device__ inline FrameTiles frame_tiles(int H, int W, int m, int th, int tw) {
+constexpr int WRAP_HALF = 16;
+__host__ __device__ inline FrameTiles frame_tiles(int H, int W, int m, int th, int tw, int kw) {
     FrameTiles f;
     const int tiles_x = (W + tw - 1) / tw, tiles_y = (H + th - 1) / th;
     f.ty0 = (m + th - 1) / th; f.tx0 = (m + tw - 1) / tw;
@@ -309,11 +319,14 @@ __host__ __device__ inline FrameTiles frame_tiles(int H, int W, int m, int th, i
     if (f.ty0 > tiles_y) f.ty0 = f.ty1 = tiles_y;
     if (f.tx1 == f.tx0) f.ty1 = f.ty0;  // no inner column: every row is a full row
     f.top = f.ty0 * tiles_x;
-    f.side = f.tx0 + (tiles_x - f.tx1);
+    f.wrap = kw > 1 && kw <= 9 && m <= WRAP_HALF && W >= 2 * WRAP_HALF && f.tx1 > f.tx0;
+    f.side = f.wrap ? 1 : f.tx0 + (tiles_x - f.tx1);
     f.mid = (f.ty1 - f.ty0) * f.side;
     f.total = f.top + f.mid + (tiles_y - f.ty1) * tiles_x;
     return f;
 }
+// wrap tiles apply to the stride-1 k x k modes (MODE_S1 / S1R / BL): the kernel and the launcher must agree
+__host__ __device__ inline int frame_kw(const ConvArgs &a) { return (a.stride == 1 && !a.narrow && a.KW > 1) ? a.KW : 0; }
 
 struct ItemState {  // one K item = (32-channel chunk c, filter tap (ky, kx)); wave-uniform scalars
     int c, ky, kx;
@@ -356,12 +369,13 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     const int tiles_y = (a.Hout + TH - 1) / TH;
     int bid = blockIdx.x;
     int tx, ty, n;
+    bool wrap = false;  // (block-uniform) this block is a wrap tile of a frame launch
     if (a.region == 2) {
         // frame-only launch: the grid holds ONLY the tiles that reach outside the box [m, H - m) x [m, W - m), enumerated rows
         // above the box | the two sides of the rows that cross it | rows below.  (A dense grid whose inner workgroups exit at
         // once put every left- and right-edge tile -- block ids = 0 / tiles_x - 1 mod tiles_x -- on TWO of the eight XCDs: 8.6
         // ms instead of 1.6 for the frame of 8 x 512^2.)
-        const FrameTiles F = frame_tiles(a.Hout, a.Wout, a.region_margin, TH, TW);
+        const FrameTiles F = frame_tiles(a.Hout, a.Wout, a.region_margin, TH, TW, frame_kw(a));
         n = bid / F.total;
         int r = bid - n * F.total;
         if (r < F.top) {
@@ -370,6 +384,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
             r -= F.top;
             const int q = r / F.side, c = r - q * F.side;
             ty = F.ty0 + q; tx = c < F.tx0 ? c : F.tx1 + (c - F.tx0);
+            wrap = F.wrap != 0;
         } else {
             r -= F.top + F.mid;
             const int q = r / tiles_x;
@@ -420,6 +435,13 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     G.Hs0 = a.Hs0; G.Ws0 = a.Ws0; G.Hs1 = a.Hs1; G.Ws1 = a.Ws1;
     G.sy0 = a.sy0; G.sx0 = a.sx0; G.sy1 = a.sy1; G.sx1 = a.sx1;
     G.c0_stride = a.c0_stride; G.c1_stride = a.c1_stride; G.HH = HH; G.HWreal = ((NR ? 16 : TW) - 1) * S + KW;
+    G.wseg = 0; G.wx0 = G.wx1 = 0;
+    if (wrap) {  // fragment lanes 0..15 = output columns Wout - 16 .., lanes 16..31 = output columns 0 ..
+        G.wseg = WRAP_HALF + KW - 1;
+        G.wx0 = a.Wout - WRAP_HALF - pad_x;
+        G.wx1 = -pad_x;
+        G.HWreal = 2 * G.wseg;
+    }
 
     // halo DMA instruction q (0..hinstr) is issued by wave q % NWAVES; the source offsets are recomputed per issue
     // (a few VALU per 1-KiB DMA; keeping them in registers cost 10 VGPRs of a kernel that sits at the 256 limit)
@@ -531,7 +553,8 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     // an XOR 32 on the byte address (records are 64-B aligned, the swizzled part index lives in bits 4-5)
     constexpr int PSEL = CPN_FP8 ? 2 : 1;  // first 16-byte part of lane half lhi: lhi (bf16 k-half 0) | 2*lhi (fp8)
     const unsigned w_lane = (unsigned) ((wave_n * WN * 32 + l31) * REC + (((PSEL * lhi) ^ ((l31 >> 2) & 3)) << 4));
-    const int x_lane = (NR ? (l31 & 15) : l31) * S;        // halo column of this lane's pixel for tap column 0
+    // halo column of this lane's pixel for tap column 0 (wrap tile: lanes 16..31 live in the second halo segment)
+    const int x_lane = (NR ? (l31 & 15) : l31) * S + (wrap ? (l31 >> 4) * (KW - 1) : 0);
     const int row_wave = wave_m * WM * RPF * S;            // halo row of fragment 0 for tap row 0
     constexpr int FRAG_STRIDE = RPF * S * PITCH * REC;     // bytes between the halo rows of consecutive fragments
     const unsigned nr_lane = NR ? (unsigned) ((l31 >> 4) * S * PITCH * REC) : 0u;  // narrow: lanes 16..31 = the fragment's 2nd row
@@ -624,7 +647,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
         for (int e = tid; e < 2 * IPR * 64; e += C::THREADS) {
             const int s = e >= IPR * 64, r = e - s * IPR * 64, ln = r & 63;
             const int hx = (r >> 6) * 16 + (ln >> 2);
-            const int ix = G.ix0 + hx * G.sub;
+            const int ix = halo_ix(G, hx);
             unsigned v = OOB_LANE;
             if (hx < G.HWreal && ix >= 0 && ix < G.Win) {
                 const int xs = (s ? G.up1 : G.up0) ? nearest_src(ix, s ? G.sx1 : G.sx0, s ? G.Ws1 : G.Ws0) : ix;
@@ -1032,7 +1055,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
                 const bf16x8 xv = *(const bf16x8 *) (smem + p * (BN * 2) + (((ks * 2 + lhi) ^ fp) << 4));
                 acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, xv, acc2, 0, 0, 0);
             }
-            const int oy = oy0 + row, ox = ox0 + l31;
+            const int oy = oy0 + row, ox = wrap ? (l31 < WRAP_HALF ? a.Wout - WRAP_HALF + l31 : l31 - WRAP_HALF) : ox0 + l31;
             if (oy >= a.Hout || ox >= a.Wout) continue;
             if (a.region) {  // 1: only inside the box [m, H - m) x [m, W - m); 2: only outside it
                 const int m = a.region_margin;
@@ -1151,7 +1174,7 @@ static int launch_mode(const ConvArgs &a, hipStream_t stream) {
         attr_set[dev].store(true, std::memory_order_release);
     }
     const int tiles_x = (a.Wout + TW - 1) / TW, tiles_y = (a.Hout + TH - 1) / TH;
-    const int ntiles = a.region == 2 ? frame_tiles(a.Hout, a.Wout, a.region_margin, TH, TW).total : tiles_x * tiles_y;
+    const int ntiles = a.region == 2 ? frame_tiles(a.Hout, a.Wout, a.region_margin, TH, TW, frame_kw(a)).total : tiles_x * tiles_y;
     dim3 grid((unsigned) (ntiles * a.N), (unsigned) ((a.cout_b + BN - 1) / BN), (unsigned) a.bundles);
     hipLaunchKernelGGL(kern, grid, dim3(C::THREADS), lds, stream, a);
     return (int) hipGetLastError();
@@ -1254,7 +1277,7 @@ double conv_executed_flops(const ConvArgs &a) {
     double px = (double) a.Hout * a.Wout;
     if (a.region == 2) {  // frame-only launch: only the tiles that reach outside the box run (the fused-head kernels' tiles)
         const int th = fused_head_rows(a, choose_tile(a));
-        px = (double) frame_tiles(a.Hout, a.Wout, a.region_margin, th, TW).total * th * TW;
+        px = (double) frame_tiles(a.Hout, a.Wout, a.region_margin, th, TW, frame_kw(a)).total * th * TW;
     }
     return 2.0 * a.N * px * (double) a.bundles * a.cout_b * a.cin_b * a.KH * a.KW;
 }

@@ -868,3 +868,32 @@ def test_bilinear_phase_refinement_head_fp8(dev, name, monkeypatch):
     assert (new[..., f:-f, f:-f] - old[..., f:-f, f:-f]).abs().max() > 0
     for a, b in zip(maps['0'][:2] + maps['0'][3:], maps['2'][:2] + maps['2'][3:]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('size', [(64, 96), (100, 140), (48, 68), (130, 260), (24, 520)])
+def test_bilinear_phase_frame_pixels_identical_any_size(dev, size, monkeypatch):
+    """Frame launches (CPN_SUBPIXEL_BL_FRAME) cut the two sides of a row into ONE wrap tile (output columns W - 16 .. W - 1 and
+    0 .. 15: two halo segments, csrc/conv_igemm.hip frame_tiles): on the frame the op is the head conv itself -- same kernel,
+    same operands, same K order -- so its pixels are bit-identical to the plain head's at any width (multiples of 32 or not, one
+    or several inner tile columns), and the phase convs fill the interior to bf16 accuracy."""
+    import celldetection_amd as cda
+    from celldetection_amd.synth import synth_state_dict
+    x = torch.rand(2, 3, *size, generator=torch.Generator().manual_seed(size[1])).to(dev)
+    maps = {}
+    for mode in ('0', '2'):
+        monkeypatch.setenv('CPN_BLPHASE', mode)
+        m = cda.models.CpnResNet18FPN(3, backbone_kwargs={'fpn_channels': 32, 'backbone_kwargs': {'base_channel': 8}})
+        m.load_state_dict(synth_state_dict(m.state_dict(), seed=5))
+        m = m.to(dev)
+        maps[mode] = m.core_forward(x)[2].float().cpu()
+        prof = m.engine(dev).profile(x, m.core.order, True)
+        ran = [(p['k'], p['gflop'] > 0) for p in prof if 'refinement_head.block.0' in (p['name'] or '')]
+        assert ran == ([(7, True), (5, False), (7, False)] if mode == '0' else [(7, False), (5, True), (7, True)]), (mode, ran)
+    old, new = maps['0'], maps['2']
+    f = 4
+    assert torch.equal(new[..., :f, :], old[..., :f, :]) and torch.equal(new[..., -f:, :], old[..., -f:, :])
+    assert torch.equal(new[..., :, :f], old[..., :, :f]) and torch.equal(new[..., :, -f:], old[..., :, -f:])
+    inner = (new[..., f:-f, f:-f] - old[..., f:-f, f:-f])
+    rel = (inner.norm() / (old[..., f:-f, f:-f].norm() + 1e-12)).item()
+    print(size, 'interior relL2 between phases and the conv over the resized map', f'{rel:.3e}')
+    assert 0 < rel < 5e-2
