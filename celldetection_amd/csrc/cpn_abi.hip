@@ -121,9 +121,14 @@ static void propagate_dims(const cpn_plan *p, int N, int H, int W, ShapePlan &sp
             if (exact && mode != 2) {
                 const int k2 = (o.kh + 3) / 2, m = 2 * ((o.kh / 2 + 1) / 2);
                 auto tiles = [](int h, int w) { return (double) ((h + 7) / 8) * ((w + 31) / 32); };
-                const double inner = (double) std::max((H - m) / 8 - (m + 7) / 8, 0) * std::max((W - m) / 32 - (m + 31) / 32, 0);
+                // frame tiles as the frame launch enumerates them (conv_igemm.hip frame_tiles, 8 x 32 tiles): whole tile rows
+                // above / below the box, per row that crosses it one wrap tile (k <= 9) or its side tiles
+                const int ty0 = (m + 7) / 8, tx0 = (m + 31) / 32, tx1 = std::max((W - m) / 32, tx0), tiles_x = (W + 31) / 32;
+                const int mid = tx1 > tx0 ? std::max((H - m) / 8 - ty0, 0) : 0;
+                const int side = (o.kh <= 9 && W >= 32) ? 1 : tx0 + tiles_x - tx1;
+                const double frame = tiles(H, W) - (double) mid * (tiles_x - side);
                 const double head = tiles(H, W) * o.kh * o.kh;
-                const double parts = 4. * tiles(H / 2, W / 2) * k2 * k2 + (tiles(H, W) - inner) * o.kh * o.kh;
+                const double parts = 4. * tiles(H / 2, W / 2) * k2 * k2 + frame * o.kh * o.kh;
                 exact = parts <= 0.85 * head;
             }
             if (exact && o.up0 != 2) {
