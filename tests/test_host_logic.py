@@ -452,5 +452,10 @@ def test_bilinear_triple_in_fpn_plans(monkeypatch):
                                        bblob.numel(), _lib.PRECISION_FP8), 'create')
         f8[env] = [lib.cpn_plan_executed_flops(hdl, 1, h, w) for h, w in ((512, 512), (75, 101))]
         lib.cpn_plan_destroy(hdl)
+    # closed form of the frame launch at 512^2 (m = 4, 8 x 32 tiles): the tile rows above and below the box whole (2 x 16 tiles),
+    # ONE wrap tile for each of the 62 rows that cross it -> 94 of 1024 tiles run the 7x7 conv; the phases run four 5x5 convs
+    # on all 256 tiles of the 256^2 map
+    tile = 2. * 256 * 32 * 32
+    assert abs(saved - (1024 * 49 - 94 * 49 - 4 * 256 * 25) * tile) < 1e-3 * head
     head8 = 2. * 512 * 512 * 64 * 32 * 49  # (fp8 plans pad channels to 64)
     assert f8['0'][1] == f8[None][1] and 0.3 * head8 < f8['0'][0] - f8[None][0] < 0.5 * head8
