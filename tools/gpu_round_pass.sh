@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-end GPU pass (run on the MI355X box through gpurun, from the repo root):
-#   tools/gpu_round_pass.sh <tag> [tests] [bench] [profile] [sparse] [slide] [configs] [fp8]
+#   tools/gpu_round_pass.sh <tag> [tests] [bench] [profile] [sparse] [slide] [configs] [c4traffic] [fp8]
 # writes everything under gpurun_out/ (the summaries that should be judged are then copied into profiles/).
 TAG=${1:-r04}; shift
 WHAT=${*:-tests bench profile}
@@ -50,6 +50,9 @@ configs)
   timeout 600 python bench.py --model CpnResNet50FPN --batch 8 --tile 1024 --precision fp8 --no-cpu-baseline --steps 10 > gpurun_out/${TAG}_bench_configs4_resnet50fpn_fp8.json 2> gpurun_out/${TAG}_cfg4.err; cut -c1-200 gpurun_out/${TAG}_bench_configs4_resnet50fpn_fp8.json
   (timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $P/c4trace -o b -- python tools/run_graph_only.py 3 CpnResNet50FPN 4 1024 fp8) > $P/c4trace.log 2>&1
   (echo "### tools/run_graph_only.py 3 CpnResNet50FPN 4 1024 fp8 (BASELINE configs[4], the engine's sub-batch of 4 tiles): kernel-trace"; $S $P/c4trace) > gpurun_out/${TAG}_configs4_fp8_rocprofv3_summary.txt 2>&1;;
+c4traffic)  # HBM traffic of BASELINE configs[4] (batch 8 x 1024^2 = two engine sub-batches per graph execution), bf16 and fp8
+  pmc_traffic c4b CpnResNet50FPN/b8/t1024/bf16 CpnResNet50FPN 8 1024 bf16
+  pmc_traffic c4f CpnResNet50FPN/b8/t1024/fp8 CpnResNet50FPN 8 1024 fp8;;
 fp8)
   timeout 600 python bench.py --precision fp8 --no-cpu-baseline > gpurun_out/${TAG}_bench_fp8_n1.json 2> gpurun_out/${TAG}_bench_fp8.err; cat gpurun_out/${TAG}_bench_fp8_n1.json | cut -c1-300
   pmc_traffic f8 CpnResNeXt101UNet/b16/t512/fp8 CpnResNeXt101UNet 16 512 fp8
