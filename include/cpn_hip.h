@@ -97,13 +97,20 @@ enum { CPN_ACT_NONE = 0, CPN_ACT_RELU = 1, CPN_ACT_SIGMOID = 2, CPN_ACT_TANH_SCA
  * .25 x[i-1] + .75 x[i], up[2i+1] = .75 x[i] + .25 x[i+1] per axis), so the conv is FOUR k2 x k2 convs on the low-resolution
  * map, k2 = (k + 3) / 2 (25 instead of 49 taps per output pixel for k = 7; tap sums formed in float64, rounded to bf16
  * once) -- wherever the conv window does not reach beyond the resized image.  A triple of consecutive ops again:
- *   CPN_SUBPIXEL_BL_HEAD   the conv as the reference states it (up0 == 2: bilinear resize in the loader)
- *   CPN_SUBPIXEL_BL_PHASE  src0 = the low-resolution map (no resize), kh = kw = k2, pad = k2 / 2, `bundles` = 4 output
+ *   CPN_SUBPIXEL_BL_HEAD   the conv as the reference states it (bf16 plans: up0 == 2, bilinear resize in the loader; fp8
+ *                          plans: up0 == 0, src0 = the output of a CPN_OP_BILINEAR op of its own)
+ *   CPN_SUBPIXEL_BL_PHASE  src0 = the low-resolution map (no resize; fp8 plans: the map in FRONT of that resize op), kh = kw =
+ *                          k2, pad = k2 / 2, `bundles` = 4 output
  *                          phases sharing cin_b input channels, ONE bias and the fused tail; phase (py, px) writes pixel
  *                          (2i + py, 2j + px) of the external output for the low-resolution pixels i in [F/2, h - F/2)
  *   CPN_SUBPIXEL_BL_FRAME  the HEAD op restricted to the frame of F full-resolution pixels along every edge (F = 4 for
  *                          k = 7, 2 for k = 3), where the conv's zero padding cuts the window
- * The executor runs PHASE + FRAME when the input is exactly twice the feature map's size, HEAD otherwise. */
+ *                          (launched on the tiles that reach into the frame only; per tile row that crosses the interior ONE
+ *                          wrap tile = output columns W - 16 .. W - 1 and 0 .. 15).  A CPN_OP_BILINEAR op flagged
+ *                          CPN_SUBPIXEL_BL_FRAME feeds such a triple: when PHASE + FRAME run it writes only the ring of its
+ *                          output the frame's windows reach (F + k / 2 pixels from the border)
+ * The executor runs PHASE + FRAME when the input is exactly twice the feature map's size and the tile-granular frame leaves
+ * a gain (CPN_BLPHASE=0 / 2 in the environment: never / wherever exact), HEAD otherwise. */
 enum { CPN_SUBPIXEL_NONE = 0, CPN_SUBPIXEL_HEAD = 1, CPN_SUBPIXEL_PHASE = 2, CPN_SUBPIXEL_LATERAL = 3,
        CPN_SUBPIXEL_SCATTER = 4, CPN_SUBPIXEL_BL_HEAD = 5, CPN_SUBPIXEL_BL_PHASE = 6, CPN_SUBPIXEL_BL_FRAME = 7 };
 enum { CPN_OUT_SCORES = 0, CPN_OUT_LOCATIONS = 1, CPN_OUT_FOURIER = 2, CPN_OUT_REFINEMENT = 3, CPN_OUT_UNCERTAINTY = 4,
