@@ -1,14 +1,20 @@
 // fp32 verification path of the conv graph (precision = CPN_PRECISION_F32): NHWC fp32 activations, fp32 weights,
-// fp32 FMA accumulation.  It exists so that the WHOLE path can be compared with the reference's fp32 CPU forward at
+// accumulation in fp64 (round 5; `CPN_F32_ACC=32` restores the plain fp32 FMA chain): a product of two fp32 values is
+// exact in fp64, so an output is the correctly rounded dot product and what remains between this path and the reference's
+// fp32 CPU forward is the reference's OWN summation-order noise (oneDNN blocks its sums differently from any chain we
+// could pick) instead of the sum of two such noises.  It exists so that the WHOLE path can be compared with the reference's fp32 CPU forward at
 // the north-star tolerance (contour coordinates within 1e-4, threshold / NMS index sets equal) -- the bf16 MFMA path
 // cannot be bit-compatible end-to-end because `scores > thresh` and round-half-even are discontinuous.
 // Throughput is not a goal here (a few TFLOP/s on the vector ALUs); every fused feature of the bf16 kernel is
 // supported with identical semantics (virtual concat, nearest-resized sources, resized residual, bundles, activations,
 // fp32 NCHW head outputs).  Weights: [bundle][kh*kw][cin_b][cout_b] fp32.
+#include <cstdlib>
+
 #include "cpn_kernels.h"
 
 namespace cpn {
 
+template <typename ACC>
 __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvArgs a) {
     // one thread = one output pixel x 4 consecutive output channels of one bundle
     const int cq_per_b = a.cout_b >> 2;
@@ -26,7 +32,7 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvArgs a) {
     const int Hs0 = a.Hs0, Ws0 = a.Ws0, Hs1 = a.Hs1, Ws1 = a.Ws1;
     const float *src0 = (const float *) a.src0, *src1 = (const float *) a.src1;
     const float *W = (const float *) a.weights + (size_t) g * a.KH * a.KW * a.cin_b * a.cout_b + cq * 4;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    ACC acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
     for (int ky = 0; ky < a.KH; ++ky) {
         const int iy = oy * a.stride - a.pad + ky;
         if (iy < 0 || iy >= a.Hin) continue;
@@ -46,19 +52,20 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvArgs a) {
                 const float4 w1 = *(const float4 *) (wt + (size_t) (c + 1) * a.cout_b);
                 const float4 w2 = *(const float4 *) (wt + (size_t) (c + 2) * a.cout_b);
                 const float4 w3 = *(const float4 *) (wt + (size_t) (c + 3) * a.cout_b);
-                acc.x += x.x * w0.x + x.y * w1.x + x.z * w2.x + x.w * w3.x;
-                acc.y += x.x * w0.y + x.y * w1.y + x.z * w2.y + x.w * w3.y;
-                acc.z += x.x * w0.z + x.y * w1.z + x.z * w2.z + x.w * w3.z;
-                acc.w += x.x * w0.w + x.y * w1.w + x.z * w2.w + x.w * w3.w;
+                const ACC xx = x.x, xy = x.y, xz = x.z, xw = x.w;
+                acc0 += xx * (ACC) w0.x + xy * (ACC) w1.x + xz * (ACC) w2.x + xw * (ACC) w3.x;
+                acc1 += xx * (ACC) w0.y + xy * (ACC) w1.y + xz * (ACC) w2.y + xw * (ACC) w3.y;
+                acc2 += xx * (ACC) w0.z + xy * (ACC) w1.z + xz * (ACC) w2.z + xw * (ACC) w3.z;
+                acc3 += xx * (ACC) w0.w + xy * (ACC) w1.w + xz * (ACC) w2.w + xw * (ACC) w3.w;
             }
         }
     }
     const int co = g * a.cout_b + cq * 4;
-    float v[4] = {acc.x, acc.y, acc.z, acc.w};
-    if (a.bias) {
+    if (a.bias) {  // (added before the one rounding to fp32)
         const float4 b = *(const float4 *) (a.bias + co);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        acc0 += (ACC) b.x; acc1 += (ACC) b.y; acc2 += (ACC) b.z; acc3 += (ACC) b.w;
     }
+    float v[4] = {(float) acc0, (float) acc1, (float) acc2, (float) acc3};
     const size_t pix = ((size_t) n * a.Hout + oy) * a.Wout + ox;
     if (a.out_mode == OUT_BF16_NHWC) {  // (fp32 NHWC in this precision)
         if (a.res) {
@@ -86,7 +93,9 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(const ConvArgs a) {
 int launch_conv_f32(const ConvArgs &a, hipStream_t stream) {
     if (a.cin_b % 4 || a.cout_b % 4 || a.out_mode == OUT_FUSED_HEAD) return (int) hipErrorInvalidValue;
     const long total = (long) a.N * a.Hout * a.Wout * a.bundles * (a.cout_b >> 2);
-    hipLaunchKernelGGL(conv_f32_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, stream, a);
+    static const bool acc32 = [] { const char *e = getenv("CPN_F32_ACC"); return e && atoi(e) == 32; }();
+    if (acc32) hipLaunchKernelGGL(conv_f32_kernel<float>, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(conv_f32_kernel<double>, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, stream, a);
     return (int) hipGetLastError();
 }
 

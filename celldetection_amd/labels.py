@@ -4,8 +4,9 @@ called from celldetection_scripts/cpn_inference.py:811), backed by ``csrc/labels
 Same result as the reference's sequential loop (contour i -> value i + 1 in the first channel whose gap-expanded
 bounding-box region is still empty), computed in parallel rounds over independent contours.  The polygon fill restates
 OpenCV's ``drawContours(thickness=-1)`` rule for integer vertices (cv2 is absent from the build image: see
-``oracle/labels_oracle.py`` -- parity with cv2 itself is unpinned).  ``ioa_thresh`` / ``return_indices`` sit behind the fill
-(pure index work): restated from the reference's own Python.
+``oracle/labels_oracle.py`` -- parity with cv2 itself is unpinned).  Everything around the fill -- ``sort_by``, rounding,
+clipping, ``ioa_thresh`` / ``return_indices``, the gap rule, channels, numbering -- is checked against outputs of the imported
+reference loop (``tests/golden/labels.npz``).
 """
 from ctypes import c_int32
 
@@ -33,7 +34,11 @@ def contours2labels(contours, size, rounded=True, clip=True, initial_depth=1, ga
         arrs = [np.asarray(c.detach().cpu() if isinstance(c, torch.Tensor) else c, np.float32).reshape(-1, 2) for c in contours]
         smax = max([len(a) for a in arrs] + [1])
         arrs = [np.concatenate((a, np.repeat(a[-1:], smax - len(a), 0))) if 0 < len(a) < smax else a for a in arrs]
-        arrs = [a for a in arrs if len(a)]
+        if any(len(a) == 0 for a in arrs):
+            # the reference fails on an empty contour as well (np.min of an empty array in render_contour, data/cpn.py:248);
+            # dropping it would silently shift the label values and the returned indices against the caller's list
+            raise ValueError('contours2labels: zero-length contour at position '
+                             f'{[i for i, a in enumerate(arrs) if len(a) == 0][0]}')
         contours = torch.as_tensor(np.stack(arrs) if arrs else np.zeros((0, 1, 2), np.float32))
         contours = contours.cuda() if torch.cuda.is_available() else contours
     if not contours.is_cuda:

@@ -4,7 +4,12 @@ Restates ``celldetection.data.contours2labels`` (celldetection/data/cpn.py:292-3
 (:245-255) for the default arguments used by celldetection_scripts/cpn_inference.py:811 (rounded, clip, gap=3,
 initial_depth=1, int32) and the ``ioa_thresh`` / ``return_indices`` options.
 
-**Parity unpinned.**  ``render_contour`` calls ``cv2.drawContours(thickness=-1)``; OpenCV is not installed in the build
+**Pinning (round 5).**  The LOOP -- ordering (``sort_by`` / ``sort_descending``), rounding, clipping, the bounding box,
+``ioa_thresh`` / ``return_indices``, the gap rule, the channel search, label numbering -- is pinned to the reference
+itself: ``tests/golden/labels.npz`` holds outputs of the IMPORTED ``celldetection.data.cpn.contours2labels`` (with
+``cv2.drawContours`` replaced by ``ref_shim.cv2_drawContours``, which calls ``fill_polygon`` below), and
+``tests/test_labels.py`` checks this restatement against them.  **The fill rule itself stays unpinned (third party):**
+``render_contour`` calls ``cv2.drawContours(thickness=-1)``; OpenCV is not installed in the build
 image and is not part of /root/reference, so the polygon fill rule below is a restatement of OpenCV's published
 algorithm (modules/imgproc/src/drawing.cpp, 4.x: ``CollectPolyEdges`` draws every edge with the 8-connected
 ``LineIterator`` (left-to-right), ``FillEdgeCollection`` fills the scanlines between paired, rounded 16.16 fixed-point
@@ -80,10 +85,16 @@ def fill_polygon(points, x0, y0, w, h):
 
 
 def contours2labels(contours, size, rounded=True, clip=True, initial_depth=1, gap=3, dtype='int32', ioa_thresh=None,
-                    return_indices=False):
-    """data/cpn.py:329-358 with ``sort_by=None`` (ioa_thresh: :341-350, return_indices: :356-357 -- the index list is only
-    filled when ``ioa_thresh`` is given, like in the reference)."""
+                    sort_by=None, sort_descending=True, return_indices=False):
+    """data/cpn.py:329-358 (sort_by: :330-334 -- ``np.argsort``, reversed for descending; the returned indices are then
+    positions in the SORTED sequence, as there; ioa_thresh: :341-350; return_indices: :356-357 -- the index list is only filled
+    when ``ioa_thresh`` is given, like in the reference)."""
     H, W = size
+    if sort_by is not None:
+        indices = np.argsort(sort_by)
+        if sort_descending:
+            indices = indices[::-1]
+        contours = [contours[i] for i in indices]
     labels = np.zeros((H, W, initial_depth), dtype=dtype)
     lbl = 1
     keep = []

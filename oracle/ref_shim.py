@@ -24,6 +24,7 @@ import sys
 import types
 from collections import OrderedDict
 
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -335,6 +336,22 @@ def remove_small_boxes(boxes, min_size):
     return torch.where(keep)[0]
 
 
+def cv2_drawContours(image, contours, contourIdx, color, thickness=1, lineType=8, hierarchy=None, maxLevel=None,
+                     offset=(0, 0)):
+    """Functional stand-in for ``cv2.drawContours(..., thickness=-1, offset=...)`` as ``render_contour`` calls it
+    (celldetection/data/cpn.py:252-254): fills ONE integer polygon into ``image`` in place and returns it.  The fill rule is
+    ``labels_oracle.fill_polygon`` -- a restatement of OpenCV's published scan-line fill that could NOT be checked against
+    cv2 here (third-party, unpinned, exactly like ``nms_cpu`` above).  What this stand-in makes importable -- and therefore
+    pins -- is the reference's own loop around it (``contours2labels``, data/cpn.py:292-358)."""
+    from labels_oracle import fill_polygon
+    if thickness >= 0:
+        raise NotImplementedError('stand-in: filled contours only (thickness=-1)')
+    pts = np.asarray(contours[contourIdx]).reshape(-1, 2).astype(np.int64) + np.asarray(offset, np.int64)
+    h, w = image.shape[:2]
+    image[fill_polygon(pts, 0, 0, w, h)] = color
+    return image
+
+
 _INSTALLED = False
 
 
@@ -392,6 +409,10 @@ def install():
     tr = mod('torchvision.transforms')
     tr.Normalize = TvNormalize
     tr.Compose = TvCompose
+
+    # cv2: everything a stub except the one call on the label path
+    cv = mod('cv2')
+    cv.drawContours = cv2_drawContours
 
     # dispatcher op torch.ops.torchvision.nms
     try:

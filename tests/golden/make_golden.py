@@ -10,6 +10,10 @@ Imports the read-only Python reference (celldetection 0.4.9) through ``oracle/re
                    via ``celldetection_amd.synth``; the file holds the 8 calibrated head tensors, the input,
                    the five ``CPNCore`` maps and the full ``CPN.forward`` outputs (nms on/off, offsets, bounds)
 * ``stitch.npz``   G8: multi-tile stitch (TileLoader offsets/overlaps -> border removal -> global NMS)
+* ``labels.npz``   G10: ``celldetection.data.cpn.contours2labels`` (the reference's own loop, imported; the one cv2 call
+                   inside it goes through ``ref_shim.cv2_drawContours`` = the restated fill, third-party unpinned):
+                   overlapping / nested contours, gap 0 / 3, initial_depth 1 / 2, ioa_thresh None / .3 / .8 with
+                   return_indices, sort_by ascending / descending, unrounded and unclipped inputs, ragged lists
 * ``stitch_dups.npz`` G8b: the stitching rule on synthetic per-tile detections WITH cross-tile duplicates (the global
                    NMS removes > 10 % of what survives the border rule)
 
@@ -394,6 +398,84 @@ def gen_stitch_dups():
     save('stitch_dups.npz', **out)
 
 
+def label_contours(seed, k, size, s=24, inside=False, nested=0):
+    """Star-shaped float contours [k, s, 2] (xy) on an image of ``size`` (h, w): random centres (some outside the image
+    unless ``inside``), radii 4..18, fractional coordinates incl. exact .5 values; the last ``nested`` ones sit inside the
+    first ones."""
+    rng = np.random.default_rng(seed)
+    h, w = size
+    t = np.linspace(0, 2 * np.pi, s, endpoint=False)
+    out = []
+    for i in range(k):
+        r = rng.uniform(4, 18)
+        lo = r * 1.4 + 1 if inside else -6
+        c = np.array([rng.uniform(lo, w - 1 - lo), rng.uniform(lo, h - 1 - lo)])
+        if i >= k - nested:
+            j = i - (k - nested)
+            c = out[j].mean(0) + rng.uniform(-1, 1, 2)
+            r = rng.uniform(2, 4)
+        rad = r * (1 + .3 * np.sin(rng.integers(2, 5) * t + rng.uniform(0, 6)))
+        con = np.stack((c[0] + rad * np.cos(t), c[1] + rad * np.sin(t)), 1)
+        con = np.round(con * 4) / 4  # quarters: exact .5 coordinates occur (np.round half-to-even)
+        out.append(con.astype(np.float32))
+    return np.stack(out)
+
+
+LABEL_CASES = [
+    # (name, contour spec, size, kwargs of contours2labels)
+    ('default', dict(seed=1, k=60, nested=8), (120, 160), dict()),
+    ('gap0', dict(seed=2, k=60, nested=8), (120, 160), dict(gap=0)),
+    ('depth2', dict(seed=3, k=50, nested=5), (100, 140), dict(initial_depth=2)),
+    ('ioa03', dict(seed=4, k=70, nested=12), (120, 160), dict(ioa_thresh=.3, return_indices=True)),
+    ('ioa08', dict(seed=4, k=70, nested=12), (120, 160), dict(ioa_thresh=.8, return_indices=True, gap=0)),
+    ('ioa_noidx', dict(seed=5, k=40, nested=6), (90, 90), dict(ioa_thresh=.5)),
+    ('idx_noioa', dict(seed=5, k=40, nested=6), (90, 90), dict(return_indices=True)),
+    ('sort_desc', dict(seed=6, k=60, nested=10), (120, 160), dict(sort_by='scores', ioa_thresh=.3, return_indices=True)),
+    ('sort_asc', dict(seed=6, k=60, nested=10), (120, 160), dict(sort_by='scores', sort_descending=False)),
+    ('sort_only', dict(seed=7, k=30, nested=4), (80, 100), dict(sort_by='scores', return_indices=True, ioa_thresh=.8)),
+    ('unrounded', dict(seed=8, k=50, nested=6), (120, 160), dict(rounded=False)),
+    ('unclipped', dict(seed=9, k=40, nested=6, inside=True), (120, 160), dict(clip=False)),
+    ('raw', dict(seed=10, k=40, nested=6, inside=True), (120, 160), dict(clip=False, rounded=False, gap=1)),
+    ('dense', dict(seed=11, k=150, nested=30), (96, 96), dict(ioa_thresh=.6, return_indices=True)),
+    ('ragged', dict(seed=12, k=30, nested=4), (100, 100), dict()),
+    ('empty', dict(seed=0, k=0), (40, 50), dict(initial_depth=2, return_indices=True)),
+]
+
+
+def gen_labels():
+    """G10: outputs of the reference's own ``contours2labels`` loop (data/cpn.py:292-358)."""
+    import json
+    from celldetection.data.cpn import contours2labels
+    out, meta = {}, []
+    for name, spec, size, kw in LABEL_CASES:
+        spec = dict(spec)
+        k = spec.pop('k')
+        con = label_contours(k=k, size=size, **spec) if k else np.zeros((0, 24, 2), np.float32)
+        kw = dict(kw)
+        if kw.get('sort_by') == 'scores':
+            scores = np.random.default_rng(100 + spec['seed']).permutation(k).astype(np.float32) / k  # distinct values
+            kw['sort_by'] = scores
+            out[f'{name}.sort_by'] = scores
+        if name == 'ragged':  # List[Array[num_points, 2]] of different lengths
+            arg = [c[:24 - (i % 5) * 3].copy() for i, c in enumerate(con)]
+            out[f'{name}.lengths'] = np.array([len(a) for a in arg])
+        else:
+            arg = con.copy()  # (clip without rounding works in place on the caller's array)
+        res = contours2labels(arg, size, **kw)
+        labels, keep = res if kw.get('return_indices') else (res, None)
+        assert labels.dtype == np.int32 and labels.shape[:2] == tuple(size)
+        out[f'{name}.contours'] = con
+        out[f'{name}.labels'] = labels
+        if keep is not None:
+            out[f'{name}.keep'] = np.asarray(keep, np.int64)
+        meta.append(dict(name=name, size=list(size), kwargs={a: (b if not isinstance(b, np.ndarray) else 'sort_by')
+                                                            for a, b in kw.items()}))
+        print(f'labels/{name}: {k} contours -> {labels.shape[2]} channels, max label {int(labels.max()) if labels.size else 0}'
+              + (f', kept {len(keep)}' if keep is not None else ''))
+    out['cases'] = np.array(json.dumps(meta))
+    save('labels.npz', **out)
+
+
 def gen_checkpoint():
     """G9: a model file written by the reference's OWN ``save_fetchable_model`` (util/util.py:545-560) -- tiny CpnU22 with one
     attribute changed after construction (-> ``updated_kwargs``) -- plus the reference's outputs for one input.  The file
@@ -412,7 +494,9 @@ def gen_checkpoint():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['ops', 'tiling', 'models', 'stitch', 'checkpoint']
+    which = sys.argv[1:] or ['ops', 'tiling', 'models', 'stitch', 'checkpoint', 'labels']
+    if 'labels' in which:
+        gen_labels()
     if 'checkpoint' in which:
         gen_checkpoint()
     if 'ops' in which:

@@ -64,6 +64,47 @@ def check_exact(prefix, y, g, n, raw_atol=1e-4, flip_frac=0.):
                 np.testing.assert_allclose(got, exp, rtol=0, atol=atol, err_msg=f'{prefix}.{k}.{i}')
 
 
+def north_star_check(label, got, ref, flip_frac=1e-3, raw_atol=1e-3):
+    """BASELINE.json north_star, literally: ``outputs match the reference CPU PyTorch forward on identical inputs/weights
+    (contour coords within 1e-4 fp32, score-threshold/NMS index sets bit-exact)``.  ``got`` = the HIP path with
+    ``precision='fp32'``, ``ref`` = ``cpn_oracle.cpn_forward`` (pinned to the imported reference by the goldens).
+    Index sets: same number of detections per image in the same order -- proposals come in ``torch.where`` order and NMS
+    survivors in descending-score order, so equal counts + equal classes + positions that agree to a fraction of a pixel
+    (``locations``: the proposal's own pixel + a sub-pixel offset, scaled) ARE equal index sets.  Coordinates: contours /
+    boxes / scores within 1e-4, except the documented pixel-snap flips (``local_refinement`` rounds half-to-even; a
+    coordinate within summation-order noise of x.5 lands on the other pixel and reads another refinement vector): their
+    fraction is printed and bounded by ``flip_frac``.  The raw, un-snapped regression outputs (locations, fourier,
+    contour_proposals: O(100) px x 1e-6 relative) get ``raw_atol``.  -> dict of the measured figures."""
+    rep = {}
+    n = len(ref['scores'])
+    assert len(got['scores']) == n
+    for i in range(n):
+        for k in ('scores', 'classes', 'locations', 'contours', 'boxes', 'fourier', 'contour_proposals'):
+            g, e = got[k][i].cpu().numpy(), np.asarray(ref[k][i])
+            assert g.shape == e.shape, f'{label}: {k}[{i}] index sets differ: {g.shape} vs {e.shape}'
+            if k == 'classes':
+                np.testing.assert_array_equal(g, e, err_msg=f'{label}.{k}.{i}')
+                continue
+            if e.size == 0:
+                continue
+            d = np.abs(g.astype(np.float64) - e.astype(np.float64))
+            rep[f'{k}.max'] = max(rep.get(f'{k}.max', 0.), float(d.max()))
+            if k == 'locations':
+                assert d.max() < .25, f'{label}: proposal {int(d.max(1).argmax())} of image {i} sits on another pixel'
+            if k in ('contours', 'boxes'):
+                bad = float((d > 1e-4).mean())
+                rep[f'{k}.frac_off'] = max(rep.get(f'{k}.frac_off', 0.), bad)
+                rep[f'{k}.max_noflip'] = max(rep.get(f'{k}.max_noflip', 0.), float(d[d < .1].max()) if (d < .1).any() else 0.)
+                assert bad <= flip_frac, f'{label}.{k}.{i}: {bad:.2e} of the coordinates off by > 1e-4 (allowed {flip_frac})'
+            elif k == 'scores':
+                np.testing.assert_allclose(g, e, rtol=0, atol=1e-4, err_msg=f'{label}.{k}.{i}')
+            else:
+                np.testing.assert_allclose(g, e, rtol=0, atol=raw_atol, err_msg=f'{label}.{k}.{i}')
+    print(f'north-star check {label}: detections {[len(t) for t in ref["scores"]]}; ' +
+          ', '.join(f'{k} {v:.2e}' for k, v in sorted(rep.items())))
+    return rep
+
+
 @pytest.mark.parametrize('name', list(MODEL_SPECS))
 def test_postprocess_on_reference_head_maps(dev, name):
     """(b): decode -> refinement -> boxes -> NMS on the reference's fp32 head maps is exact."""
@@ -529,6 +570,13 @@ def test_full_size_properties(dev):
     n_ref, n_got = len(ref['scores'][0]), len(got['scores'][0])
     print('full size tile 0: proposals', n_got, 'oracle', n_ref, 'IoU>0.5 match rate', rate)
     assert abs(n_ref - n_got) <= 0.1 * n_ref and rate > .9
+    # THE NORTH-STAR STATEMENT AT THE HEADLINE CONFIG: the fp32 verification path on a full-width 3x512x512
+    # tile against the fp32 CPU oracle -- identical proposal and NMS index sets, contours within 1e-4 (snap flips reported)
+    model.precision = 'fp32'
+    north_star_check('configs[2] tile 0, proposals', model(x[:1], nms=False), ref)
+    ref_nms = orc.cpn_forward({k: v.cpu() for k, v in sd.items()}, x[:1].cpu(), nms=True)
+    assert len(ref_nms['scores'][0]) > 20
+    north_star_check('configs[2] tile 0, after NMS', model(x[:1], nms=True), ref_nms)
     # fp8 graph at full size: proposals IoU-matched against the fp32 oracle's (e4m3 activations: 3-bit mantissa)
     model.precision = 'fp8'
     model.calibrate_fp8(x[:2])
@@ -557,10 +605,9 @@ def test_fp8_precision_vs_reference_maps(dev, name):
         assert got.shape == e.shape and torch.isfinite(got).all(), key
         rep[key] = ((got - e).norm() / (e.norm() + 1e-12)).item()
     print(name, 'fp8 relL2', {k: f'{v:.3f}' for k, v in rep.items()})
-    # measured 0.08 .. 0.53 on the synthetic-weight tiny models; the CPU simulation of the SAME algorithm (below) gives
-    # 0.38 .. 0.51 on the deepest one (CpnResNet50FPN, whichever stem alternative runs): the bound that matters is the
-    # comparison with that simulation at the end of this test
-    assert max(rep.values()) < 0.6, rep
+    # (no absolute bound here: measured 0.08 .. 0.53 on the synthetic-weight tiny models, a number that would also pass a
+    # broken head -- VERDICT r4.  The gate is the comparison with the CPU simulation of the SAME algorithm at the end of this
+    # test, map by map, plus the IoU-matched proposals.)
     y = model(x, nms=False)
     rates = [_iou_match_rate(y['boxes'][i].cpu().numpy(), g[f'nonms.boxes.{i}']) for i in range(x.shape[0])]
     print(name, 'fp8 proposal IoU>0.5 match rates', rates)
@@ -708,14 +755,49 @@ def test_full_size_properties_config1_resnet18fpn(dev):
     n_ref, n_got = len(ref['scores'][0]), len(got['scores'][0])
     print('configs[1] tile 0: proposals', n_got, 'oracle', n_ref, 'IoU>0.5 match rate', rate)
     assert abs(n_ref - n_got) <= max(3, 0.1 * n_ref) and rate > .9
-    # the fp32 verification path on the same tile: index sets equal, coordinates within 1e-4 of the oracle
+    # the fp32 verification path on the same tile: the north-star statement in the same form as at configs[2]
     model.precision = 'fp32'
-    got32 = model(x[:1], nms=False)
-    assert len(got32['scores'][0]) == n_ref
-    np.testing.assert_allclose(got32['contours'][0].cpu().numpy(), ref['contours'][0], rtol=0, atol=2e-3)
-    bad = float((np.abs(got32['contours'][0].cpu().numpy() - ref['contours'][0]) > 1e-4).mean())
-    print('configs[1] fp32 path: fraction of contour coordinates off by > 1e-4:', bad)
-    assert bad < 5e-3
+    north_star_check('configs[1] tile 0, proposals', model(x[:1], nms=False), ref)
+    ref_nms = orc.cpn_forward({k: v.cpu() for k, v in sd.items()}, x[:1].cpu(), nms=True)
+    north_star_check('configs[1] tile 0, after NMS', model(x[:1], nms=True), ref_nms)
+
+
+def test_full_width_cpnu22_config0(dev):
+    """BASELINE.json configs[0] on the HIP path: the FULL-WIDTH ``CpnU22(3)`` (31.6 M parameters, base_channels 64) on one
+    3x256x256 tile -- bf16 (the product precision) IoU-matched against the fp32 CPU oracle, then the north-star statement on
+    the fp32 verification path, and the default-init model (0 detections) through the whole path."""
+    import sys
+    import cpn_oracle as orc
+    import celldetection_amd as cda
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import build_model
+    model, sd = build_model('CpnU22', dev, tile=256)
+    assert sum(v.numel() for k, v in model.state_dict().items() if 'num_batches' not in k and 'running' not in k
+               and k != 'order_weights') > 31e6
+    torch.manual_seed(0)
+    x = torch.rand(1, 3, 256, 256).to(dev)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    sd_cpu = {k: v.cpu() for k, v in sd.items()}
+    ref = orc.cpn_forward(sd_cpu, x.cpu(), nms=False)
+    n_ref = len(ref['scores'][0])
+    got = model(x, nms=False)
+    rate = _iou_match_rate(got['boxes'][0].cpu().numpy(), ref['boxes'][0])
+    print('configs[0] full-width CpnU22 bf16: proposals', len(got['scores'][0]), 'oracle', n_ref, 'IoU>0.5 match rate', rate)
+    assert n_ref > 50 and abs(n_ref - len(got['scores'][0])) <= max(3, 0.1 * n_ref) and rate > .9
+    _invariants(model, model(x), x, (256, 256))
+    model.precision = 'fp32'
+    north_star_check('configs[0] CpnU22, proposals', model(x, nms=False), ref)
+    north_star_check('configs[0] CpnU22, after NMS', model(x, nms=True), orc.cpn_forward(sd_cpu, x.cpu(), nms=True))
+    # PyTorch-default initialisation, as configs[0] states it: no pixel passes the 0.9 threshold -> empty lists of the
+    # contract's shapes and dtypes (a20)
+    torch.manual_seed(0)
+    plain = cda.models.CpnU22(3).to(dev)
+    y = plain(x)
+    assert list(y) == list(model(x)) and len(y['contours']) == 1
+    k = len(y['scores'][0])
+    print('configs[0] default-init CpnU22: detections', k)
+    assert k == 0, 'SURVEY 8d config 1: the default initialisation yields no detections'
+    assert tuple(y['contours'][0].shape) == (0, 32, 2) and y['classes'][0].dtype == torch.int64 and y['boxes'][0].shape == (0, 4)
 
 
 def test_full_size_properties_config4_resnet50fpn_fp8(dev):

@@ -1,11 +1,62 @@
-"""contours -> label image: the numpy oracle's invariants on the CPU, the HIP path against the
-oracle on the GPU.  cv2 is absent from the image, so the polygon fill rule is a restatement of OpenCV's (parity with
-cv2 itself is unpinned -- see oracle/labels_oracle.py); the channel / gap logic follows the reference's Python."""
+"""contours -> label image.  The LOOP of ``contours2labels`` is pinned to the reference itself:
+``tests/golden/labels.npz`` = outputs of the imported ``celldetection.data.cpn.contours2labels`` (make_golden.py ``labels``);
+the numpy oracle (CPU) and ``labels.hip`` (GPU) are checked against them.  cv2 is absent from the image, so the polygon
+FILL rule inside that loop is a restatement of OpenCV's (third party, unpinned -- see oracle/labels_oracle.py)."""
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
 
 import labels_oracle as lo
+
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'labels.npz')
+
+
+def golden_label_cases():
+    g = np.load(GOLDEN)
+    for case in json.loads(str(g['cases'])):
+        name, kw = case['name'], dict(case['kwargs'])
+        if kw.get('sort_by') == 'sort_by':
+            kw['sort_by'] = g[f'{name}.sort_by']
+        con = g[f'{name}.contours']
+        if f'{name}.lengths' in g:
+            con = [c[:n].copy() for c, n in zip(con, g[f'{name}.lengths'])]
+        yield name, con, tuple(case['size']), kw, g[f'{name}.labels'], (g[f'{name}.keep'] if f'{name}.keep' in g else None)
+
+
+def test_oracle_matches_reference_loop_goldens():
+    """labels_oracle.contours2labels == the imported reference's loop on all 16 fixtures (sort_by / sort_descending,
+    ioa_thresh + return_indices, gap, initial_depth, unrounded / unclipped inputs, ragged lists, no contours)."""
+    n = 0
+    for name, con, size, kw, labels, keep in golden_label_cases():
+        arg = [c.copy() for c in con] if isinstance(con, list) else con.copy()
+        res = lo.contours2labels(arg, size, **kw)
+        got, got_keep = res if kw.get('return_indices') else (res, None)
+        assert got.dtype == labels.dtype and got.shape == labels.shape, name
+        np.testing.assert_array_equal(got, labels, err_msg=name)
+        if keep is not None:
+            assert list(got_keep) == list(keep), name
+        n += 1
+    assert n == 16
+
+
+@pytest.mark.gpu
+def test_contours2labels_matches_reference_loop_goldens():
+    """``labels.hip`` through ``cda.contours2labels`` == the imported reference's loop (same 16 fixtures)."""
+    import celldetection_amd as cda
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    for name, con, size, kw, labels, keep in golden_label_cases():
+        arg = [c.copy() for c in con] if isinstance(con, list) else torch.as_tensor(con).cuda()
+        res = cda.contours2labels(arg, size, **kw)
+        got, got_keep = res if kw.get('return_indices') else (res, None)
+        assert got.dtype == torch.int32 and tuple(got.shape) == labels.shape, (name, tuple(got.shape), labels.shape)
+        np.testing.assert_array_equal(got.cpu().numpy(), labels, err_msg=name)
+        if keep is not None:
+            assert list(got_keep) == list(keep), name
 
 
 def random_contours(rng, k, size, s=16, rmin=2., rmax=9., spread=1.):
