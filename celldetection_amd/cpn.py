@@ -292,7 +292,8 @@ class _Engine:
         slot = None
         if _timed is None and _absmax is None and nb == n and self.precision != 'fp32':
             # kernel-selection switches that are read per launch are frozen into a captured graph: part of the key
-            env = tuple(os.environ.get(k) for k in ('CPN_RW', 'CPN_PWR', 'CPN_PAIR_CPS', 'CPN_TH64'))
+            env = tuple(os.environ.get(k) for k in ('CPN_RW', 'CPN_PWR', 'CPN_PAIR_CPS', 'CPN_TH64', 'CPN_BLPHASE', 'CPN_PAIR',
+                                                      'CPN_S1F'))
             slot = self._graph_slot((n, x.shape[1], h, w, dt, order_total, bool(refinement), env), x, dt, order_total,
                                     refinement, gated)
         if slot is not None and 'graph' in slot:
@@ -484,7 +485,14 @@ class CPN(nn.Module):
         gate = self._gate_requested(_forward_path)
         if self.precision == 'bf16' and not gate and self.sparse_heads == 'auto':
             return self._dense_engine(device)  # ('auto': the dense engine lives next to the gated one)
-        sparse = (gate, bool(self.subpixel)) if self.precision == 'bf16' else None
+        if self.precision == 'bf16' and gate and self.sparse_heads == 'auto' and \
+                self.plan_for('bf16', True).meta.get('sparse_heads') is None:
+            # ('auto' on a plan whose heads do not qualify for the gate: ONE engine serves both paths -- a second set of
+            # packed weights and hipGraph slots would buy nothing)
+            return self._dense_engine(device)
+        # the packed plan depends on `subpixel` in bf16 (sub-pixel triples) AND in fp8 (bilinear phase head): both keys carry it
+        sparse = (gate, bool(self.subpixel)) if self.precision == 'bf16' else \
+            ((None, bool(self.subpixel)) if self.precision == 'fp8' else None)
         if self._engine is None or self._engine.device != device or self._engine.precision != self.precision or \
                 self._engine.sparse_requested != sparse:
             if self.precision == 'fp8':

@@ -54,7 +54,7 @@ struct cpn_plan {
     const float *bias = nullptr;
     size_t bias_count = 0;
     int precision = 0;  // CPN_PRECISION_BF16 / CPN_PRECISION_F32 / CPN_PRECISION_FP8
-    std::map<std::tuple<int, int, int>, cpn::ShapePlan> shape_plans;  // guarded by shape_mutex (std::map nodes are
+    std::map<std::tuple<int, int, int, int, int>, cpn::ShapePlan> shape_plans;  // guarded by shape_mutex (std::map nodes are
     std::mutex shape_mutex;                                            // stable: returned references stay valid)
 };
 
@@ -86,7 +86,7 @@ static PairArgs pair_args(const cpn_plan *p, const cpn_op_desc &o, int N, int H,
     return a;
 }
 
-static void propagate_dims(const cpn_plan *p, int N, int H, int W, ShapePlan &sp) {
+static void propagate_dims(const cpn_plan *p, int N, int H, int W, ShapePlan &sp, int blphase_mode, int pair_mode) {
     const int nt = (int) p->tensors.size();
     sp.th.assign(nt, 0);
     sp.tw.assign(nt, 0);
@@ -110,8 +110,7 @@ static void propagate_dims(const cpn_plan *p, int N, int H, int W, ShapePlan &sp
             // (CPN_BLPHASE=0: kernel A/B switch, read when a shape is planned)
             // ... and the decomposition executes fewer MACs than the conv it replaces: the frame is whole 8 x 32 tiles of the
             // k x k conv, most of a small image (CPN_BLPHASE=0 / 2: never / wherever exact -- kernel A/B and tests)
-            const char *e = getenv("CPN_BLPHASE");
-            const int mode = e ? atoi(e) : 1;
+            const int mode = blphase_mode;
             // bf16 plans: head and frame conv resize their source in the halo loader (up0 == 2, all three ops read the
             // low-resolution map); fp8 plans: the resize is an op of its own, head and frame conv read its output
             const int lo = p->ops[oi + 1].src0;
@@ -121,12 +120,9 @@ static void propagate_dims(const cpn_plan *p, int N, int H, int W, ShapePlan &sp
             if (exact && mode != 2) {
                 const int k2 = (o.kh + 3) / 2, m = 2 * ((o.kh / 2 + 1) / 2);
                 auto tiles = [](int h, int w) { return (double) ((h + 7) / 8) * ((w + 31) / 32); };
-                // frame tiles as the frame launch enumerates them (conv_igemm.hip frame_tiles, 8 x 32 tiles): whole tile rows
-                // above / below the box, per row that crosses it one wrap tile (k <= 9) or its side tiles
-                const int ty0 = (m + 7) / 8, tx0 = (m + 31) / 32, tx1 = std::max((W - m) / 32, tx0), tiles_x = (W + 31) / 32;
-                const int mid = tx1 > tx0 ? std::max((H - m) / 8 - ty0, 0) : 0;
-                const int side = (o.kh <= 9 && W >= 32) ? 1 : tx0 + tiles_x - tx1;
-                const double frame = tiles(H, W) - (double) mid * (tiles_x - side);
+                // frame tiles exactly as the frame launch enumerates them (cpn_kernels.h frame_tiles, 8 x 32 tiles of a stride-1
+                // k x k conv: whole tile rows above / below the box, per row that crosses it one wrap tile or its side tiles)
+                const double frame = (double) frame_tiles(H, W, m, 8, 32, o.kw > 1 ? o.kw : 0).total;
                 const double head = tiles(H, W) * o.kh * o.kh;
                 const double parts = 4. * tiles(H / 2, W / 2) * k2 * k2 + frame * o.kh * o.kh;
                 exact = parts <= 0.85 * head;
@@ -164,8 +160,7 @@ static void propagate_dims(const cpn_plan *p, int N, int H, int W, ShapePlan &sp
             case CPN_OP_CONV_PAIR: {
                 // runs instead of the two convs in front of it wherever the kernel's full-width strips fit the feature map
                 // and its strips x slabs fill the chip (CPN_PAIR=0 / 2: never / wherever supported -- kernel A/B and tests)
-                const char *e = getenv("CPN_PAIR");
-                const int mode = e ? atoi(e) : 1;
+                const int mode = pair_mode;
                 const int mid = p->ops[oi - 2].dst;  // conv1's output: the kernel's H x W (conv2 may stride it down)
                 const PairArgs pa = pair_args(p, o, N, sp.th[mid], sp.tw[mid]);
                 const bool fused = mode != 0 && p->precision == CPN_PRECISION_BF16 && conv_pair_supported(pa) &&
@@ -228,11 +223,15 @@ static void propagate_dims(const cpn_plan *p, int N, int H, int W, ShapePlan &sp
 
 static const ShapePlan &get_shape_plan(cpn_plan *p, int N, int H, int W) {
     std::lock_guard<std::mutex> lock(p->shape_mutex);
-    auto key = std::make_tuple(N, H, W);
+    // the executor's A/B switches are part of the key: toggling CPN_BLPHASE / CPN_PAIR on a live plan re-plans the shape
+    // (the Python engine's hipGraph key carries them as well)
+    const char *eb = getenv("CPN_BLPHASE"), *ep = getenv("CPN_PAIR");
+    const int blphase_mode = eb ? atoi(eb) : 1, pair_mode = ep ? atoi(ep) : 1;
+    auto key = std::make_tuple(N, H, W, blphase_mode, pair_mode);
     auto it = p->shape_plans.find(key);
     if (it != p->shape_plans.end()) return it->second;
     ShapePlan sp;
-    propagate_dims(p, N, H, W, sp);
+    propagate_dims(p, N, H, W, sp, blphase_mode, pair_mode);
     const int nt = (int) p->tensors.size();
     sp.offsets.assign(nt, -1);
     if (sp.error) return p->shape_plans.emplace(key, std::move(sp)).first->second;

@@ -73,6 +73,32 @@ __host__ __device__ inline int nearest_src(int dst, float scale, int in_size) {
     return s < in_size - 1 ? s : in_size - 1;
 }
 
+// tiles (th x tw) of an H x W output that are NOT entirely inside the box [m, H - m) x [m, W - m) (region 2 launches)
+// kw > 0 (stride-1 k x k convs, k <= 9, m <= 16): the two sides of a row that crosses the box are ONE wrap tile -- output
+// columns W - 16 .. W - 1 and 0 .. 15 (two halo segments of 16 + kw - 1 columns in the 48-column halo pitch) -- instead of a
+// whole 32-column tile per side for a frame that is m columns wide
+struct FrameTiles {
+    int ty0, ty1, tx0, tx1;  // tile rows / columns [ty0, ty1) x [tx0, tx1) lie entirely inside the box
+    int top, side, mid, total, wrap;
+};
+constexpr int WRAP_HALF = 16;
+__host__ __device__ inline FrameTiles frame_tiles(int H, int W, int m, int th, int tw, int kw) {
+    FrameTiles f;
+    const int tiles_x = (W + tw - 1) / tw, tiles_y = (H + th - 1) / th;
+    f.ty0 = (m + th - 1) / th; f.tx0 = (m + tw - 1) / tw;
+    f.ty1 = (H - m) / th; f.tx1 = (W - m) / tw;
+    if (f.ty1 < f.ty0) f.ty1 = f.ty0;
+    if (f.tx1 < f.tx0) f.tx1 = f.tx0;
+    if (f.ty0 > tiles_y) f.ty0 = f.ty1 = tiles_y;
+    if (f.tx1 == f.tx0) f.ty1 = f.ty0;  // no inner column: every row is a full row
+    f.top = f.ty0 * tiles_x;
+    f.wrap = kw > 1 && kw <= 9 && m <= WRAP_HALF && W >= 2 * WRAP_HALF && f.tx1 > f.tx0;
+    f.side = f.wrap ? 1 : f.tx0 + (tiles_x - f.tx1);
+    f.mid = (f.ty1 - f.ty0) * f.side;
+    f.total = f.top + f.mid + (tiles_y - f.ty1) * tiles_x;
+    return f;
+}
+
 // picks a tile configuration and launches; returns hipError_t as int
 int launch_conv(const ConvArgs &a, hipStream_t stream);
 int launch_conv_fp8(const ConvArgs &a, hipStream_t stream);  // e4m3 operands, v_mfma_scale_f32_32x32x64_f8f6f4
