@@ -31,7 +31,8 @@ import subprocess
 import sys
 import time
 
-import torch
+_T_PROCESS = time.perf_counter()  # (before `import torch`: 1-2 minutes on a cold box while the image pages in)
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -48,6 +49,17 @@ TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'traffic.json')  # written by tool
 CALIB_RECIPE = 'shift-4.5_gain3_f1.5_l.5_v1'  # part of the cache key of the calibrated synthetic weights
 
 
+PHASES = {'import_torch': time.perf_counter() - _T_PROCESS}
+_T_PHASE = [time.perf_counter()]
+
+
+def phase(name):
+    """Wall seconds since the previous mark (the driver's clock around a cold-box run is mostly set-up: reported in the line)."""
+    now = time.perf_counter()
+    PHASES[name] = PHASES.get(name, 0.) + now - _T_PHASE[0]
+    _T_PHASE[0] = now
+
+
 def build_model(name, dev, seed=0, tile=512, calib_tiles=2):
     """Synthetic weights of the reference shapes, heads calibrated on the GPU.  The calibrated state dict is cached on disk
     for the run (CPN_BENCH_CACHE, default /tmp/cpn_bench_cache): the calibration costs ~8 repack + forward rounds, which
@@ -56,6 +68,17 @@ def build_model(name, dev, seed=0, tile=512, calib_tiles=2):
     from celldetection_amd.synth import calibrate_heads, synth_state_dict
     model = getattr(cda.models, name)(3)
     model.sparse_heads = False  # calibration reads the dense head maps
+    # the calibration only rescales the eight final 1x1 head tensors (synth.HEAD_FINAL_KEYS): its result for the bench
+    # configurations is committed (tools/bench_calibration/*.npz, written by a run with CPN_BENCH_SAVE_CALIB=<dir>), so a
+    # cold box builds the SAME workload -- same weights, same proposal density -- without ~10 repack + forward rounds
+    fix = os.path.join(ROOT, 'tools', 'bench_calibration', f'{name}_t{tile}_s{seed}_c{calib_tiles}_{CALIB_RECIPE}.npz')
+    if os.path.isfile(fix) and os.environ.get('CPN_BENCH_RECALIBRATE') != '1':
+        import numpy as np
+        with np.load(fix) as z:
+            ov = {k: torch.as_tensor(z[k]) for k in z.files}
+        sd = synth_state_dict(model.state_dict(), seed=seed, overrides=ov)
+        model.load_state_dict(sd)
+        return model.to(dev), sd
     cache_dir = os.environ.get('CPN_BENCH_CACHE', '/tmp/cpn_bench_cache')
     cache = os.path.join(cache_dir, f'{name}_t{tile}_s{seed}_c{calib_tiles}_{CALIB_RECIPE}.pt') if cache_dir != '0' else None
     if cache and os.path.isfile(cache):
@@ -95,6 +118,12 @@ def build_model(name, dev, seed=0, tile=512, calib_tiles=2):
             sd['core.score_head.block.4.' + p_] = -sd['core.score_head.block.4.' + p_]
         sd, _ = calibrate_heads(sd, core_fn, score_shift=-4.5, score_gain=3., fourier_std=1.5, location_std=.5)
     model.load_state_dict(sd)
+    if os.environ.get('CPN_BENCH_SAVE_CALIB'):
+        import numpy as np
+        from celldetection_amd.synth import HEAD_FINAL_KEYS
+        os.makedirs(os.environ['CPN_BENCH_SAVE_CALIB'], exist_ok=True)
+        np.savez(os.path.join(os.environ['CPN_BENCH_SAVE_CALIB'], os.path.basename(fix)),
+                 **{k: sd[k].detach().cpu().numpy() for k in HEAD_FINAL_KEYS})
     if cache:
         try:
             os.makedirs(cache_dir, exist_ok=True)
@@ -376,7 +405,9 @@ def main():
         td.init_process_group('nccl', device_id=dev)
         assert td.get_world_size() == args.gpus, (td.get_world_size(), args.gpus)
 
+    phase('import_and_init')
     model, sd = build_model(args.model, dev, tile=args.tile)
+    phase('build_model')
     if args.workload == 'slide':
         return slide_workload(args, model, dev, world, rank, dist)
     g = torch.Generator().manual_seed(100 + rank)
@@ -453,10 +484,12 @@ def main():
         return dt_, ev_, y_
 
     eng = warm_engine()
+    phase('pack_and_warm')
     mem0 = torch.cuda.memory_stats(dev).get('num_device_alloc', 0)
     # ---- timed region of the headline value
     dt, ev, y = timed(args.steps, args.warmup, args.pipeline)
     mem1 = torch.cuda.memory_stats(dev).get('num_device_alloc', 0)
+    phase('timed_region')
     sclk = _sclk_mhz(dev)  # right after the timed region, per rank
     if dist:
         t = torch.tensor([sclk if sclk is not None else -1.], dtype=torch.float64, device=dev)
@@ -524,6 +557,7 @@ def main():
                     print(f"{p['index']:3d} {p['op']:8s} {p['ms']:8.3f} ms", file=sys.stderr)
             print(f'conv graph total {tot:.3f} ms', file=sys.stderr)
 
+    phase('per_op_profile')
     if rank == 0:
         tiles = args.batch * args.steps * world
         value = tiles / dt
@@ -599,11 +633,71 @@ def main():
                                        'conv_graph_ms': sum(a.elapsed_time(b) for a, b in evs) / steps2,
                                        'step_mode': 'forward() per step (dense graph), synchronous'}
             out['gated'] = gated_lines(model, x, args, timed, warm_engine, gf, peak)
+            phase('extras')
+            if (args.model, args.batch, args.tile) == ('CpnResNeXt101UNet', 16, 512):
+                out['configs'] = configs_lines(dev)
+                phase('configs')
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(sd, args.tile)
+            phase('cpu_baseline')
+        out['setup_s'] = {k: round(v, 2) for k, v in PHASES.items()}
         print(json.dumps(out), file=_JSON_OUT, flush=True)
     if dist:
         td.destroy_process_group()
+
+
+def measure_pipelined(model, x, steps, warmup=2):
+    """One GPU, no process group: engine warm-up (hipGraph slots captured), `steps` pipelined steps between synchronizes ->
+    (seconds, HIP-event pairs around every conv-graph execution, last output, engine)."""
+    eng = model.engine(x.device)
+    for _ in range(eng.GRAPH_SLOTS + 1):
+        model.core_forward(x, _static_ok=True)
+    y = None
+    for y in model.forward_pipelined((x for _ in range(max(warmup, 2)))):
+        pass
+    torch.cuda.synchronize()
+    ev = []
+    t0 = time.perf_counter()
+    for y in model.forward_pipelined((x for _ in range(steps)), _events=ev):
+        pass
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, ev, y, eng
+
+
+def configs_lines(dev):
+    """BASELINE.json configs[1] and configs[4] (its per-GPU share: 32 tiles over 4 GPUs, no data-path collective) under the
+    SAME clock as the headline: dense reference graph, pipelined tile loop, inputs resident in HBM.
+    `frac` prices the REFERENCE graph's FLOPs over the conv-graph time, `executed_frac` the FLOPs the MFMA loops execute (the
+    bilinear phase head executes 0.55-0.68 of the reference's): the hardware-utilisation figure is the second one."""
+    from celldetection_amd.graph import reference_flops
+    out = []
+    for label, name, batch, tile, precision, steps in (
+            ('configs[1]', 'CpnResNet18FPN', 8, 512, 'bf16', 20),
+            ('configs[4] per-GPU share (8 of 32 tiles)', 'CpnResNet50FPN', 8, 1024, 'fp8', 10)):
+        t_setup = time.perf_counter()
+        model, _ = build_model(name, dev, tile=tile, calib_tiles=1 if tile > 512 else 2)
+        model.sparse_heads = False
+        x = torch.rand(batch, 3, tile, tile, generator=torch.Generator().manual_seed(100)).to(dev)
+        if precision == 'fp8':
+            model.precision = 'fp8'
+            model.calibrate_fp8(x[:1])
+        t_setup = time.perf_counter() - t_setup
+        dt, ev, y, eng = measure_pipelined(model, x, steps)
+        conv_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+        gf = reference_flops(model._plan, tile, tile) / 1e9
+        executed = eng.executed_flops(batch, tile, tile) / 1e9
+        peak = PEAK_BF16_TFLOPS * (2 if precision == 'fp8' else 1)
+        traffic, traffic_src = load_traffic(name, batch, tile, precision)
+        out.append({'config': label, 'model': name, 'batch': batch, 'tile': tile, 'dtype': precision,
+                    'value': batch * steps / dt, 'unit': 'tiles/s', 'steps': steps, 'ms_per_step': 1e3 * dt / steps,
+                    'conv_graph_ms': conv_ms, 'algorithmic_gflop_per_launch': gf * batch,
+                    'executed_gflop_per_launch': executed, 'peak': peak, 'frac': gf * batch / conv_ms / peak,
+                    'executed_frac': executed / conv_ms / peak, 'traffic': traffic, 'traffic_source': traffic_src,
+                    'detections_last_step': sum(len(v) for v in y['scores']), 'setup_s': t_setup})
+        del model, eng, x, y
+        torch.cuda.empty_cache()
+    return {'note': 'same run and box as the headline, outside its timed region; one GPU; dense reference graph, '
+                    'forward_pipelined()', 'lines': out}
 
 
 def gated_lines(model, x, args, timed, warm_engine, gf_tile, peak, densities=(.01, .10)):

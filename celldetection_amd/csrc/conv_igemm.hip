@@ -122,12 +122,21 @@ __device__ __forceinline__ void add_res8(float (&v)[8], const store8_t r, float)
 #ifndef CPN_RW_DEFAULT
 #define CPN_RW_DEFAULT 0  // see conv_mode
 #endif
-enum Mode : int { MODE_PW = 0, MODE_S1 = 1, MODE_S2 = 2, MODE_BL = 3, MODE_S1R = 4, MODE_PWR = 5, MODE_N = 6 };
+#ifndef CPN_S1F_DEFAULT
+#define CPN_S1F_DEFAULT 1  // see flat_ok
+#endif
+// MODE_S1F (round 5) = MODE_S1 for TWO co-resident 4-wave workgroups per CU (tile 8 x 32 px x 128 cout, the flagship's 128 px x
+// 64 cout wave tile): a tile's head (first DMA round trip) and tail (LDS-staged epilogue + 64 KiB of stores, MFMA idle) overlap
+// the OTHER workgroup's main loop instead of nothing.  What makes two of them fit the 160 KiB: a FLAT halo tile with a row pitch
+// of 36 records (34 used by a 3x3 conv) instead of 48 -- a DMA instruction covers 16 consecutive records across row ends, its
+// per-lane source offsets are six loop-invariant registers per wave (no column table) -- and 128-row weight slabs: 2 x 23 + 32
+// = 78 KiB.  Single-source stride-1 k x k convs, 2 <= k <= 5, NHWC output.
+enum Mode : int { MODE_PW = 0, MODE_S1 = 1, MODE_S2 = 2, MODE_BL = 3, MODE_S1R = 4, MODE_PWR = 5, MODE_N = 6, MODE_S1F = 7 };
 
 template <int MODE>
 struct ModeCfg {
     static constexpr int S = MODE == MODE_S2 ? 2 : 1;                              // conv stride
-    static constexpr int PITCH = (MODE == MODE_PW || MODE == MODE_PWR || MODE == MODE_N) ? 32 : (MODE == MODE_S2 ? 80 : 48);  // halo row pitch (pixels)
+    static constexpr int PITCH = (MODE == MODE_PW || MODE == MODE_PWR || MODE == MODE_N) ? 32 : (MODE == MODE_S2 ? 80 : (MODE == MODE_S1F ? 36 : 48));  // halo row pitch (pixels)
 };
 
 template <int TH, int BN, int WM, int WN>
@@ -323,13 +332,14 @@ __device__ __forceinline__ ItemState next_item(const ItemState I, int KH, int KW
 }
 
 template <int TH, int BN, int WM, int WN, int MODE>
-__global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igemm_kernel(const ConvArgs a) {
+__global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), (MODE == MODE_S1F ? 2 : 1)) void conv_igemm_kernel(const ConvArgs a) {
     using C = Cfg<TH, BN, WM, WN>;
     constexpr int S = ModeCfg<MODE>::S;
     constexpr int PITCH = ModeCfg<MODE>::PITCH;
     constexpr bool PW = MODE == MODE_PW || MODE == MODE_PWR;
     constexpr bool BL = MODE == MODE_BL;
     constexpr bool RW = MODE == MODE_S1R || MODE == MODE_PWR;  // weights: global -> registers (no weight tiles in LDS)
+    constexpr bool FL = MODE == MODE_S1F;  // flat halo tile (pitch 36), two 4-wave workgroups per CU
     constexpr bool NR = MODE == MODE_N;  // narrow output: fragment = 2 rows x 16 px; a.Hout / a.Wout are the virtual [H/2][32]
     constexpr int RPF = NR ? 2 : 1;      // output rows per pixel fragment
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -345,6 +355,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     const int tiles_y = (a.Hout + TH - 1) / TH;
     int bid = blockIdx.x;
     int tx, ty, n;
+    int yblk = blockIdx.y;
     bool wrap = false;  // (block-uniform) this block is a wrap tile of a frame launch
     if (a.region == 2) {
         // frame-only launch: the grid holds ONLY the tiles that reach outside the box [m, H - m) x [m, W - m), enumerated rows
@@ -367,13 +378,23 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
             ty = F.ty1 + q; tx = r - q * tiles_x;
         }
     } else {
+        if constexpr (FL) {
+            // the cout blocks of a pixel tile are folded into blockIdx.x so that they are CONSECUTIVE workgroups of one XCD
+            // (block id mod 8 = XCD): bid = (group of 8 tiles, cout block, tile within the group) -- they read the same halo
+            // tiles through one L2 (ideally as the two residents of one CU) instead of a whole grid sweep apart
+            const int nh = (a.cout_b + BN - 1) / BN;
+            const int j = bid & 7, r = bid >> 3;
+            yblk = r % nh;
+            bid = (r / nh) * 8 + j;
+            if (bid >= tiles_x * tiles_y * a.N) return;  // (grid rounded up to whole groups of 8 tiles)
+        }
         tx = bid % tiles_x;
         bid /= tiles_x;
         ty = bid % tiles_y;
         n = bid / tiles_y;
     }
     const int oy0 = ty * TH, ox0 = tx * TW;
-    const int n0 = blockIdx.y * BN;  // first output channel (within the bundle) of this block
+    const int n0 = yblk * BN;  // first output channel (within the bundle) of this block
     const int g = blockIdx.z;        // bundle
 
     const int KW = PW ? 1 : a.KW;
@@ -398,8 +419,8 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     constexpr int WITEM = BN * REC;   // one item's weight slab tile
     constexpr int WBUF = 2 * WITEM;   // one step's weights
     const int ldsW_off = nhb * halo_buf;
-    constexpr int IPR = PITCH / 16;  // halo DMA instructions per halo row (16 pixel records of 64 B each)
-    static_assert(PITCH % 16 == 0, "a halo row must be a whole number of DMA instructions");
+    constexpr int IPR = FL ? 1 : PITCH / 16;  // halo DMA instructions per halo row (16 pixel records of 64 B each)
+    static_assert(FL || PITCH % 16 == 0, "a halo row must be a whole number of DMA instructions");
     typedef __attribute__((address_space(3))) unsigned lds_u32_t;
     lds_u32_t *const coltab = (lds_u32_t *) (smem + ldsW_off + 2 * WBUF);  // column offset table (see below)
 
@@ -459,10 +480,41 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
         a_voff[it] = o0 < 0 ? OOB_LANE : (unsigned) o0 * (unsigned) ES;  // out-of-image lanes read zeros
     }
 
+    // MODE_S1F: DMA instruction q covers records 16 q .. 16 q + 15 of the FLAT halo tile (record r = halo row r / 36, column
+    // r % 36): lane -> (record, 16-byte slot), the slot holds channel part slot ^ ((column >> 2) & 3) -- the same column-only
+    // swizzle the fragment reads undo.  Per-lane byte offsets within the image are loop constants of the tile (one register per
+    // instruction of this wave); image + channel chunk travel in the scalar offset.  Single source, no resize.
+    constexpr int FQ = FL ? (((8 - 1 + 5) * 36 * 4 + 63) / 64 + C::NWAVES - 1) / C::NWAVES : 1;
+    unsigned f_voff[FQ];
+    unsigned f_soff = 0;
+    if constexpr (FL) {
+        f_soff = (unsigned) (((size_t) n * a.Hs0 * a.Ws0 * a.c0_stride + cin0) * ES);
+#pragma unroll
+        for (int it = 0; it < FQ; ++it) {
+            const int idx = ((wave + it * C::NWAVES) << 6) + lane;
+            const int rec = idx >> 2;
+            const int hy = rec / PITCH, hx = rec - hy * PITCH;
+            const int iy = G.iy0 + hy, ix = G.ix0 + hx;
+            const bool valid = hy < HH && hx < G.HWreal && iy >= 0 && iy < G.Hin && ix >= 0 && ix < G.Win;
+            f_voff[it] = valid ? (unsigned) (((iy * a.Ws0 + ix) * a.c0_stride + ((idx & 3) ^ ((hx >> 2) & 3)) * EPP) * ES) : OOB_LANE;
+        }
+    }
+
 #define HALO_DMA(CHUNK) HALO_DMA_RANGE(CHUNK, 0, hinstr)
 
     // instructions [Q0, Q1) of the halo tile of chunk CHUNK
 #define HALO_DMA_RANGE(CHUNK, Q0, Q1)                                                                          \
+    if constexpr (FL) {                                                                                        \
+        const int c_ = (CHUNK);                                                                                \
+        const unsigned s_ = f_soff + (unsigned) (c_ * CH * ES);                                                \
+        unsigned char *dstb_ = smem + (c_ & nhb_mask) * halo_buf;                                              \
+        _Pragma("unroll") for (int it_ = 0; it_ < FQ; ++it_) {                                                 \
+            const int q_ = wave + it_ * C::NWAVES;                                                             \
+            if (q_ < hinstr) bdma16(rs0, f_voff[it_], s_, dstb_ + (q_ << 10));                                 \
+        }                                                                                                      \
+    } else HALO_DMA_RANGE_ROWS(CHUNK, Q0, Q1)
+
+#define HALO_DMA_RANGE_ROWS(CHUNK, Q0, Q1)                                                                          \
     {                                                                                                          \
         const int c_ = (CHUNK);                                                                                \
         const int cin_ = cin0 + c_ * CH;                                                                       \
@@ -619,7 +671,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
     // instruction.  The column parts of both sources live in a small LDS table (2 x IPR x 64 dwords) filled once:
     // recomputing them per instruction (div / float nearest / bounds, ~50 VALU) cost 6 % of a 3x3 conv and 17 % of
     // the 64-channel layers (profiles/r02_dma_ablation.txt, HCONTIG vs HCONTIGC).
-    if (!BL) {  // (the 1x1 fast path stages its first tiles through the generic path, too)
+    if (!BL && !FL) {  // (the 1x1 fast path stages its first tiles through the generic path, too)
         for (int e = tid; e < 2 * IPR * 64; e += C::THREADS) {
             const int s = e >= IPR * 64, r = e - s * IPR * 64, ln = r & 63;
             const int hx = (r >> 6) * 16 + (ln >> 2);
@@ -823,6 +875,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN)))) void conv_igem
 #endif
 #undef HALO_DMA
 #undef HALO_DMA_RANGE
+#undef HALO_DMA_RANGE_ROWS
 #undef CPN_HALO_AT_TRANSITION
 #undef CPN_BL_FLUSH
 #undef PW_HALO_DMA
@@ -1097,8 +1150,27 @@ static bool narrow_ok(const ConvArgs &a) {
            a.up0 != 2 && a.res_up == 0 && a.phase != 2 && a.phase != 3 && a.region == 0 && a.KW <= 17;
 }
 
+// MODE_S1F: single-source stride-1 k x k convs (2 <= k <= 5) with NHWC output and >= 128 output channels per bundle whose
+// 8 x 32 x 128 tiles fill the chip twice over (two resident workgroups per CU); CPN_S1F=0 / 2 (read per call): never / wherever
+// the kernel applies -- kernel A/B and tests
+static bool flat_ok(const ConvArgs &a) {
+    if (CPN_FP8) return false;
+    const char *e = getenv("CPN_S1F");
+    const int mode = e ? atoi(e) : CPN_S1F_DEFAULT;
+    if (mode == 0) return false;
+    const bool shape = a.stride == 1 && a.KH >= 2 && a.KH <= 5 && a.KW >= 2 && a.KW <= 5 && !a.src1 && !a.up0 && !a.up1 &&
+                       a.region == 0 && !a.narrow && a.out_mode == OUT_BF16_NHWC && a.cout_b % 128 == 0 && a.Hout >= 8;
+    if (!shape) return false;
+    // two workgroups per CU is the point of the mode: halo ring + weight slabs of one must fit half the LDS (k <= 3 at 8 rows)
+    const size_t halo_buf = (size_t) (((8 - 1 + a.KH) * 36 * 4 + 63) / 64) * 1024;
+    if ((a.cin_b / 32 > 1 ? 2 : 1) * halo_buf + 2 * 2 * (size_t) 128 * REC > 160 * 1024 / 2) return false;
+    const long blocks = (long) ((a.Wout + TW - 1) / TW) * ((a.Hout + 7) / 8) * a.N * (a.cout_b / 128) * a.bundles;
+    return mode == 2 || blocks >= 1024;
+}
+
 static int conv_mode(const ConvArgs &a) {
     if (a.narrow) return MODE_N;
+    if (flat_ok(a)) return MODE_S1F;
     if (a.KH == 1 && a.KW == 1 && a.pad == 0) {  // incl. strided 1x1: the tile gathers only its outputs
         const char *e = getenv("CPN_PWR");  // opt-in experiment (read per call): register-weight loop, 8x256 tile only
         return (!CPN_FP8 && e && atoi(e) != 0) ? MODE_PWR : MODE_PW;
@@ -1119,6 +1191,10 @@ static int conv_mode(const ConvArgs &a) {
 static size_t lds_bytes(const ConvArgs &a, int TH, int BN) {
     const int mode = conv_mode(a);
     const int S = mode == MODE_S2 ? 2 : 1;
+    if (mode == MODE_S1F) {  // flat pitch-36 halo tiles, no column table
+        const size_t halo_buf = (size_t) (((TH - 1 + a.KH) * 36 * 4 + 63) / 64) * 1024;
+        return (a.cin_b / 32 > 1 ? 2 : 1) * halo_buf + 2 * 2 * (size_t) BN * REC;
+    }
     const int pitch = (mode == MODE_PW || mode == MODE_PWR || mode == MODE_N) ? 32 : (mode == MODE_S2 ? 80 : 48);
     const int HH = ((mode == MODE_N ? 2 : 1) * TH - 1) * S + a.KH;
     const int nchunks = a.cin_b / 32;
@@ -1152,6 +1228,10 @@ static int launch_mode(const ConvArgs &a, hipStream_t stream) {
     const int tiles_x = (a.Wout + TW - 1) / TW, tiles_y = (a.Hout + TH - 1) / TH;
     const int ntiles = a.region == 2 ? frame_tiles(a.Hout, a.Wout, a.region_margin, TH, TW, frame_kw(a)).total : tiles_x * tiles_y;
     dim3 grid((unsigned) (ntiles * a.N), (unsigned) ((a.cout_b + BN - 1) / BN), (unsigned) a.bundles);
+    if constexpr (MODE == MODE_S1F) {  // cout blocks folded into x (see the kernel's block coordinates)
+        if (lds > LDS_MAX / 2) return (int) hipErrorInvalidValue;  // (two workgroups per CU is the point of the mode)
+        grid = dim3((unsigned) (((ntiles * a.N + 7) / 8) * 8 * ((a.cout_b + BN - 1) / BN)), 1u, (unsigned) a.bundles);
+    }
     hipLaunchKernelGGL(kern, grid, dim3(C::THREADS), lds, stream, a);
     return (int) hipGetLastError();
 }
@@ -1223,6 +1303,9 @@ int launch_conv(const ConvArgs &a_in, hipStream_t stream) {
     if (a.up0 == 2 && (CPN_FP8 || a.stride != 1 || a.src1 || a.up1 || (a.KH == 1 && a.KW == 1)))
         return (int) hipErrorInvalidValue;  // bilinear source: single-source KxK stride-1 convs of the bf16 path only
     if ((a.stride == 1 && a.KW > 17) || (a.stride == 2 && a.KW > 18)) return (int) hipErrorInvalidValue;
+#if !CPN_FP8
+    if (conv_mode(a) == MODE_S1F) return launch_mode<8, 128, 4, 2, MODE_S1F>(a, stream);
+#endif
     TileChoice c = choose_tile(a);
     if (a.out_mode == OUT_FUSED_HEAD) {  // the block must own all output channels; TH multiple of the wave count
         if (a.bundles != (a.phase == 3 ? 4 : 1) || (a.cout_b != 256 && a.cout_b != 128 && a.cout_b != 64 && a.cout_b != 32))

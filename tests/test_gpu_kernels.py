@@ -232,6 +232,36 @@ def test_conv_register_weight_loop_64_channel_tiles(dev, name, monkeypatch):
     assert (rw - ref).abs().max().item() < 5e-2 * scale
 
 
+S1F_CASES = {
+    # MODE_S1F (two 4-wave workgroups per CU, flat pitch-36 halo tile): CPN_S1F=2 forces it wherever the kernel applies
+    's1f_3x3_256': dict(n=8, h=128, w=128, cin=64, cout=256, k=3),                 # the decoder's 3x3 class
+    's1f_3x3_one_chunk': dict(n=2, h=64, w=64, cin=32, cout=128, k=3, seed=31),   # a single chunk: one halo buffer
+    's1f_3x3_partial_tiles': dict(n=3, h=44, w=72, cin=96, cout=256, k=3, seed=32),   # ragged rows / columns, 3 chunks
+    's1f_3x3_res': dict(n=2, h=64, w=96, cin=64, cout=128, k=3, res=True, seed=33),
+    's1f_5x5_falls_back': dict(n=2, h=64, w=64, cin=64, cout=128, k=5, seed=34),   # two halo tiles + slabs > 80 KiB: the plain tiles run
+    's1f_2x2ish_k3_cin2048': dict(n=1, h=32, w=64, cin=2048, cout=128, k=3, seed=39),   # 64 chunks through the two-buffer ring
+    's1f_3x3_512_two_blocks': dict(n=4, h=64, w=64, cin=128, cout=512, k=3, seed=36),   # four cout blocks folded into x
+    's1f_3x3_odd_tile_count': dict(n=3, h=24, w=40, cin=64, cout=384, k=3, seed=37),    # tiles not a multiple of 8: padded grid
+    's1f_3x3_no_bias_none': dict(n=1, h=32, w=32, cin=64, cout=128, k=3, bias=False, bn=False, act='none', seed=38),
+}
+
+
+@pytest.mark.parametrize('name', list(S1F_CASES))
+def test_conv_two_workgroups_per_cu_mode(dev, name, monkeypatch):
+    """MODE_S1F against the flagship path (CPN_S1F=0): same operands, K order and MFMA sequence per output element ->
+    bit-identical; and within the usual tolerance of the fp32 conv."""
+    cfg = S1F_CASES[name]
+    monkeypatch.setenv('CPN_S1F', '0')
+    base, ref, _ = run_conv(dev, **cfg)
+    monkeypatch.setenv('CPN_S1F', '2')
+    got, _, _ = run_conv(dev, **cfg)
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, base), f'{name}: MODE_S1F differs from the one-workgroup-per-CU tiles ' \
+                                   f'(max abs {(got - base).abs().max().item():.3e}, {(got != base).float().mean().item():.2e} of the outputs)'
+    scale = max(ref.abs().max().item(), 1.)
+    assert (got - ref).abs().max().item() < 5e-2 * scale
+
+
 SUBPIXEL_CASES = {
     'sp_64_128_64': dict(n=2, h=32, w=32, c0=64, c1=128, cout=64),
     'sp_padded_channels': dict(n=1, h=64, w=64, c0=8, c1=16, cout=16),
