@@ -10,7 +10,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CPN_HIP_LIB') or os.path.join(HERE, 'libcpn_hip.so')  # env: kernel A/B tuning only
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 PRECISION_BF16, PRECISION_F32, PRECISION_FP8 = 0, 1, 2
 E_INVALID, E_UNSUPPORTED, E_WORKSPACE = -1, -2, -3
 

@@ -462,7 +462,9 @@ class CPN(nn.Module):
         if key not in self._alt_plans:
             # fp8: the resize stays its own op (the refinement head over it carries the bilinear phase decomposition: same
             # tensors either way) and the ResNet stem takes its bf16 fast path (e4m3 output); fp32: nothing fused
-            extra = dict(fuse_bilinear=False, stem_fast=True, bilinear_phases=bool(self.subpixel)) if precision == 'fp8' else \
+            # ... and the UNet decoders carry their sub-pixel triples (partial sums as bf16; the bridge keeps its stated conv)
+            extra = dict(fuse_bilinear=False, stem_fast=True, bilinear_phases=bool(self.subpixel),
+                         subpixel='triples' if self.subpixel else False) if precision == 'fp8' else \
                 dict(fuse_readout=False, fuse_bilinear=False)
             self._alt_plans[key] = graph.build_plan(**self._plan_kwargs, **extra)
         return self._alt_plans[key]

@@ -93,6 +93,21 @@ __device__ __forceinline__ void add_res8(float (&v)[8], const store8_t r, float 
     v[4] += __builtin_amdgcn_cvt_f32_fp8((int) r.y, 0) * scale; v[5] += __builtin_amdgcn_cvt_f32_fp8((int) r.y, 1) * scale;
     v[6] += __builtin_amdgcn_cvt_f32_fp8((int) r.y, 2) * scale; v[7] += __builtin_amdgcn_cvt_f32_fp8((int) r.y, 3) * scale;
 }
+// bf16 side of an fp8 plan (partial sums of a sub-pixel triple: ConvArgs.dst_wide / res_wide)
+__device__ __forceinline__ u32x4 pack8_wide(const float (&v)[8]) {
+    u32x4 o;
+    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+    o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+    return o;
+}
+__device__ __forceinline__ void add_res8_wide(float (&v)[8], const u32x4 r) {
+    const unsigned r4[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[2 * e] += bf16_bits_to_f32(r4[e] & 0xffffu);
+        v[2 * e + 1] += __uint_as_float(r4[e] & 0xffff0000u);
+    }
+}
 #else
 typedef u32x4 store8_t;
 __device__ __forceinline__ store8_t pack8(const float (&v)[8], float) {
@@ -939,29 +954,49 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), (MODE == MODE_
         // bases are wave-uniform, lane offsets are 32-bit, ALL residual loads of the wave are issued before the first
         // staging pass, and a store costs ~25 instructions.
         constexpr int NIT = 32 / PPI;
+        // bytes per element of the destination / the residual (fp8 plans: bf16 partial sums of a sub-pixel triple are "wide")
+        const bool dwide = CPN_FP8 && a.dst_wide, rwide = CPN_FP8 && a.res_wide;
+        const int DES = dwide ? 2 : ES, RES = rwide ? 2 : ES;
         const bool full_tile = oy0 + TH <= a.Hout && ox0 + TW <= a.Wout && n0 + BN <= cout_b && a.res_up != 1;
         if (full_tile) {
-            const unsigned lane_off = (unsigned) ((((prow << ssh) + spx) * a.dst_stride + a.dst_coff + co) * ES);
-            const unsigned step = (unsigned) ((PPI << ssh) * a.dst_stride * ES);
+            const unsigned lane_off = (unsigned) ((((prow << ssh) + spx) * a.dst_stride + a.dst_coff + co) * DES);
+            const unsigned step = (unsigned) ((PPI << ssh) * a.dst_stride * DES);
             const bool has_res = a.res != nullptr;
+#if CPN_FP8
+            u32x4 rr[WM][NIT];  // (16 bytes per entry: a wide residual is bf16; e4m3 codes use .x / .y)
+#else
             store8_t rr[WM][NIT];
+#endif
             if (has_res) {
                 // res_up 2: phase tensor [Hout/2][Wout/2][4 * res_cph] read pixel-shuffled -- pixel p of the row sits in
                 // low-resolution pixel p >> 1, phase column p & 1 (ox0 and PPI are even); the row phase is wave-uniform
                 static_assert(PPI % 2 == 0, "pixel-shuffled residual: even pixel count per store instruction");
                 const bool shuf = a.res_up == 2;
-                const unsigned rlane_off = shuf ? (unsigned) (((prow >> 1) * a.res_stride + (prow & 1) * a.res_cph + co) * ES)
-                                                : (unsigned) ((prow * a.res_stride + co) * ES);
-                const unsigned rstep = (unsigned) ((shuf ? PPI / 2 : PPI) * a.res_stride * ES);
+                const unsigned rlane_off = shuf ? (unsigned) (((prow >> 1) * a.res_stride + (prow & 1) * a.res_cph + co) * RES)
+                                                : (unsigned) ((prow * a.res_stride + co) * RES);
+                const unsigned rstep = (unsigned) ((shuf ? PPI / 2 : PPI) * a.res_stride * RES);
 #pragma unroll
                 for (int f = 0; f < WM; ++f) {
                     const int oy = oy0 + wave_m * WM + f;
                     const unsigned char *rrow = (const unsigned char *) a.res +
-                        (shuf ? (((size_t) n * a.Hr + (oy >> 1)) * a.Wr + (ox0 >> 1)) * (size_t) a.res_stride * ES +
-                                    (size_t) ((oy & 1) * 2 * a.res_cph) * ES
-                              : (((size_t) n * a.Hout + oy) * a.Wout + ox0) * (size_t) a.res_stride * ES);
+                        (shuf ? (((size_t) n * a.Hr + (oy >> 1)) * a.Wr + (ox0 >> 1)) * (size_t) a.res_stride * RES +
+                                    (size_t) ((oy & 1) * 2 * a.res_cph) * RES
+                              : (((size_t) n * a.Hout + oy) * a.Wout + ox0) * (size_t) a.res_stride * RES);
+#if CPN_FP8
+                    if (rwide) {
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it) rr[f][it] = *(const u32x4 *) (rrow + rlane_off + it * rstep);
+                    } else {
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it) {
+                            const store8_t r8 = *(const store8_t *) (rrow + rlane_off + it * rstep);
+                            rr[f][it].x = r8.x; rr[f][it].y = r8.y;
+                        }
+                    }
+#else
 #pragma unroll
                     for (int it = 0; it < NIT; ++it) rr[f][it] = *(const store8_t *) (rrow + rlane_off + it * rstep);
+#endif
                 }
             }
 #pragma unroll
@@ -969,7 +1004,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), (MODE == MODE_
                 const int oy = oy0 + wave_m * WM + f;
                 unsigned char *drow = (unsigned char *) a.dst +
                                       (((size_t) n * (a.Hout << ssh) + ((oy << ssh) + spy)) * (a.Wout << ssh) + (ox0 << ssh)) *
-                                          (size_t) a.dst_stride * ES;
+                                          (size_t) a.dst_stride * DES;
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
 #pragma unroll
@@ -985,12 +1020,23 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), (MODE == MODE_
                     const float4 v0 = *(const float4 *) (stg + p * SPITCH + part * 32);
                     const float4 v1 = *(const float4 *) (stg + p * SPITCH + part * 32 + 16);
                     float v[8] = CPN_V8(v0, v1);
+#if CPN_FP8
+                    if (has_res) {
+                        if (rwide) add_res8_wide(v, rr[f][it]);
+                        else { store8_t r8; r8.x = rr[f][it].x; r8.y = rr[f][it].y; add_res8(v, r8, a.res_scale); }
+                    }
+#else
                     if (has_res) add_res8(v, rr[f][it], a.res_scale);
+#endif
                     if (a.act == ACT_RELU) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e)  // relu as one integer max (sign bit set -> 0; -0.0 -> +0.0)
                             v[e] = __int_as_float(max(__float_as_int(v[e]), 0));
                     }
+#if CPN_FP8
+                    if (dwide) *(u32x4 *) (drow + lane_off + it * step) = pack8_wide(v);
+                    else
+#endif
                     *(store8_t *) (drow + lane_off + it * step) = pack8(v, a.out_inv_scale);
                 }
             }
@@ -1025,12 +1071,20 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), (MODE == MODE_
                         rco += ((oy & 1) * 2 + (ox & 1)) * a.res_cph;
                     } else if (a.res_up)
                         rpix = ((size_t) n * a.Hr + nearest_src(oy, a.ry, a.Hr)) * a.Wr + nearest_src(ox, a.rx, a.Wr);
+#if CPN_FP8
+                    if (rwide) add_res8_wide(v, *(const u32x4 *) ((const unsigned short *) a.res + rpix * a.res_stride + rco));
+                    else
+#endif
                     add_res8(v, *(const store8_t *) ((const elem_t *) a.res + rpix * a.res_stride + rco), a.res_scale);
                 }
                 if (a.act == ACT_RELU) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
+#if CPN_FP8
+                if (dwide) *(u32x4 *) ((unsigned short *) a.dst + dpix * a.dst_stride + a.dst_coff + co) = pack8_wide(v);
+                else
+#endif
                 *(store8_t *) ((elem_t *) a.dst + dpix * a.dst_stride + a.dst_coff + co) = pack8(v, a.out_inv_scale);
             }
         }

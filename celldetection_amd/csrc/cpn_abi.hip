@@ -255,15 +255,19 @@ static const ShapePlan &get_shape_plan(cpn_plan *p, int N, int H, int W) {
     for (int t = 0; t < nt; ++t)
         if (root[t] == t && def[t] >= 0) order.push_back(t);
     std::sort(order.begin(), order.end(), [&](int a, int b) { return def[a] < def[b]; });
-    const int elem = p->precision == CPN_PRECISION_F32 ? 4 : (p->precision == CPN_PRECISION_FP8 ? 1 : 2);
+    // bytes per element: fp32 4 | bf16 2 | e4m3 1 -- except the bf16 partial-sum tensors of an fp8 plan (scale < 0)
+    auto elem_of = [&](int t) {
+        return p->precision == CPN_PRECISION_F32 ? 4 : (p->precision == CPN_PRECISION_FP8 ? (p->tensors[t].scale < 0.f ? 2 : 1) : 2);
+    };
     std::vector<int> placed;
     for (int t : order) {
+        const int elem = elem_of(t);
         const int64_t sz = tensor_bytes(p->tensors[t], N, sp.th[t], sp.tw[t], elem);
         // candidate offsets: 0 and the end of every conflicting placed tensor; take the lowest that fits
         std::vector<std::pair<int64_t, int64_t>> busy;  // [begin, end) of live-overlapping tensors
         for (int q : placed)
             if (!(last[q] < def[t] || last[t] < def[q]))
-                busy.emplace_back(sp.offsets[q], sp.offsets[q] + tensor_bytes(p->tensors[q], N, sp.th[q], sp.tw[q], elem));
+                busy.emplace_back(sp.offsets[q], sp.offsets[q] + tensor_bytes(p->tensors[q], N, sp.th[q], sp.tw[q], elem_of(q)));
         std::sort(busy.begin(), busy.end());
         int64_t off = 0;
         for (auto &b : busy) {
@@ -356,8 +360,10 @@ static int build_conv_args(const cpn_plan *p, const cpn_op_desc &o, int N, ConvA
         return fail(CPN_E_INVALID, "conv: channel counts must be positive multiples of 32 (64 input channels for fp8)");
     if (p && p->precision == CPN_PRECISION_FP8) {
         a.mult = o.mult_offset >= 0 ? p->bias + o.mult_offset : nullptr;
-        a.res_scale = o.res >= 0 ? p->tensors[o.res].scale : 0.f;
-        a.out_inv_scale = o.dst >= 0 ? 1.f / p->tensors[o.dst].scale : 0.f;
+        a.res_wide = o.res >= 0 && p->tensors[o.res].scale < 0.f;   // (bf16 partial sums of a sub-pixel triple)
+        a.dst_wide = o.dst >= 0 && p->tensors[o.dst].scale < 0.f;
+        a.res_scale = o.res >= 0 ? (a.res_wide ? 1.f : p->tensors[o.res].scale) : 0.f;
+        a.out_inv_scale = o.dst >= 0 ? (a.dst_wide ? 1.f : 1.f / p->tensors[o.dst].scale) : 0.f;
     }
     if (o.bundles > 1 && s1) return fail(CPN_E_INVALID, "conv: grouped conv with two sources");
     if (!s1 && o.c0_used < (a.phase ? 1 : o.bundles) * o.cin_b) return fail(CPN_E_INVALID, "conv: c0_used smaller than input channels");
@@ -406,10 +412,10 @@ int cpn_plan_create(cpn_plan **plan, const cpn_tensor_desc *tensors, int32_t n_t
     p->precision = precision;
     for (const auto &t : p->tensors)
         if (t.channels <= 0 || t.channels % (precision == CPN_PRECISION_FP8 ? 64 : 32) || t.down < 1 ||
-            (t.down & (t.down - 1)) || t.down > 32 || (precision == CPN_PRECISION_FP8 && !(t.scale > 0.f))) {
+            (t.down & (t.down - 1)) || t.down > 32 || (precision == CPN_PRECISION_FP8 && !(t.scale > 0.f || t.scale < 0.f))) {
             delete p;
             return fail(CPN_E_INVALID, "cpn_plan_create: tensor channels must be multiples of 32 (fp8: 64, with a "
-                                       "positive scale), down a power of two <= 32");
+                                       "positive scale, or a negative one for a bf16 partial-sum tensor), down a power of two <= 32");
         }
     for (const auto &o : p->ops) {
         for (int s : {o.src0, o.src1, o.res, o.dst})
@@ -418,6 +424,16 @@ int cpn_plan_create(cpn_plan **plan, const cpn_tensor_desc *tensors, int32_t n_t
                 return fail(CPN_E_INVALID, "cpn_plan_create: tensor id out of range");
             }
         const size_t oi_ = (size_t) (&o - p->ops.data());
+        if (precision == CPN_PRECISION_FP8) {
+            // bf16 partial-sum tensors (negative scale) exist between the PHASE and the LATERAL op of a sub-pixel triple only
+            auto wide = [&](int t) { return t >= 0 && p->tensors[t].scale < 0.f; };
+            if (wide(o.src0) || wide(o.src1) || (wide(o.dst) != (o.op == CPN_OP_CONV && o.subpixel == CPN_SUBPIXEL_PHASE && o.dst >= 0)) ||
+                (wide(o.res) && !(o.op == CPN_OP_CONV && o.subpixel == CPN_SUBPIXEL_LATERAL && o.res_up == 2))) {
+                delete p;
+                return fail(CPN_E_INVALID, "cpn_plan_create: a bf16 tensor of an fp8 plan (negative scale) is the destination of a "
+                                           "sub-pixel PHASE op and the residual of its LATERAL op, nothing else");
+            }
+        }
         if (o.subpixel == CPN_SUBPIXEL_HEAD &&
             (o.op != CPN_OP_CONV || precision == CPN_PRECISION_F32 || oi_ + 2 >= p->ops.size() || p->ops[oi_ + 1].subpixel != CPN_SUBPIXEL_PHASE ||
              p->ops[oi_ + 2].subpixel != CPN_SUBPIXEL_LATERAL || p->ops[oi_ + 1].op != CPN_OP_CONV ||

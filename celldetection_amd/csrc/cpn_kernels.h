@@ -65,6 +65,10 @@ struct ConvArgs {
     // value = acc * mult[cout] + bias (+ residual code * res_scale); NHWC outputs are stored as e4m3(value * out_inv_scale)
     const float *mult;
     float res_scale, out_inv_scale;
+    // fp8 plans, sub-pixel triples (round 5): the partial sums between the phase convs and the lateral conv travel as bf16
+    // (one e4m3 rounding of a partial sum would outweigh the accumulated e4m3 noise of its inputs): dst_wide = the NHWC
+    // destination holds bf16 VALUES (acc * mult + bias, no output scale); res_wide = the residual holds bf16 values
+    int dst_wide, res_wide;
 };
 
 // PyTorch 'nearest' source index (upsample_nearest2d, legacy 'nearest' mode, size= given)

@@ -152,8 +152,10 @@ def _two_conv_norm_relu(P, x, cout, prefix, bias=True, src1=None, up0=False, up1
     ``subpixel``: the first conv reads cat(x, nearest-upsampled src1) -- emit it as a sub-pixel triple (see
     include/cpn_hip.h, CPN_SUBPIXEL_*): the conv itself (runs at sizes where the upsampling is not an exact x2), then
     its decomposition into four 2 x 2 phase convs on the low-resolution map + the lateral conv with the pixel-shuffled
-    partial sums as residual (4/9 of the multiply-accumulates on the upsampled channels)."""
-    if subpixel and src1 is None and up0 is True:
+    partial sums as residual (4/9 of the multiply-accumulates on the upsampled channels).  ``subpixel='triples'`` (fp8
+    plans): the triples only -- the bridge level keeps the conv as stated (its scattered single-op form has no HEAD op for the
+    executor's fallback sizes and the e4m3 simulator to follow)."""
+    if subpixel is True and src1 is None and up0 is True:
         # bridge level: the conv's ONLY source is the x2-upsampled map (scale_factor=2: always exact) -> one op, the four
         # 2 x 2 phase convs + bias + ReLU scattered to their pixels (CPN_SUBPIXEL_SCATTER)
         x = P.conv(x, cout, 2, w=prefix + '0.', bn=prefix + '1.', bias=bias, act='relu', pad=1, sub=('scatter', 0))
@@ -416,8 +418,9 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
     (cpn.py:613-637), so the two convs are packed but not executed by the graph (``deferred`` ops) and evaluated at the
     proposals by ``ops.sparse_heads``; needs both heads fused, on the same plain feature, stride 1, same kernel size
     and a hidden width of 128 or 256 (``Plan.meta['sparse_heads']`` = None when the plan does not qualify).
-    ``subpixel`` (bf16 plans): the first conv of every UNet decoder level (models/unet.py:213-224) additionally carries its
-    sub-pixel decomposition; the executor picks it wherever the top-down map is upsampled by exactly 2.
+    ``subpixel`` (bf16 plans; ``'triples'`` in fp8 plans): the first conv of every UNet decoder level (models/unet.py:213-224)
+    additionally carries its sub-pixel decomposition; the executor picks it wherever the top-down map is upsampled by exactly 2.
+    In an fp8 plan the partial sums between the phase convs and the lateral conv travel as bf16.
     ``stem_fast`` (bf16 plans, ResNet-family encoders with <= 4 input channels): the 7x7 stride-2 stem additionally carries
     its dedicated kernel on a padded 4-channel input layout (``Plan.stem_fast_path``).
     ``fuse_blocks`` (bf16 plans, ResNeXt encoders): every bottleneck block additionally carries conv1 -> grouped conv2 as
@@ -610,7 +613,9 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=Non
     tens = (_lib.TensorDesc * len(plan.tensors))()
     for i, t in enumerate(plan.tensors):
         tens[i].channels, tens[i].down = _pad(t['c']) * t.get('phases', 1), t['down']
-        tens[i].scale = float(act_scales[i]) if fp8 else 0.
+        # fp8 plans: the partial-sum tensor of a sub-pixel triple ([phase][c], ``phases`` == 4) is stored as bf16 -- flagged by a
+        # negative scale (include/cpn_hip.h cpn_tensor_desc)
+        tens[i].scale = (-1. if t.get('phases', 1) == 4 else float(act_scales[i])) if fp8 else 0.
     ops = (_lib.OpDesc * len(plan.ops))()
     wparts, bparts = [], []
     woff = boff = 0
@@ -680,8 +685,8 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=Non
         k, groups, cin, cout = op['k'], op['groups'], op['cin'], op['cout']
         sub = op.get('sub')
         bl = sub == 'blhead' or (isinstance(sub, tuple) and sub[0] in ('blphase', 'blframe'))
-        if sub is not None and (f32 or (fp8 and not bl)):
-            raise ValueError('sub-pixel conv triples are a bf16-plan feature (the bilinear phases: bf16 / fp8)')
+        if sub is not None and (f32 or (fp8 and isinstance(sub, tuple) and sub[0] == 'scatter')):
+            raise ValueError('sub-pixel conv triples are a bf16 / fp8-plan feature (the scattered bridge form: bf16)')
         if isinstance(sub, tuple) and sub[0] == 'lateral':  # the lateral's share of the head conv's weights (+ its bias)
             w = w[:, :sub[1]]
         if op.get('share') is not None:  # a channel range of the stated conv; its (BN-folded) bias travels with ONE of the parts
@@ -716,6 +721,8 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=Non
             dense[:, :cout, :cin] = w
             packed = dense.reshape(4, coutp, cinp // KC, KC, kk * kk).permute(0, 2, 4, 1, 3)
             bias = None  # (partial sums; the lateral op of the triple adds the bias)
+            if fp8 and sub[0] == 'phase':  # (an all-zero bias keeps the bias / multiplier indices of the e4m3 kernel aligned)
+                bias = torch.zeros(4 * coutp, dtype=torch.float64)
             if sub[0] in ('scatter', 'blphase'):  # one bias shared by the four phases
                 bias = torch.zeros(coutp, dtype=torch.float64)
                 bias[:cout] = b
@@ -754,10 +761,11 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=Non
                 codes = torch.cat((codes, torch.zeros_like(codes[:, :1])), 1)
             wparts.append(codes.contiguous().reshape(-1))
             mparts.append((wscale[:1] if (isinstance(sub, tuple) and sub[0] == 'blphase') else wscale).reshape(-1).to(torch.float32))
-            op_scales[-1] = (float(act_scales[op['res']]) if op['res'] is not None else 0.,
-                             1. / float(act_scales[op['dst']]) if op['dst'] is not None else 0.)
-            if effective_weights is not None and phase:  # (a member op: the simulator follows the head op it restates)
-                effective_weights.append(dict(w=None, b=None))
+            wide = lambda t_: plan.tensors[t_].get('phases', 1) == 4  # bf16 partial sums: values, no code scale
+            op_scales[-1] = ((1. if wide(op['res']) else float(act_scales[op['res']])) if op['res'] is not None else 0.,
+                             (1. if wide(op['dst']) else 1. / float(act_scales[op['dst']])) if op['dst'] is not None else 0.)
+            if effective_weights is not None and (phase or (isinstance(sub, tuple) and sub[0] == 'lateral')):
+                effective_weights.append(dict(w=None, b=None))  # (a member op: the simulator follows the head op it restates)
             elif effective_weights is not None:
                 dq = codes[:, :packed.shape[1]].view(torch.float8_e4m3fn).to(torch.float64) * wscale[:, None, :, None]
                 dq = dq.reshape(bundles, cin_b // KC, k * k, cout_b, KC).permute(0, 3, 1, 4, 2)  # [B][cout][chunk][64][tap]

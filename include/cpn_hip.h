@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CPN_ABI_VERSION 10
+#define CPN_ABI_VERSION 11
 
 #define CPN_E_INVALID (-1)
 #define CPN_E_UNSUPPORTED (-2)
@@ -44,7 +44,9 @@ int cpn_abi_version(void);
 typedef struct {
     int32_t channels;  /* padded channel count (multiple of 32; 64 for CPN_PRECISION_FP8 plans)   */
     int32_t down;      /* nominal down-sampling factor (1,2,4,...,32); actual sizes are propagated per input size */
-    float scale;       /* CPN_PRECISION_FP8: value of one e4m3 code unit of this tensor; else unused */
+    float scale;       /* CPN_PRECISION_FP8: value of one e4m3 code unit of this tensor (> 0); a NEGATIVE scale marks a tensor
+                        * stored as bf16 values inside an fp8 plan -- the partial sums between the PHASE and the LATERAL op of
+                        * a sub-pixel triple (ABI 11).  Other precisions: unused */
 } cpn_tensor_desc;
 
 /* CPN_OP_CONV_DEFERRED (score-gated heads, cpn_sparse_heads below): a fused ReadOut head conv that cpn_plan_run does NOT

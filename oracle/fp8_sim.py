@@ -101,8 +101,8 @@ def _simulate(plan, state_dict, effective_weights, act_scales, x, T, outs, ei, _
         else:
             e = effective_weights[ei]
             ei += 1
-            if isinstance(op.get('sub'), tuple) and op['sub'][0] in ('blphase', 'blframe'):
-                continue  # members of a bilinear sub-pixel triple: the simulation follows the head op they restate
+            if isinstance(op.get('sub'), tuple) and op['sub'][0] in ('blphase', 'blframe', 'phase', 'lateral'):
+                continue  # members of a (bilinear) sub-pixel triple: the simulation follows the head op they restate
             if op['up0'] == 'bilinear':  # resize fused into the conv's loader: blended values are re-quantised with
                 t0 = T[op['src0']]        # the source tensor's scale (codes), exactly like the separate op did
                 xin = t0 if t0.shape[2:] == x.shape[2:] else _q(

@@ -954,6 +954,38 @@ def test_bilinear_phase_refinement_head_fp8(dev, name, monkeypatch):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('name', ['CpnU22', 'CpnU22_wide', 'CpnResNeXt101UNet', 'CpnResNet50UNet', 'CpnResNeXt101UNet_odd'])
+def test_fp8_subpixel_triples_of_the_unet_decoders(dev, name):
+    """fp8 plans carry the sub-pixel triples of the UNet decoder convs (models/unet.py:213-224) since round 5: four 2 x 2 phase
+    convs on the e4m3 top-down map write their partial sums as bf16, the 3 x 3 lateral conv adds them as a pixel-shuffled
+    residual.  Against the reference's fp32 head maps the triples must not be noisier than the conv over the virtual concat
+    (``model.subpixel = False``: same e4m3 operands, one accumulation), map by map; at sizes where the top-down map is not an
+    exact half (75 x 101) the HEAD conv runs either way -> identical maps."""
+    rel = lambda a, b: ((a - b).norm() / (b.norm() + 1e-12)).item()
+    maps = {}
+    for sub in (False, True):
+        m, g = build(name, dev)
+        x = torch.as_tensor(g['x']).to(dev)
+        m.subpixel = sub
+        m.precision = 'fp8'
+        m.calibrate_fp8(x)
+        maps[sub] = [t.cpu() for t in m.core_forward(x)]
+        prof = m.engine(dev).profile(x, m.core.order, True)
+        ran_k2 = sum(1 for p in prof if p['op'] == 'conv' and p['k'] == 2 and p['gflop'] > 0)
+        exact = all(v % 32 == 0 for v in x.shape[-2:])
+        assert ran_k2 == (4 if (sub and exact) else 0), (name, sub, ran_k2)  # four decoder levels with a lateral
+    ref = (torch.sigmoid(torch.as_tensor(g['core.scores'])), torch.as_tensor(g['core.locations']),
+           torch.as_tensor(g['core.refinement']), torch.as_tensor(g['core.fourier']))
+    for key, a, b, e in zip(('scores', 'locations', 'refinement', 'fourier'), maps[False], maps[True], ref):
+        ea, eb = rel(a, e), rel(b, e)
+        print(f'{name} fp8 {key}: relL2 vs fp32 reference: stated conv {ea:.3e}, sub-pixel triples {eb:.3e}; between the two {rel(b, a):.3e}')
+        assert torch.isfinite(b).all()
+        if all(v % 32 == 0 for v in x.shape[-2:]):
+            assert eb < 1.15 * ea + 1e-2, (key, ea, eb)
+        else:
+            assert torch.equal(a, b), key
+
+
 @pytest.mark.parametrize('size', [(64, 96), (100, 140), (48, 68), (130, 260), (24, 520)])
 def test_bilinear_phase_frame_pixels_identical_any_size(dev, size, monkeypatch):
     """Frame launches (CPN_SUBPIXEL_BL_FRAME) cut the two sides of a row into ONE wrap tile (output columns W - 16 .. W - 1 and

@@ -288,7 +288,16 @@ def test_subpixel_plans_keep_entries_and_flops_and_switch_per_size():
     plain = graph.build_plan(**m._plan_kwargs)
     assert plain.entries == m._plan.entries and all(op.get('sub') is None for op in plain.ops)
     assert graph.reference_flops(plain, 256, 256) == graph.reference_flops(m._plan, 256, 256)
-    assert all(op.get('sub') is None for p_ in ('fp8', 'fp32') for op in m.plan_for(p_).ops)
+    assert all(op.get('sub') is None for op in m.plan_for('fp32').ops)
+    # fp8 plans (round 5): the triples, never the scattered single-op form of a bridge level; same entries
+    f8 = m.plan_for('fp8')
+    assert sum(1 for op in f8.ops if op.get('sub') == 'head') == 4 and f8.entries == plain.entries
+    assert not any(isinstance(op.get('sub'), tuple) and op['sub'][0] == 'scatter' for op in f8.ops)
+    r = cda.models.CpnResNeXt101UNet(3, backbone_kwargs={'backbone_kwargs': {'base_channel': 8}})
+    assert any(isinstance(op.get('sub'), tuple) and op['sub'][0] == 'scatter' for op in r.plan_for('bf16').ops)
+    assert not any(isinstance(op.get('sub'), tuple) and op['sub'][0] == 'scatter' for op in r.plan_for('fp8').ops)
+    r.subpixel = False
+    assert all(op.get('sub') in (None,) or 'bl' in str(op.get('sub')) for op in r.plan_for('fp8').ops)
     m.subpixel = False
     assert all(op.get('sub') is None for op in m.plan_for('bf16').ops)
     m.subpixel = True
