@@ -546,7 +546,10 @@ def main():
                         'share_of_graph_time': d_ms / tot}
         if args.profile_layers:
             for p in prof:
-                if p['op'] == 'conv_pair':
+                if p['op'] == 'conv_bridge':
+                    print(f"{p['index']:3d} conv_bridge (scatter conv -> conv 3x3, one kernel) {p['ms']:8.3f} ms "
+                          f"{p['gflop'] / max(p['ms'], 1e-6):8.1f} TF/s executed  {p['name']}", file=sys.stderr)
+                elif p['op'] == 'conv_pair':
                     print(f"{p['index']:3d} conv_pair (conv1 1x1 -> grouped conv2 3x3) {p['ms']:8.3f} ms "
                           f"{p['gflop'] / max(p['ms'], 1e-6):8.1f} TF/s executed  {p['name']}", file=sys.stderr)
                 elif p['op'] == 'conv':
@@ -572,7 +575,7 @@ def main():
         ndet = sum(len(s) for s in y['scores'])
         # conv launches of one graph execution (sub-pixel triples run either their head or their two member ops: per-op
         # executed FLOPs of the profiled run tell which)
-        n_launch = sum(1 for p in prof if p['op'] in ('conv', 'conv_pair') and p['gflop'] > 0) - (2 if args.sparse_heads and eng.sparse else 0)
+        n_launch = sum(1 for p in prof if p['op'] in ('conv', 'conv_pair', 'conv_bridge') and p['gflop'] > 0) - (2 if args.sparse_heads and eng.sparse else 0)
         rccl_world = td.get_world_size() if dist else None  # None: no process group exists (one rank, RCCL never initialised)
         gated = None
         if args.sparse_heads and eng.sparse:

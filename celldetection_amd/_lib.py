@@ -14,7 +14,8 @@ ABI_VERSION = 11
 PRECISION_BF16, PRECISION_F32, PRECISION_FP8 = 0, 1, 2
 E_INVALID, E_UNSUPPORTED, E_WORKSPACE = -1, -2, -3
 
-OP_INPUT, OP_CONV, OP_MAXPOOL, OP_BILINEAR, OP_CONV_DEFERRED, OP_INPUT_STEM, OP_STEM7, OP_CONV_PAIR = 0, 1, 2, 3, 4, 5, 6, 7
+OP_INPUT, OP_CONV, OP_MAXPOOL, OP_BILINEAR, OP_CONV_DEFERRED, OP_INPUT_STEM, OP_STEM7, OP_CONV_PAIR, OP_CONV_BRIDGE = \
+    0, 1, 2, 3, 4, 5, 6, 7, 8
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH_SCALED = 0, 1, 2, 3
 SUBPIXEL_NONE, SUBPIXEL_HEAD, SUBPIXEL_PHASE, SUBPIXEL_LATERAL, SUBPIXEL_SCATTER = 0, 1, 2, 3, 4
 SUBPIXEL_BL_HEAD, SUBPIXEL_BL_PHASE, SUBPIXEL_BL_FRAME = 5, 6, 7
@@ -67,6 +68,8 @@ _SIGNATURES = [
                                  c_float, c_void_p]),
     ('cpn_conv_pair', ctypes.c_int, [POINTER(OpDesc), c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                      c_void_p, c_void_p, c_void_p]),
+    ('cpn_conv_bridge', ctypes.c_int, [POINTER(OpDesc), c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32,
+                                       c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     ('cpn_maxpool2d', ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                      c_int32, c_void_p]),
     ('cpn_resize_bilinear', ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,

@@ -146,7 +146,11 @@ __device__ __forceinline__ void add_res8(float (&v)[8], const store8_t r, float)
 // of 36 records (34 used by a 3x3 conv) instead of 48 -- a DMA instruction covers 16 consecutive records across row ends, its
 // per-lane source offsets are six loop-invariant registers per wave (no column table) -- and 128-row weight slabs: 2 x 23 + 32
 // = 78 KiB.  Single-source stride-1 k x k convs, 2 <= k <= 5, NHWC output.
-enum Mode : int { MODE_PW = 0, MODE_S1 = 1, MODE_S2 = 2, MODE_BL = 3, MODE_S1R = 4, MODE_PWR = 5, MODE_N = 6, MODE_S1F = 7 };
+// MODE_BR (round 5) = MODE_S1 on the <16,64,2,2> tile whose two halo tiles (cin = 64 = both chunks) are COMPUTED in the kernel:
+// the bridge level of the ResNet-UNets -- conv 3x3 (64 -> 64, bias-free, BN, ReLU) over the x2-upsampled 64-channel map, run as
+// four 2x2 phase convs (CPN_SUBPIXEL_SCATTER), followed by the second conv 3x3 of that TwoConvNormRelu block -- as ONE launch:
+// the 537 MB full-resolution intermediate of a 16 x 512^2 batch is neither written nor read (ConvArgs.pre_*).
+enum Mode : int { MODE_PW = 0, MODE_S1 = 1, MODE_S2 = 2, MODE_BL = 3, MODE_S1R = 4, MODE_PWR = 5, MODE_N = 6, MODE_S1F = 7, MODE_BR = 8 };
 
 template <int MODE>
 struct ModeCfg {
@@ -355,6 +359,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), (MODE == MODE_
     constexpr bool BL = MODE == MODE_BL;
     constexpr bool RW = MODE == MODE_S1R || MODE == MODE_PWR;  // weights: global -> registers (no weight tiles in LDS)
     constexpr bool FL = MODE == MODE_S1F;  // flat halo tile (pitch 36), two 4-wave workgroups per CU
+    constexpr bool BR = MODE == MODE_BR;   // halo tiles computed in the kernel by the scattered phase conv in front (bridge fusion)
     constexpr bool NR = MODE == MODE_N;  // narrow output: fragment = 2 rows x 16 px; a.Hout / a.Wout are the virtual [H/2][32]
     constexpr int RPF = NR ? 2 : 1;      // output rows per pixel fragment
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -515,11 +520,115 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), (MODE == MODE_
         }
     }
 
+    // ---- MODE_BR stage 1: the scattered phase conv (CPN_SUBPIXEL_SCATTER) on the low-resolution map, straight into the two halo
+    // buffers of the main loop.  Halo row r / column c = full-resolution pixel (Y, X) = (oy0 - 1 + r, ox0 - 1 + c) = phase (py, px)
+    // = (Y & 1, X & 1) of low-resolution pixel (Y >> 1, X >> 1); out(i, j; py, px) = sum over the 2 x 2 taps (ty, tx) of
+    // W[py, px][ty, tx] . in(i - 1 + py + ty, j - 1 + px + tx).  The 18 x 34 tile holds 9 x 17 = 153 pixels of every phase = 5 MFMA
+    // pixel fragments; wave w owns phase w >> 1 and output channels (w & 1) * 32 .. + 31 = main-loop chunk w & 1: 5 accumulators,
+    // weights from L2 straight into registers (the scatter op's packed slabs ARE the A-fragment rows), pixel operand from a 12 x 20
+    // low-resolution input tile staged by LDS-DMA.  Same K order (chunk-major, tap-minor, k-half-minor), bias, ReLU and bf16
+    // rounding as the stand-alone op -> the main loop reads the bits the intermediate tensor would have held.
+    if constexpr (BR) {
+        constexpr int PR = 12, PC = 20, PREC = PR * PC;           // input tile: rows x columns (records of 64 B), 15 DMA instr / chunk
+        static_assert(TH == 16 && BN == 64 && WM == 2 && WN == 2, "bridge stage: the <16,64,2,2> tile");
+        unsigned char *const pin = smem + ldsW_off + 2 * WBUF + 2 * IPR * 256;
+        const int pch = a.pre_cin >> 5;
+        const int ly0 = (oy0 >> 1) - 2, lx0 = (ox0 >> 1) - 2;     // low-resolution pixel of input-tile record (0, 0)
+        const rsrc_t rsp = make_rsrc(a.pre_src, (unsigned) ((size_t) a.N * a.pre_H * a.pre_W * a.pre_stride * ES));
+        for (int c = 0; c < pch; ++c) {
+            const unsigned so = (unsigned) (((size_t) n * a.pre_H * a.pre_W * a.pre_stride + c * 32) * ES);
+            for (int q = wave; q < PREC / 16; q += C::NWAVES) {
+                const int idx = (q << 6) + lane, rec = idx >> 2;
+                const int r = rec / PC, cc = rec - r * PC;
+                const int ly = ly0 + r, lx = lx0 + cc;
+                const bool valid = ly >= 0 && ly < a.pre_H && lx >= 0 && lx < a.pre_W;
+                const unsigned vo = valid ? (unsigned) (((ly * a.pre_W + lx) * a.pre_stride + ((idx & 3) ^ ((rec >> 2) & 3)) * EPP) * ES) : OOB_LANE;
+                bdma16(rsp, vo, so, pin + c * (PREC * REC) + (q << 10));
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int ph = wave >> 1, jb = wave & 1, py = ph >> 1, px = ph & 1;
+        const int l31b = lane & 31, lhib = lane >> 5;
+        f32x16 acc1[5];
+#pragma unroll
+        for (int f = 0; f < 5; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[f][r] = 0.f;
+        // output pixel o = 32 f + lane of this phase = (ri, rj) of its 9 x 17 grid = low-resolution pixel ((oy0 >> 1) - py + ri,
+        // (ox0 >> 1) - px + rj); its tap (ty, tx) reads input row i - 1 + py + ty = input-tile row ri + 1 + ty (likewise the columns)
+        int ri[5], rj[5];
+        unsigned base[5];
+#pragma unroll
+        for (int f = 0; f < 5; ++f) {
+            const int o = f * 32 + l31b;
+            ri[f] = o < 153 ? o / 17 : 0;
+            rj[f] = o < 153 ? o - ri[f] * 17 : 0;
+            base[f] = (unsigned) ((ri[f] + 1) * PC + rj[f] + 1);
+        }
+        const int nit1 = 4 * pch;  // items of a phase bundle (even)
+        const unsigned char *w1 = (const unsigned char *) a.pre_w + ((size_t) ph * nit1 * 64 + jb * 32 + l31b) * REC + (lhib << 4);
+        const unsigned lds_pin = (unsigned) (size_t) (__attribute__((address_space(3))) unsigned char *) pin;
+        for (int c = 0; c < pch; ++c) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const unsigned char *wp = w1 + (size_t) (c * 4 + t) * 64 * REC;
+                const frag_t wA0 = *(const frag_t *) wp, wA1 = *(const frag_t *) (wp + 32);
+                const int toff = (t >> 1) * PC + (t & 1);
+                frag_t pB0[5], pB1[5];
+#pragma unroll
+                for (int f = 0; f < 5; ++f) {
+                    const unsigned rec = base[f] + toff;
+                    const unsigned ad = lds_pin + (unsigned) (c * (PREC * REC)) + rec * REC + (((unsigned) lhib ^ ((rec >> 2) & 3u)) << 4);
+                    ds_read16<0>(pB0[f], ad);
+                    ds_read16<0>(pB1[f], ad ^ 32u);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pB0[0]), "+v"(pB0[1]), "+v"(pB0[2]), "+v"(pB0[3]), "+v"(pB0[4]),
+                             "+v"(pB1[0]), "+v"(pB1[1]), "+v"(pB1[2]), "+v"(pB1[3]), "+v"(pB1[4]));
+#pragma unroll
+                for (int f = 0; f < 5; ++f) acc1[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA0, pB0[f], acc1[f], 0, 0, 0);
+#pragma unroll
+                for (int f = 0; f < 5; ++f) acc1[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA1, pB1[f], acc1[f], 0, 0, 0);
+            }
+        }
+        // bias + ReLU -> bf16 -> the main loop's halo record of (row 1 - py + 2 ri, column 1 - px + 2 rj), chunk jb; pixels outside
+        // the image are the 3x3 conv's zero padding
+        float b1[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b1[q][e] = a.pre_b ? a.pre_b[jb * 32 + 8 * q + 4 * lhib + e] : 0.f;
+        typedef __attribute__((address_space(3))) u32x2 lds_u32x2_t;
+#pragma unroll
+        for (int f = 0; f < 5; ++f) {
+            const int o = f * 32 + l31b;
+            if (o >= 153) continue;
+            const int r = 1 - py + 2 * ri[f], cc = 1 - px + 2 * rj[f];
+            const int Y = oy0 - 1 + r, X = ox0 - 1 + cc;
+            const bool in_img = Y >= 0 && Y < a.Hin && X >= 0 && X < a.Win;
+            unsigned char *rec = smem + jb * halo_buf + (r * PITCH + cc) * REC + lhib * 8;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc1[f][q * 4 + e] + b1[q][e];
+                    v[e] = in_img ? __int_as_float(max(__float_as_int(v[e]), 0)) : 0.f;   // (the stand-alone epilogue's ReLU)
+                }
+                u32x2 w2;
+                w2.x = pack_bf16x2(v[0], v[1]);
+                w2.y = pack_bf16x2(v[2], v[3]);
+                *(lds_u32x2_t *) (rec + ((q ^ ((cc >> 2) & 3)) << 4)) = w2;
+            }
+        }
+    }
+
 #define HALO_DMA(CHUNK) HALO_DMA_RANGE(CHUNK, 0, hinstr)
 
     // instructions [Q0, Q1) of the halo tile of chunk CHUNK
 #define HALO_DMA_RANGE(CHUNK, Q0, Q1)                                                                          \
-    if constexpr (FL) {                                                                                        \
+    if constexpr (BR) {  /* both chunks' halo tiles are computed before the main loop (bridge stage below) */  \
+    } else if constexpr (FL) {                                                                                        \
         const int c_ = (CHUNK);                                                                                \
         const unsigned s_ = f_soff + (unsigned) (c_ * CH * ES);                                                \
         unsigned char *dstb_ = smem + (c_ & nhb_mask) * halo_buf;                                              \
@@ -686,7 +795,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), (MODE == MODE_
     // instruction.  The column parts of both sources live in a small LDS table (2 x IPR x 64 dwords) filled once:
     // recomputing them per instruction (div / float nearest / bounds, ~50 VALU) cost 6 % of a 3x3 conv and 17 % of
     // the 64-channel layers (profiles/r02_dma_ablation.txt, HCONTIG vs HCONTIGC).
-    if (!BL && !FL) {  // (the 1x1 fast path stages its first tiles through the generic path, too)
+    if (!BL && !FL && !BR) {  // (the 1x1 fast path stages its first tiles through the generic path, too)
         for (int e = tid; e < 2 * IPR * 64; e += C::THREADS) {
             const int s = e >= IPR * 64, r = e - s * IPR * 64, ln = r & 63;
             const int hx = (r >> 6) * 16 + (ln >> 2);
@@ -1204,6 +1313,20 @@ static bool narrow_ok(const ConvArgs &a) {
            a.up0 != 2 && a.res_up == 0 && a.phase != 2 && a.phase != 3 && a.region == 0 && a.KW <= 17;
 }
 
+}  // namespace CPN_NS
+#if !CPN_FP8
+namespace cpn {
+// the bridge kernel's shape: 3x3 stride-1 pad-1 conv 64 -> 64 (one bundle, NHWC output, no resize / second source / residual
+// resize) over the x2 map of a 32 | 64-channel low-resolution source
+bool conv_bridge_supported(const ConvArgs &a) {
+    return a.pre_src && a.pre_w && (a.pre_cin == 32 || a.pre_cin == 64) && a.pre_stride >= a.pre_cin && a.KH == 3 && a.KW == 3 &&
+           a.stride == 1 && a.pad == 1 && a.bundles == 1 && a.cin_b == 64 && a.cout_b == 64 && !a.src1 && !a.up0 && !a.up1 &&
+           a.res_up != 1 && a.phase == 0 && a.region == 0 && a.out_mode == OUT_BF16_NHWC && a.Hin == 2 * a.pre_H &&
+           a.Win == 2 * a.pre_W && a.Hout == a.Hin && a.Wout == a.Win && a.Hout >= 16 && a.Wout >= 32;
+}
+}  // namespace cpn
+#endif
+namespace CPN_NS {
 // MODE_S1F: single-source stride-1 k x k convs (2 <= k <= 5) with NHWC output and >= 128 output channels per bundle whose
 // 8 x 32 x 128 tiles fill the chip twice over (two resident workgroups per CU); CPN_S1F=0 / 2 (read per call): never / wherever
 // the kernel applies -- kernel A/B and tests
@@ -1223,6 +1346,7 @@ static bool flat_ok(const ConvArgs &a) {
 }
 
 static int conv_mode(const ConvArgs &a) {
+    if (a.pre_src) return MODE_BR;
     if (a.narrow) return MODE_N;
     if (flat_ok(a)) return MODE_S1F;
     if (a.KH == 1 && a.KW == 1 && a.pad == 0) {  // incl. strided 1x1: the tile gathers only its outputs
@@ -1245,6 +1369,8 @@ static int conv_mode(const ConvArgs &a) {
 static size_t lds_bytes(const ConvArgs &a, int TH, int BN) {
     const int mode = conv_mode(a);
     const int S = mode == MODE_S2 ? 2 : 1;
+    if (mode == MODE_BR)  // the <16,64,2,2> tile of a 3x3 conv + the 12 x 20 low-resolution input tile of the bridge stage (two chunks)
+        return 2 * (size_t) (((TH - 1 + 3) * 48 * 4 + 63) / 64) * 1024 + 2 * 2 * (size_t) BN * REC + 2 * 3 * 256 + 2 * 15 * 1024;
     if (mode == MODE_S1F) {  // flat pitch-36 halo tiles, no column table
         const size_t halo_buf = (size_t) (((TH - 1 + a.KH) * 36 * 4 + 63) / 64) * 1024;
         return (a.cin_b / 32 > 1 ? 2 : 1) * halo_buf + 2 * 2 * (size_t) BN * REC;
@@ -1358,7 +1484,13 @@ int launch_conv(const ConvArgs &a_in, hipStream_t stream) {
         return (int) hipErrorInvalidValue;  // bilinear source: single-source KxK stride-1 convs of the bf16 path only
     if ((a.stride == 1 && a.KW > 17) || (a.stride == 2 && a.KW > 18)) return (int) hipErrorInvalidValue;
 #if !CPN_FP8
+    if (a.pre_src) {  // bridge fusion (see ConvArgs.pre_*): checked by conv_bridge_supported
+        if (!conv_bridge_supported(a)) return (int) hipErrorInvalidValue;
+        return launch_mode<16, 64, 2, 2, MODE_BR>(a, stream);
+    }
     if (conv_mode(a) == MODE_S1F) return launch_mode<8, 128, 4, 2, MODE_S1F>(a, stream);
+#else
+    if (a.pre_src) return (int) hipErrorInvalidValue;
 #endif
     TileChoice c = choose_tile(a);
     if (a.out_mode == OUT_FUSED_HEAD) {  // the block must own all output channels; TH multiple of the wave count

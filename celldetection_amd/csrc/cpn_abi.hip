@@ -86,7 +86,32 @@ static PairArgs pair_args(const cpn_plan *p, const cpn_op_desc &o, int N, int H,
     return a;
 }
 
-static void propagate_dims(const cpn_plan *p, int N, int H, int W, ShapePlan &sp, int blphase_mode, int pair_mode) {
+// ConvArgs of a CPN_OP_CONV_BRIDGE op `o` (behind the scatter conv c1 and the 3x3 conv c2 it restates); pointers filled by the caller
+static int build_conv_args(const cpn_plan *p, const cpn_op_desc &o, int N, ConvArgs &a, const void *s0, int c0s, const void *s1,
+                           int c1s, const void *res, int rs, void *dst, int ds, int Hin, int Win, const int *src_dims);
+static int bridge_args(const cpn_plan *p, const cpn_op_desc &o, const cpn_op_desc &c2, int N, int Hp, int Wp, ConvArgs &a,
+                       const void *src, int c_stride, const void *res, int rs, void *dst, int ds, const void *weights,
+                       const float *bias) {
+    static const char dummy = 0;
+    const int sdims[6] = {2 * Hp, 2 * Wp, 0, 0, 2 * Hp, 2 * Wp};
+    int rc = build_conv_args(p, c2, N, a, &dummy, c2.cin_b, nullptr, 0, res, rs, dst, ds, 2 * Hp, 2 * Wp, sdims);
+    if (rc) return rc;
+    a.src0 = src;  // (unused by the kernel: its halo tiles are computed from pre_src)
+    a.pre_src = src; a.pre_stride = c_stride; a.pre_cin = o.cin_b; a.pre_H = Hp; a.pre_W = Wp;
+    a.pre_w = (const unsigned char *) weights + o.weight_offset;
+    a.pre_b = (bias && o.bias_offset >= 0) ? bias + o.bias_offset : nullptr;
+    a.weights = (const unsigned char *) weights + o.fuse_weight_offset;
+    a.bias = (bias && o.fuse_bias_offset >= 0) ? bias + o.fuse_bias_offset : nullptr;
+    return 0;
+}
+// FLOPs the bridge kernel's MFMA loops execute: the 3x3 conv + the scatter conv on every tile's 18 x 34 halo (20 fragments)
+static double bridge_executed_flops(const ConvArgs &a) {
+    const double tiles = (double) a.N * ((a.Hout + 15) / 16) * ((a.Wout + 31) / 32);
+    return conv_executed_flops(a) + tiles * 20. * 32. * 64. * a.pre_cin * 4. * 2.;
+}
+
+static void propagate_dims(const cpn_plan *p, int N, int H, int W, ShapePlan &sp, int blphase_mode, int pair_mode_) {
+    const int pair_mode = pair_mode_ & 7, bridge_mode = (pair_mode_ >> 3) & 1;
     const int nt = (int) p->tensors.size();
     sp.th.assign(nt, 0);
     sp.tw.assign(nt, 0);
@@ -157,6 +182,16 @@ static void propagate_dims(const cpn_plan *p, int N, int H, int W, ShapePlan &sp
             sp.skip[oi] = (o.alt == 2) != fast;
         }
         switch (o.op) {
+            case CPN_OP_CONV_BRIDGE: {
+                // runs instead of the scatter conv + 3x3 conv in front of it wherever the kernel's 16 x 32 tiles fit the output
+                // (CPN_BRIDGE=0: never -- kernel A/B and tests)
+                const int Hp = sp.th[o.src0], Wp = sp.tw[o.src0];
+                const bool fused = bridge_mode != 0 && p->precision == CPN_PRECISION_BF16 && 2 * Hp >= 16 && 2 * Wp >= 32 &&
+                                   sp.th[o.dst] == 2 * Hp && sp.tw[o.dst] == 2 * Wp;
+                sp.skip[oi] = !fused;
+                sp.skip[oi - 1] = sp.skip[oi - 2] = fused;
+                break;
+            }
             case CPN_OP_CONV_PAIR: {
                 // runs instead of the two convs in front of it wherever the kernel's full-width strips fit the feature map
                 // and its strips x slabs fill the chip (CPN_PAIR=0 / 2: never / wherever supported -- kernel A/B and tests)
@@ -225,8 +260,8 @@ static const ShapePlan &get_shape_plan(cpn_plan *p, int N, int H, int W) {
     std::lock_guard<std::mutex> lock(p->shape_mutex);
     // the executor's A/B switches are part of the key: toggling CPN_BLPHASE / CPN_PAIR on a live plan re-plans the shape
     // (the Python engine's hipGraph key carries them as well)
-    const char *eb = getenv("CPN_BLPHASE"), *ep = getenv("CPN_PAIR");
-    const int blphase_mode = eb ? atoi(eb) : 1, pair_mode = ep ? atoi(ep) : 1;
+    const char *eb = getenv("CPN_BLPHASE"), *ep = getenv("CPN_PAIR"), *er = getenv("CPN_BRIDGE");
+    const int blphase_mode = eb ? atoi(eb) : 1, pair_mode = (ep ? atoi(ep) : 1) + 8 * (er ? (atoi(er) != 0) : 1);  // (bit 3: bridge fusion)
     auto key = std::make_tuple(N, H, W, blphase_mode, pair_mode);
     auto it = p->shape_plans.find(key);
     if (it != p->shape_plans.end()) return it->second;
@@ -498,6 +533,29 @@ int cpn_plan_create(cpn_plan **plan, const cpn_tensor_desc *tensors, int32_t n_t
                                            "3x3 conv + ReLU (stride 1 | 2, bundles of 32 | 64 channels) it restates and share their offsets");
             }
         }
+        if (o.op == CPN_OP_CONV_BRIDGE) {
+            const cpn_op_desc *c1 = oi_ >= 2 ? &p->ops[oi_ - 2] : nullptr, *c2 = oi_ >= 2 ? &p->ops[oi_ - 1] : nullptr;
+            bool ok = precision == CPN_PRECISION_BF16 && c1 && c1->op == CPN_OP_CONV && c2->op == CPN_OP_CONV &&
+                      c1->subpixel == CPN_SUBPIXEL_SCATTER && c1->dst >= 0 && c1->act == CPN_ACT_RELU && c1->cout_b == 64 &&
+                      (c1->cin_b == 32 || c1->cin_b == 64) && c1->bundles == 4 && c1->bias_offset >= 0 &&
+                      c2->src0 == c1->dst && c2->src1 < 0 && !c2->up0 && c2->kh == 3 && c2->kw == 3 && c2->stride == 1 &&
+                      c2->pad == 1 && c2->bundles == 1 && c2->cin_b == 64 && c2->cout_b == 64 && c2->subpixel == 0 && !c2->alt &&
+                      c2->dst >= 0 && c2->res_up != 1 && c2->fuse_cout == 0 && o.src0 == c1->src0 && o.dst == c2->dst &&
+                      o.res == c2->res && o.res_up == c2->res_up && o.act == c2->act && o.cin_b == c1->cin_b && o.cout_b == 64 &&
+                      o.kh == 3 && o.kw == 3 && o.weight_offset == c1->weight_offset && o.bias_offset == c1->bias_offset &&
+                      o.fuse_weight_offset == c2->weight_offset && o.fuse_bias_offset == c2->bias_offset &&
+                      p->tensors[o.src0].channels >= o.cin_b;
+            for (size_t j = 0; ok && j < p->ops.size(); ++j) {  // nothing else may read the tensor that is no longer stored
+                const cpn_op_desc &q = p->ops[j];
+                if (j != oi_ - 1 && (q.src0 == c1->dst || q.src1 == c1->dst || q.res == c1->dst)) ok = false;
+            }
+            if (!ok) {
+                delete p;
+                return fail(CPN_E_INVALID, "cpn_plan_create: a CPN_OP_CONV_BRIDGE op must follow the scatter conv (32 | 64 -> 64 "
+                                           "channels, ReLU) and the 3x3 conv (64 -> 64) it restates, share their offsets, and "
+                                           "the tensor between them must have no other reader");
+            }
+        }
         if (o.alt < 0 || o.alt > 2) {
             delete p;
             return fail(CPN_E_INVALID, "cpn_plan_create: alt must be 0, 1 or 2");
@@ -594,7 +652,9 @@ static int run_or_count(cpn_plan *plan, const void *input, int32_t in_dtype, int
     if (!flops && sp.total > workspace_bytes) return fail(CPN_E_WORKSPACE, "cpn_plan_run: workspace too small");
     const bool f32 = plan->precision == CPN_PRECISION_F32, fp8 = plan->precision == CPN_PRECISION_FP8;
     if (absmax && plan->precision != CPN_PRECISION_BF16) return fail(CPN_E_INVALID, "cpn_plan_run_stats: bf16 plans only");
-    char *ws = (char *) workspace;
+    // (FLOP-count mode runs without a workspace: a non-null dummy base keeps "tensor at offset 0" distinguishable from "no tensor"
+    //  in the argument checks -- nothing is launched in that mode)
+    char *ws = (flops && !workspace) ? (char *) 256 : (char *) workspace;
     auto tptr = [&](int t) -> void * { return t >= 0 ? (void *) (ws + sp.offsets[t]) : nullptr; };
     auto tch = [&](int t) -> int { return t >= 0 ? plan->tensors[t].channels : 0; };
     for (size_t i = 0; i < plan->ops.size(); ++i) {
@@ -654,6 +714,18 @@ static int run_or_count(cpn_plan *plan, const void *input, int32_t in_dtype, int
                 if (op_flops) op_flops[i] = fl;
                 if (flops) { *flops += fl; break; }
                 rc = check_hip((hipError_t) launch_conv_pair(a, st), "conv pair kernel");
+                break;
+            }
+            case CPN_OP_CONV_BRIDGE: {
+                ConvArgs a;
+                rc = bridge_args(plan, o, plan->ops[i - 1], N, sp.th[o.src0], sp.tw[o.src0], a, tptr(o.src0), tch(o.src0), tptr(o.res),
+                                 tch(o.res), tptr(o.dst), tch(o.dst), plan->weights, plan->bias);
+                if (rc) return rc;
+                if (!conv_bridge_supported(a)) return fail(CPN_E_INVALID, "cpn_plan_run: bridge op at an unsupported size");
+                const double fl = bridge_executed_flops(a);
+                if (op_flops) op_flops[i] = fl;
+                if (flops) { *flops += fl; break; }
+                rc = check_hip((hipError_t) launch_conv(a, st), "conv bridge kernel");
                 break;
             }
             case CPN_OP_CONV_DEFERRED: break;  // evaluated at the proposal pixels only (cpn_sparse_heads)
@@ -793,6 +865,22 @@ int cpn_conv_pair(const cpn_op_desc *op, const void *src, int32_t c_stride, void
         return fail(CPN_E_UNSUPPORTED, "cpn_conv_pair: needs W = 16 or W >= 32, conv1 output channels a multiple of 256 (128 at "
                                        "W > 32 and for a stride-2 conv2), conv2 bundles of 32 | 64 channels (32 on stride-1 generic tiles)");
     return check_hip((hipError_t) launch_conv_pair(a, (hipStream_t) stream), "cpn_conv_pair");
+}
+
+int cpn_conv_bridge(const cpn_op_desc *op, const void *src, int32_t c_stride, const void *res, int32_t res_stride, void *dst,
+                    int32_t dst_stride, int32_t N, int32_t H, int32_t W, const void *weights, const float *bias, void *stream) {
+    if (!op || !src || !dst || !weights || op->op != CPN_OP_CONV_BRIDGE || N <= 0 || H <= 0 || W <= 0)
+        return fail(CPN_E_INVALID, "cpn_conv_bridge: needs a CPN_OP_CONV_BRIDGE descriptor and non-null buffers");
+    cpn_op_desc c2 = *op;  // the 3x3 conv the op restates: one plain 64-channel source, its own weights behind fuse_*_offset
+    c2.op = CPN_OP_CONV; c2.src1 = -1; c2.up0 = c2.up1 = 0; c2.c0_used = 64; c2.cin_b = 64; c2.cout_b = 64; c2.bundles = 1;
+    c2.kh = c2.kw = 3; c2.stride = 1; c2.pad = 1; c2.subpixel = 0; c2.fuse_cout = 0; c2.dst = 0; c2.dst_coff = 0;
+    ConvArgs a;
+    int rc = bridge_args(nullptr, *op, c2, N, H, W, a, src, c_stride, res, res_stride, dst, dst_stride, weights, bias);
+    if (rc) return rc;
+    if (!conv_bridge_supported(a))
+        return fail(CPN_E_UNSUPPORTED, "cpn_conv_bridge: needs 32 | 64 input channels, 64 output channels and an output of at "
+                                       "least 16 x 32 pixels (run the two convs)");
+    return check_hip((hipError_t) launch_conv(a, (hipStream_t) stream), "cpn_conv_bridge");
 }
 
 int cpn_convert_input_stem(const void *src, int32_t in_dtype, void *dst, int32_t N, int32_t C, int32_t H, int32_t W,

@@ -69,6 +69,14 @@ struct ConvArgs {
     // (one e4m3 rounding of a partial sum would outweigh the accumulated e4m3 noise of its inputs): dst_wide = the NHWC
     // destination holds bf16 VALUES (acc * mult + bias, no output scale); res_wide = the residual holds bf16 values
     int dst_wide, res_wide;
+    // Bridge fusion (bf16, round 5; csrc/conv_igemm.hip MODE_BR): this 3x3 conv's input -- the output of a CPN_SUBPIXEL_SCATTER
+    // conv (four 2x2 phase convs + one bias + ReLU over a x2 nearest-upsampled map, models/unet.py:92-107,213-217) -- is never
+    // stored: the workgroup computes its 18 x 34 x 64-channel halo tile from the LOW-resolution map pre_src [N][pre_H][pre_W]
+    // [pre_stride] (pre_cin = 32 | 64 channels) straight into the main loop's halo buffers.  Hin x Win = 2 pre_H x 2 pre_W,
+    // cin_b = cout_b = 64.  pre_w: the scatter op's packed weights [phase][chunk][2 x 2 taps][64][32], pre_b: its 64 biases
+    const void *pre_src, *pre_w;
+    const float *pre_b;
+    int pre_stride, pre_cin, pre_H, pre_W;
 };
 
 // PyTorch 'nearest' source index (upsample_nearest2d, legacy 'nearest' mode, size= given)
@@ -105,7 +113,8 @@ __host__ __device__ inline FrameTiles frame_tiles(int H, int W, int m, int th, i
 
 // picks a tile configuration and launches; returns hipError_t as int
 int launch_conv(const ConvArgs &a, hipStream_t stream);
-int launch_conv_fp8(const ConvArgs &a, hipStream_t stream);  // e4m3 operands, v_mfma_scale_f32_32x32x64_f8f6f4
+int launch_conv_fp8(const ConvArgs &a, hipStream_t stream);
+bool conv_bridge_supported(const ConvArgs &a);  // ConvArgs.pre_*: the shape the bridge kernel (MODE_BR) runs  // e4m3 operands, v_mfma_scale_f32_32x32x64_f8f6f4
 // algorithmic FLOPs actually executed by the MFMA loop of that launch (for utilisation reports)
 double conv_executed_flops(const ConvArgs &a);
 

@@ -109,6 +109,24 @@ class Plan:
                                  w=c1['w'] + '+' + c2['w'].rsplit('.', 2)[-2] + '.'))
         return ok
 
+    def conv_bridge(self):
+        """Restates the last two conv ops -- the scattered bridge conv (``sub=('scatter', 0)``, 32 | 64 -> 64 channels, ReLU) and
+        the 3x3 conv 64 -> 64 behind it = TwoConvNormRelu of a UNet bridge level (models/unet.py:92-107, commons.py:120-149) -- as
+        ONE fused op (include/cpn_hip.h CPN_OP_CONV_BRIDGE, csrc/conv_igemm.hip MODE_BR): the full-resolution tensor between
+        them stays in LDS.  The executor runs it instead of the pair wherever the output holds a 16 x 32 tile; no state-dict
+        entries, no weights of its own.  Returns False (and adds nothing) when the pair does not qualify."""
+        c1, c2 = self.ops[-2], self.ops[-1]
+        p32 = lambda c: (c + 31) // 32 * 32
+        ok = (c1['op'] == c2['op'] == 'conv' and isinstance(c1.get('sub'), tuple) and c1['sub'][0] == 'scatter' and
+              c1['act'] == 'relu' and p32(c1['cout']) == 64 and p32(c1['cin']) in (32, 64) and c1['dst'] is not None and
+              c2['src0'] == c1['dst'] and c2['src1'] is None and not c2['up0'] and c2['k'] == 3 and c2['stride'] == 1 and
+              c2['pad'] == 1 and c2['groups'] == 1 and p32(c2['cout']) == 64 and c2.get('sub') is None and c2['dst'] is not None and
+              c2['fuse'] is None and c2['res_up'] in (False, 0, 'shuffle'))
+        if ok:
+            self.ops.append(dict(op='conv_bridge', src0=c1['src0'], dst=c2['dst'], res=c2['res'], first=len(self.ops) - 2,
+                                 w=c1['w'] + '+' + c2['w'].rsplit('.', 2)[-2] + '.'))
+        return ok
+
     def maxpool(self, src, k, stride, pad):
         t = self.tensors[src]
         dst = self.tensor(t['c'], t['down'] * stride)
@@ -159,7 +177,9 @@ def _two_conv_norm_relu(P, x, cout, prefix, bias=True, src1=None, up0=False, up1
         # bridge level: the conv's ONLY source is the x2-upsampled map (scale_factor=2: always exact) -> one op, the four
         # 2 x 2 phase convs + bias + ReLU scattered to their pixels (CPN_SUBPIXEL_SCATTER)
         x = P.conv(x, cout, 2, w=prefix + '0.', bn=prefix + '1.', bias=bias, act='relu', pad=1, sub=('scatter', 0))
-        return P.conv(x, cout, 3, w=prefix + '3.', bn=prefix + '4.', bias=bias, act='relu')
+        x = P.conv(x, cout, 3, w=prefix + '3.', bn=prefix + '4.', bias=bias, act='relu')
+        P.conv_bridge()  # both convs as one kernel where the output holds a 16 x 32 tile (64-channel bridges: the ResNet-UNets)
+        return x
     lat = x
     sub = bool(subpixel) and src1 is not None and up1 and not up0
     x = P.conv(lat, cout, 3, w=prefix + '0.', bn=prefix + '1.', bias=bias, act='relu', src1=src1, up0=up0, up1=up1,
@@ -669,6 +689,18 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=Non
             d.weight_offset, d.bias_offset = c1.weight_offset, c1.bias_offset
             d.fuse_weight_offset, d.fuse_bias_offset, d.fuse_cout = c2.weight_offset, c2.bias_offset, c2.cout_b
             d.act, d.fuse_act, d.out_index, d.cout_real = _lib.ACT_RELU, _lib.ACT_RELU, -1, c2.cout_real
+            continue
+        if op['op'] == 'conv_bridge':  # shares the packed weights / biases of the scatter conv and the 3x3 conv in front of it
+            if f32 or fp8:
+                raise ValueError('the fused bridge level is a bf16-plan feature')
+            c1, c2 = ops[op['first']], ops[op['first'] + 1]
+            assert op['first'] == i - 2 and c1.cout_b == c2.cin_b == c2.cout_b == 64
+            d.op, d.src0, d.dst, d.res = _lib.OP_CONV_BRIDGE, op['src0'], op['dst'], c2.res
+            d.kh = d.kw = 3
+            d.stride, d.pad, d.bundles, d.cin_b, d.cout_b, d.c0_used = 1, 1, 1, c1.cin_b, 64, c1.cin_b
+            d.res_up, d.act, d.act_scale, d.out_index, d.cout_real = c2.res_up, c2.act, c2.act_scale, -1, c2.cout_real
+            d.weight_offset, d.bias_offset = c1.weight_offset, c1.bias_offset
+            d.fuse_weight_offset, d.fuse_bias_offset, d.fuse_cout = c2.weight_offset, c2.bias_offset, 0
             continue
         if op['op'] == 'maxpool':
             d.op, d.src0, d.dst = _lib.OP_MAXPOOL, op['src0'], op['dst']

@@ -72,8 +72,18 @@ typedef struct {
  * slabs give >= 192 workgroups; the two convs run otherwise.  Same operands and per-conv
  * rounding (bf16 activations between the two convs) as the unfused pair; conv1 is recomputed on one halo row above and
  * below each 8-row strip. */
+/* CPN_OP_CONV_BRIDGE (bf16 plans, ABI 11; csrc/conv_igemm.hip MODE_BR): the bridge level of the ResNet-UNets -- TwoConvNormRelu
+ * (bias-free convs, celldetection/models/unet.py:92-107; commons.py:120-149) over the x2 nearest-upsampled 64-channel map
+ * (unet.py:213-217, `scale_factor=2`) -- as ONE kernel: the first conv runs as its CPN_SUBPIXEL_SCATTER form (four 2x2 phase convs
+ * + bias + ReLU) on the halo tile of the second conv's workgroup and lands in LDS, the full-resolution tensor between the two
+ * convs is neither written nor read.  The op stands directly BEHIND the two CPN_OP_CONV ops it restates (the SCATTER conv at
+ * index i - 2, the 3x3 conv at i - 1) and adds no weights: src0 = the scatter conv's source (32 | 64 channels), dst / res /
+ * res_up / act = the 3x3 conv's, cin_b = the scatter conv's input channels, cout_b = 64, weight_offset / bias_offset = the
+ * scatter conv's, fuse_weight_offset / fuse_bias_offset = the 3x3 conv's.  The executor runs it INSTEAD of the two convs
+ * wherever the output is at least 16 x 32 pixels and nothing else reads the tensor in between (CPN_BRIDGE=0 in the
+ * environment: never); same operands, K order and rounding points as the two launches. */
 enum { CPN_OP_INPUT = 0, CPN_OP_CONV = 1, CPN_OP_MAXPOOL = 2, CPN_OP_BILINEAR = 3, CPN_OP_CONV_DEFERRED = 4,
-       CPN_OP_INPUT_STEM = 5, CPN_OP_STEM7 = 6, CPN_OP_CONV_PAIR = 7 };
+       CPN_OP_INPUT_STEM = 5, CPN_OP_STEM7 = 6, CPN_OP_CONV_PAIR = 7, CPN_OP_CONV_BRIDGE = 8 };
 enum { CPN_ACT_NONE = 0, CPN_ACT_RELU = 1, CPN_ACT_SIGMOID = 2, CPN_ACT_TANH_SCALED = 3 };
 /* Sub-pixel decomposition of a k = 3 conv over cat(lateral, nearest-x2-upsampled top-down map) -- the first conv of every
  * GeneralizedUNet decoder level (celldetection/models/unet.py:213-224).  Output pixel (2i+py, 2j+px) sees the upsampled
@@ -238,6 +248,11 @@ int cpn_stem7(const cpn_op_desc *op, const void *src, void *dst, int32_t dst_str
  * CPN_E_UNSUPPORTED when W < 16 or between 17 and 31, or cout_b is no multiple of the slab width (run the two convs). */
 int cpn_conv_pair(const cpn_op_desc *op, const void *src, int32_t c_stride, void *dst, int32_t dst_stride, int32_t N,
                   int32_t H, int32_t W, const void *weights, const float *bias, void *stream);
+/* Fused bridge level (see CPN_OP_CONV_BRIDGE; `op`: such a descriptor, `weights` / `bias`: the blobs its four offsets point
+ * into): src = [N, H, W, c_stride] bf16 low-resolution map, dst = [N, 2H, 2W, dst_stride] bf16; res (optional) = a residual of
+ * the 3x3 conv at the output's size.  CPN_E_UNSUPPORTED when the kernel's shape does not apply (output below 16 x 32 pixels). */
+int cpn_conv_bridge(const cpn_op_desc *op, const void *src, int32_t c_stride, const void *res, int32_t res_stride, void *dst,
+                    int32_t dst_stride, int32_t N, int32_t H, int32_t W, const void *weights, const float *bias, void *stream);
 int cpn_maxpool2d(const void *src, void *dst, int32_t N, int32_t Hin, int32_t Win, int32_t C, int32_t k, int32_t stride,
                   int32_t pad, void *stream);
 int cpn_resize_bilinear(const void *src, void *dst, int32_t N, int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout,

@@ -21,6 +21,8 @@ def klass(p):
     n = p['name']
     if p['op'] == 'conv_pair':
         return 'enc pair (conv1+conv2)'
+    if p['op'] == 'conv_bridge':
+        return 'dec 64ch'
     if p['op'] != 'conv':
         return 'helpers'
     if 'backbone.body' in n:
