@@ -520,109 +520,6 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), (MODE == MODE_
         }
     }
 
-    // ---- MODE_BR stage 1: the scattered phase conv (CPN_SUBPIXEL_SCATTER) on the low-resolution map, straight into the two halo
-    // buffers of the main loop.  Halo row r / column c = full-resolution pixel (Y, X) = (oy0 - 1 + r, ox0 - 1 + c) = phase (py, px)
-    // = (Y & 1, X & 1) of low-resolution pixel (Y >> 1, X >> 1); out(i, j; py, px) = sum over the 2 x 2 taps (ty, tx) of
-    // W[py, px][ty, tx] . in(i - 1 + py + ty, j - 1 + px + tx).  The 18 x 34 tile holds 9 x 17 = 153 pixels of every phase = 5 MFMA
-    // pixel fragments; wave w owns phase w >> 1 and output channels (w & 1) * 32 .. + 31 = main-loop chunk w & 1: 5 accumulators,
-    // weights from L2 straight into registers (the scatter op's packed slabs ARE the A-fragment rows), pixel operand from a 12 x 20
-    // low-resolution input tile staged by LDS-DMA.  Same K order (chunk-major, tap-minor, k-half-minor), bias, ReLU and bf16
-    // rounding as the stand-alone op -> the main loop reads the bits the intermediate tensor would have held.
-    if constexpr (BR) {
-        constexpr int PR = 12, PC = 20, PREC = PR * PC;           // input tile: rows x columns (records of 64 B), 15 DMA instr / chunk
-        static_assert(TH == 16 && BN == 64 && WM == 2 && WN == 2, "bridge stage: the <16,64,2,2> tile");
-        unsigned char *const pin = smem + ldsW_off + 2 * WBUF + 2 * IPR * 256;
-        const int pch = a.pre_cin >> 5;
-        const int ly0 = (oy0 >> 1) - 2, lx0 = (ox0 >> 1) - 2;     // low-resolution pixel of input-tile record (0, 0)
-        const rsrc_t rsp = make_rsrc(a.pre_src, (unsigned) ((size_t) a.N * a.pre_H * a.pre_W * a.pre_stride * ES));
-        for (int c = 0; c < pch; ++c) {
-            const unsigned so = (unsigned) (((size_t) n * a.pre_H * a.pre_W * a.pre_stride + c * 32) * ES);
-            for (int q = wave; q < PREC / 16; q += C::NWAVES) {
-                const int idx = (q << 6) + lane, rec = idx >> 2;
-                const int r = rec / PC, cc = rec - r * PC;
-                const int ly = ly0 + r, lx = lx0 + cc;
-                const bool valid = ly >= 0 && ly < a.pre_H && lx >= 0 && lx < a.pre_W;
-                const unsigned vo = valid ? (unsigned) (((ly * a.pre_W + lx) * a.pre_stride + ((idx & 3) ^ ((rec >> 2) & 3)) * EPP) * ES) : OOB_LANE;
-                bdma16(rsp, vo, so, pin + c * (PREC * REC) + (q << 10));
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const int ph = wave >> 1, jb = wave & 1, py = ph >> 1, px = ph & 1;
-        const int l31b = lane & 31, lhib = lane >> 5;
-        f32x16 acc1[5];
-#pragma unroll
-        for (int f = 0; f < 5; ++f)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[f][r] = 0.f;
-        // output pixel o = 32 f + lane of this phase = (ri, rj) of its 9 x 17 grid = low-resolution pixel ((oy0 >> 1) - py + ri,
-        // (ox0 >> 1) - px + rj); its tap (ty, tx) reads input row i - 1 + py + ty = input-tile row ri + 1 + ty (likewise the columns)
-        int ri[5], rj[5];
-        unsigned base[5];
-#pragma unroll
-        for (int f = 0; f < 5; ++f) {
-            const int o = f * 32 + l31b;
-            ri[f] = o < 153 ? o / 17 : 0;
-            rj[f] = o < 153 ? o - ri[f] * 17 : 0;
-            base[f] = (unsigned) ((ri[f] + 1) * PC + rj[f] + 1);
-        }
-        const int nit1 = 4 * pch;  // items of a phase bundle (even)
-        const unsigned char *w1 = (const unsigned char *) a.pre_w + ((size_t) ph * nit1 * 64 + jb * 32 + l31b) * REC + (lhib << 4);
-        const unsigned lds_pin = (unsigned) (size_t) (__attribute__((address_space(3))) unsigned char *) pin;
-        for (int c = 0; c < pch; ++c) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const unsigned char *wp = w1 + (size_t) (c * 4 + t) * 64 * REC;
-                const frag_t wA0 = *(const frag_t *) wp, wA1 = *(const frag_t *) (wp + 32);
-                const int toff = (t >> 1) * PC + (t & 1);
-                frag_t pB0[5], pB1[5];
-#pragma unroll
-                for (int f = 0; f < 5; ++f) {
-                    const unsigned rec = base[f] + toff;
-                    const unsigned ad = lds_pin + (unsigned) (c * (PREC * REC)) + rec * REC + (((unsigned) lhib ^ ((rec >> 2) & 3u)) << 4);
-                    ds_read16<0>(pB0[f], ad);
-                    ds_read16<0>(pB1[f], ad ^ 32u);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pB0[0]), "+v"(pB0[1]), "+v"(pB0[2]), "+v"(pB0[3]), "+v"(pB0[4]),
-                             "+v"(pB1[0]), "+v"(pB1[1]), "+v"(pB1[2]), "+v"(pB1[3]), "+v"(pB1[4]));
-#pragma unroll
-                for (int f = 0; f < 5; ++f) acc1[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA0, pB0[f], acc1[f], 0, 0, 0);
-#pragma unroll
-                for (int f = 0; f < 5; ++f) acc1[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA1, pB1[f], acc1[f], 0, 0, 0);
-            }
-        }
-        // bias + ReLU -> bf16 -> the main loop's halo record of (row 1 - py + 2 ri, column 1 - px + 2 rj), chunk jb; pixels outside
-        // the image are the 3x3 conv's zero padding
-        float b1[4][4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) b1[q][e] = a.pre_b ? a.pre_b[jb * 32 + 8 * q + 4 * lhib + e] : 0.f;
-        typedef __attribute__((address_space(3))) u32x2 lds_u32x2_t;
-#pragma unroll
-        for (int f = 0; f < 5; ++f) {
-            const int o = f * 32 + l31b;
-            if (o >= 153) continue;
-            const int r = 1 - py + 2 * ri[f], cc = 1 - px + 2 * rj[f];
-            const int Y = oy0 - 1 + r, X = ox0 - 1 + cc;
-            const bool in_img = Y >= 0 && Y < a.Hin && X >= 0 && X < a.Win;
-            unsigned char *rec = smem + jb * halo_buf + (r * PITCH + cc) * REC + lhib * 8;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = acc1[f][q * 4 + e] + b1[q][e];
-                    v[e] = in_img ? __int_as_float(max(__float_as_int(v[e]), 0)) : 0.f;   // (the stand-alone epilogue's ReLU)
-                }
-                u32x2 w2;
-                w2.x = pack_bf16x2(v[0], v[1]);
-                w2.y = pack_bf16x2(v[2], v[3]);
-                *(lds_u32x2_t *) (rec + ((q ^ ((cc >> 2) & 3)) << 4)) = w2;
-            }
-        }
-    }
-
 #define HALO_DMA(CHUNK) HALO_DMA_RANGE(CHUNK, 0, hinstr)
 
     // instructions [Q0, Q1) of the halo tile of chunk CHUNK
@@ -810,10 +707,153 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), (MODE == MODE_
         __syncthreads();
     }
 
+    // ---- MODE_BR stage 1: the scattered phase conv (CPN_SUBPIXEL_SCATTER) on the low-resolution map, straight into the two halo
+    // buffers of the main loop.  Halo row r / column c = full-resolution pixel (Y, X) = (oy0 - 1 + r, ox0 - 1 + c) = phase (py, px)
+    // = (Y & 1, X & 1) of low-resolution pixel (Y >> 1, X >> 1); out(i, j; py, px) = sum over the 2 x 2 taps (ty, tx) of
+    // W[py, px][ty, tx] . in(i - 1 + py + ty, j - 1 + px + tx).  The 18 x 34 tile holds 9 x 17 = 153 pixels of every phase = 5 MFMA
+    // pixel fragments; wave w owns phase w >> 1 and output channels (w & 1) * 32 .. + 31 = main-loop chunk w & 1: 5 accumulators,
+    // weights from L2 straight into registers (the scatter op's packed slabs ARE the A-fragment rows), pixel operand from a 12 x 20
+    // low-resolution input tile staged by LDS-DMA.  Same K order (chunk-major, tap-minor, k-half-minor), bias, ReLU and bf16
+    // rounding as the stand-alone op -> the main loop reads the bits the intermediate tensor would have held.
+    if constexpr (BR) {
+        constexpr int PR = 12, PC = 20, PREC = PR * PC;           // input tile: rows x columns (records of 64 B), 15 DMA instr / chunk
+        static_assert(TH == 16 && BN == 64 && WM == 2 && WN == 2, "bridge stage: the <16,64,2,2> tile");
+        unsigned char *const pin = smem + ldsW_off + 2 * WBUF + 2 * IPR * 256;
+        const int pch = a.pre_cin >> 5;
+        const int ly0 = (oy0 >> 1) - 2, lx0 = (ox0 >> 1) - 2;     // low-resolution pixel of input-tile record (0, 0)
+        const rsrc_t rsp = make_rsrc(a.pre_src, (unsigned) ((size_t) a.N * a.pre_H * a.pre_W * a.pre_stride * ES));
+        for (int c = 0; c < pch; ++c) {
+            const unsigned so = (unsigned) (((size_t) n * a.pre_H * a.pre_W * a.pre_stride + c * 32) * ES);
+            for (int q = wave; q < PREC / 16; q += C::NWAVES) {
+                const int idx = (q << 6) + lane, rec = idx >> 2;
+                const int r = rec / PC, cc = rec - r * PC;
+                const int ly = ly0 + r, lx = lx0 + cc;
+                const bool valid = ly >= 0 && ly < a.pre_H && lx >= 0 && lx < a.pre_W;
+                const unsigned vo = valid ? (unsigned) (((ly * a.pre_W + lx) * a.pre_stride + ((idx & 3) ^ ((rec >> 2) & 3)) * EPP) * ES) : OOB_LANE;
+                bdma16(rsp, vo, so, pin + c * (PREC * REC) + (q << 10));
+            }
+        }
+        // this wave's stage-1 weights: phase w >> 1, output channels (w & 1) * 32 .. + 31, per (chunk, tap) item two k-halves from
+        // L2 straight into registers (the packed slab rows ARE the A-fragment rows), requested step by step (all sixteen up front
+        // measured 3.5 % slower: 214 instead of 171 registers and one L2 burst per tile); the first weight slabs of the MAIN loop
+        // are requested here, in front of the stage, instead of behind it
+        const int ph = wave >> 1, jb = wave & 1, py = ph >> 1, px = ph & 1;
+        const int l31b = lane & 31, lhib = lane >> 5;
+        frag_t wA[8][2];
+        {
+            const unsigned char *w1 = (const unsigned char *) a.pre_w + ((size_t) ph * (4 * pch) * 64 + jb * 32 + l31b) * REC + (lhib << 4);
+#ifdef CPN_BR_EARLY_W  // (tuning ablation, profiles/r05_kernel_experiments.txt #3: all 16 weight fragments requested up front -- 3.5 % slower)
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const unsigned char *wp = w1 + (size_t) (s < 4 * pch ? s : 0) * 64 * REC;
+                wA[s][0] = *(const frag_t *) wp;
+                wA[s][1] = *(const frag_t *) (wp + 32);
+            }
+#endif
+        }
+        W_DMA(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        f32x16 acc1[5];
+#pragma unroll
+        for (int f = 0; f < 5; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[f][r] = 0.f;
+        // output pixel o = 32 f + lane of this phase = (ri, rj) of its 9 x 17 grid = low-resolution pixel ((oy0 >> 1) - py + ri,
+        // (ox0 >> 1) - px + rj); its tap (ty, tx) reads input row i - 1 + py + ty = input-tile row ri + 1 + ty (likewise the columns)
+        int ri[5], rj[5];
+        unsigned base[5];
+#pragma unroll
+        for (int f = 0; f < 5; ++f) {
+            const int o = f * 32 + l31b;
+            ri[f] = o < 153 ? o / 17 : 0;
+            rj[f] = o < 153 ? o - ri[f] * 17 : 0;
+            base[f] = (unsigned) ((ri[f] + 1) * PC + rj[f] + 1);
+        }
+        const int nit1 = 4 * pch;  // items of a phase bundle (even)
+        const unsigned lds_pin = (unsigned) (size_t) (__attribute__((address_space(3))) unsigned char *) pin;
+        // fragment reads of K step s = (chunk s >> 2, tap s & 3): k-half 0 and 1 of the five pixel fragments
+#define BR_READ(S, P0, P1)                                                                                     \
+    {                                                                                                          \
+        const int toff_ = (((S) >> 1) & 1) * PC + ((S) & 1);                                                   \
+        _Pragma("unroll") for (int f = 0; f < 5; ++f) {                                                        \
+            const unsigned rec_ = base[f] + toff_;                                                             \
+            const unsigned ad_ = lds_pin + (unsigned) (((S) >> 2) * (PREC * REC)) + rec_ * REC +               \
+                                 (((unsigned) lhib ^ ((rec_ >> 2) & 3u)) << 4);                                \
+            ds_read16<0>(P0[f], ad_);                                                                          \
+            ds_read16<0>(P1[f], ad_ ^ 32u);                                                                    \
+        }                                                                                                      \
+    }
+#define BR_WAIT(N, P0, P1)                                                                                     \
+    asm volatile("s_waitcnt lgkmcnt(%10)" : "+v"(P0[0]), "+v"(P0[1]), "+v"(P0[2]), "+v"(P0[3]), "+v"(P0[4]),  \
+                 "+v"(P1[0]), "+v"(P1[1]), "+v"(P1[2]), "+v"(P1[3]), "+v"(P1[4]) : "n"(N))
+#define BR_MMA(S, P0, P1)                                                                                      \
+    {                                                                                                          \
+        _Pragma("unroll") for (int f = 0; f < 5; ++f)                                                          \
+            acc1[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA[S][0], P0[f], acc1[f], 0, 0, 0);              \
+        _Pragma("unroll") for (int f = 0; f < 5; ++f)                                                          \
+            acc1[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA[S][1], P1[f], acc1[f], 0, 0, 0);              \
+    }
+        // (one fragment set: the two waves of a SIMD belong to different phases and cover each other's read latency; a second set
+        //  pushed the kernel past 256 registers next to the 64 of prefetched weights)
+        frag_t pa0[5], pa1[5];
+#pragma unroll
+        for (int s1 = 0; s1 < 8; ++s1) {
+            if (s1 < nit1) {
+#ifndef CPN_BR_EARLY_W
+                {
+                    const unsigned char *wp = (const unsigned char *) a.pre_w + ((size_t) ph * (4 * pch) * 64 + jb * 32 + l31b) * REC +
+                                              (lhib << 4) + (size_t) s1 * 64 * REC;
+                    wA[s1][0] = *(const frag_t *) wp;
+                    wA[s1][1] = *(const frag_t *) (wp + 32);
+                }
+#endif
+#ifndef CPN_BR_NOSTAGE1  // (ablation: no stage-1 reads / MFMAs -- wrong results by construction)
+                BR_READ(s1, pa0, pa1);
+                BR_WAIT(0, pa0, pa1);
+                BR_MMA(s1, pa0, pa1);
+#endif
+            }
+        }
+#undef BR_READ
+#undef BR_WAIT
+#undef BR_MMA
+        // bias + ReLU -> bf16 -> the main loop's halo record of (row 1 - py + 2 ri, column 1 - px + 2 rj), chunk jb; pixels outside
+        // the image are the 3x3 conv's zero padding
+        float b1[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b1[q][e] = a.pre_b ? a.pre_b[jb * 32 + 8 * q + 4 * lhib + e] : 0.f;
+        typedef __attribute__((address_space(3))) u32x2 lds_u32x2_t;
+#pragma unroll
+        for (int f = 0; f < 5; ++f) {
+            const int o = f * 32 + l31b;
+            if (o >= 153) continue;
+            const int r = 1 - py + 2 * ri[f], cc = 1 - px + 2 * rj[f];
+            const int Y = oy0 - 1 + r, X = ox0 - 1 + cc;
+            const bool in_img = Y >= 0 && Y < a.Hin && X >= 0 && X < a.Win;
+            unsigned char *rec = smem + jb * halo_buf + (r * PITCH + cc) * REC + lhib * 8;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc1[f][q * 4 + e] + b1[q][e];
+                    v[e] = in_img ? __int_as_float(max(__float_as_int(v[e]), 0)) : 0.f;   // (the stand-alone epilogue's ReLU)
+                }
+                u32x2 w2;
+                w2.x = pack_bf16x2(v[0], v[1]);
+                w2.y = pack_bf16x2(v[2], v[3]);
+                *(lds_u32x2_t *) (rec + ((q ^ ((cc >> 2) & 3)) << 4)) = w2;
+            }
+        }
+    }
+
     // ---- prologue: stage step 0, open it, stage step 1, first fragment reads
     HALO_DMA(0);
     if (pw && nchunks > 1) HALO_DMA(1);
-    W_DMA(0);
+    if constexpr (!BR) W_DMA(0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (lgkmcnt: the MODE_BL halo is written with ds_write)
     __builtin_amdgcn_s_barrier();
     ISSUE_AT_TRANSITION(i0, 0, true);
