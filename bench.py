@@ -532,18 +532,32 @@ def main():
                         'algorithmic_gflop': bb_gf * prof_batch, 'batch': prof_batch,
                         'note': 'backbone conv stack (encoder + decoder incl. input/maxpool helpers) of one per-op-timed graph '
                                 'execution outside the timed region; algorithmic FLOPs of the reference graph'}
-        # the dominant kernel instantiation, conv_igemm_kernel<8,256,4,2,1>: dense k x k stride-1 convs with >= 256 output
-        # channels (8 decoder 3x3 + 3 head 7x7 convs of CpnResNeXt101UNet), from the same per-op timing
-        # (a 16-pixel-wide output runs the MODE_N instantiation <8,256,4,2,6>: not part of this kernel's statistics)
-        dom = [p for p in prof if p['op'] == 'conv' and (p['k'] or 0) > 1 and p['groups'] == 1 and p['stride'] == 1
-               and (p['cout'] or 0) >= 256 and (p['cin'] or 0) >= 64 and p['gflop'] > 0 and p['out_w'] != 16]
+        # the dominant kernel instantiation, conv_igemm_kernel<8,256,4,2,1>: dense k x k stride-1 convs with >= 256 output channels that
+        # do NOT take the two-workgroups-per-CU tiles (round 5: MODE_S1F runs the decoder's single-source 3x3 / 2x2 convs; what
+        # stays on the flagship tile are the three fused 7x7 heads of CpnResNeXt101UNet and any conv with a second / resized source),
+        # from the same per-op timing (a 16-pixel-wide output runs the MODE_N instantiation <8,256,4,2,6>: not part of the statistics)
+        pops = peng.plan.ops
+
+        def s1f(p):  # mirrors csrc/conv_igemm.hip flat_ok() for this batch
+            o = pops[p['index']]
+            return (args.precision == 'bf16' and o.get('dst') is not None and o.get('src1') is None and not o.get('up0')
+                    and p['k'] in (2, 3) and p['stride'] == 1 and p['groups'] == 1 and o.get('fuse') is None
+                    and ((p['cout'] or 0) + 31) // 32 * 32 % 128 == 0 and os.environ.get('CPN_S1F', '1') != '0')
+
+        convs = [p for p in prof if p['op'] == 'conv' and (p['k'] or 0) > 1 and p['groups'] == 1 and p['stride'] == 1
+                 and (p['cin'] or 0) >= 64 and p['gflop'] > 0 and p['out_w'] != 16]
+        dom = [p for p in convs if (p['cout'] or 0) >= 256 and not s1f(p)]
+        flat = [p for p in convs if s1f(p)]
+        pk = PEAK_BF16_TFLOPS * (2 if args.precision == 'fp8' else 1)
+
+        def kstats(ps, name):
+            ms_, gf_ = sum(p['ms'] for p in ps), sum(p['gflop'] for p in ps)
+            return {'kernel': name, 'launches_per_graph': len(ps), 'avg_launch_us': 1e3 * ms_ / len(ps), 'gflop_per_graph': gf_,
+                    'batch': prof_batch, 'achieved': gf_ / ms_, 'frac': gf_ / ms_ / pk, 'share_of_graph_time': ms_ / tot}
         if dom:
-            d_ms, d_gf = sum(p['ms'] for p in dom), sum(p['gflop'] for p in dom)
-            dominant = {'kernel': 'conv_igemm_kernel<8,256,4,2,1>' if args.precision == 'bf16' else 'cpn_fp8::conv_igemm_kernel<8,256,4,2,1>',
-                        'launches_per_graph': len(dom), 'avg_launch_us': 1e3 * d_ms / len(dom), 'gflop_per_graph': d_gf,
-                        'batch': prof_batch,
-                        'achieved': d_gf / d_ms, 'frac': d_gf / d_ms / (PEAK_BF16_TFLOPS * (2 if args.precision == 'fp8' else 1)),
-                        'share_of_graph_time': d_ms / tot}
+            dominant = kstats(dom, 'conv_igemm_kernel<8,256,4,2,1>' if args.precision == 'bf16' else 'cpn_fp8::conv_igemm_kernel<8,256,4,2,1>')
+            if flat:
+                dominant['second_kernel'] = kstats(flat, 'conv_igemm_kernel<8,128,4,2,7> (MODE_S1F: two workgroups per CU)')
         if args.profile_layers:
             for p in prof:
                 if p['op'] == 'conv_bridge':

@@ -403,9 +403,15 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), (MODE == MODE_
             // (block id mod 8 = XCD): bid = (group of 8 tiles, cout block, tile within the group) -- they read the same halo
             // tiles through one L2 (ideally as the two residents of one CU) instead of a whole grid sweep apart
             const int nh = (a.cout_b + BN - 1) / BN;
+#ifdef CPN_EXP_S1F_MAP  // tuning ablation: 1 = cout blocks on ADJACENT block ids (different XCDs), 2 = cout-block-major (a grid sweep apart)
+            const int nt8 = ((tiles_x * tiles_y * a.N + 7) / 8) * 8;
+            if (CPN_EXP_S1F_MAP == 1) { yblk = bid % nh; bid = bid / nh; }
+            else { yblk = bid / nt8; bid = bid % nt8; }
+#else
             const int j = bid & 7, r = bid >> 3;
             yblk = r % nh;
             bid = (r / nh) * 8 + j;
+#endif
             if (bid >= tiles_x * tiles_y * a.N) return;  // (grid rounded up to whole groups of 8 tiles)
         }
         tx = bid % tiles_x;
