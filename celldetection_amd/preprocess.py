@@ -4,7 +4,8 @@
 The slide stays on the device: order statistics come from a value histogram (8/16-bit images; exact, no sort of 10^9
 values) or from ``torch.kthvalue`` (float images), the clip / rescale / round-to-uint8 pass is one HBM-bound kernel.
 ``np.percentile``'s linear interpolation and ``skimage.img_as_ubyte``'s rounding (rint of value * 255 in float64) are
-restated; skimage is not part of the reference repository (third-party, unpinned).
+restated; skimage is not part of the reference repository (third-party, unpinned).  The script's optional grayscale / gamma /
+contrast steps (cv2, albumentations: third party, unpinned) are 256-entry table look-ups and one fixed-point luma pass.
 """
 import warnings
 
@@ -14,7 +15,7 @@ import torch
 from . import _lib
 from ._lib import check, ptr, stream_ptr
 
-__all__ = ['normalize_percentile', 'preprocess']
+__all__ = ['normalize_percentile', 'preprocess', 'to_grayscale']
 
 _DT = {torch.float32: 0, torch.uint8: 1, torch.uint16: 2, torch.int16: 2}
 
@@ -85,15 +86,52 @@ def normalize_percentile(image: torch.Tensor, percentile=99.9, to_uint8=True):
     return out
 
 
+def _lut(img: torch.Tensor, table) -> torch.Tensor:
+    """``cv2.LUT`` for a uint8 tensor: one gather through a 256-entry table."""
+    t = torch.as_tensor(np.asarray(table), dtype=torch.uint8, device=img.device)
+    return t[img.long()]
+
+
+def to_grayscale(img: torch.Tensor) -> torch.Tensor:
+    """``cv2.cvtColor(img, COLOR_RGB2GRAY | COLOR_RGBA2GRAY)`` for a uint8 [3 | 4, H, W] tensor -> [H, W]: OpenCV's 8-bit path
+    is fixed point, ``(R * 4899 + G * 9617 + B * 1868 + 2^13) >> 14`` (0.299 / 0.587 / 0.114 in 14 fractional bits; restated --
+    cv2 is not in the image: third-party, unpinned)."""
+    r, g, b = (img[i].to(torch.int32) for i in range(3))
+    return ((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14).to(torch.uint8)
+
+
 def preprocess(img: torch.Tensor, gamma=1., contrast=1., brightness=0., percentile=None, grayscale=False):
-    """``preprocess`` of the inference script (cpn_inference.py:196-222) for a slide on the GPU: optional percentile
-    normalisation, implicit percentile normalisation of non-uint8 inputs.  The cv2 / albumentations steps (grayscale
-    conversion, gamma, contrast) are not part of the HIP path."""
-    if grayscale or gamma != 1. or contrast != 1. or brightness != 0.:
-        raise NotImplementedError('preprocess on the HIP path: grayscale / gamma / contrast / brightness are not supported')
+    """``preprocess`` of the inference script (cpn_inference.py:196-222) for a slide on the GPU, Tensor[C, H, W] or [H, W] (the
+    layout ``tiled_inference`` takes; the script's arrays are channels-last): optional percentile normalisation, implicit
+    percentile normalisation of non-uint8 inputs, ``grayscale`` (1 / 3 / 4 channels -> luma, replicated to three channels like the
+    script's GRAY2RGB; the script's 2-channel branch hands a float64 array to cv2 and cannot run), ``gamma`` (albumentations
+    ``gamma_transform``: 256-entry table ``(i / 255) ** gamma * 255`` truncated to uint8) and ``contrast`` / ``brightness``
+    (albumentations ``brightness_contrast_adjust``: table ``clip(i * alpha + alpha * beta * mean(img), 0, 255)`` truncated to uint8 --
+    applied only when ``contrast != 1``, like the script).  cv2 / albumentations are third party and absent here: their documented
+    arithmetic is restated (unpinned; ``oracle/preprocess_oracle.py`` holds the numpy statement the GPU path is tested against)."""
     if percentile is not None:
         img = normalize_percentile(img, percentile)
     if img.element_size() > 1:
         warnings.warn('Performing implicit percentile normalization, since input is not uint8.')
         img = normalize_percentile(img)
+    if not img.is_cuda:
+        raise RuntimeError('celldetection_amd.preprocess runs on the MI355X only (got a CPU tensor).')
+    if grayscale and img.ndim == 3:
+        channels = img.shape[0]
+        if channels == 1:
+            img = img[0]
+        elif channels in (3, 4):
+            img = to_grayscale(img)
+        else:
+            raise ValueError(f'Unsupported number of channels: {channels}')
+    if img.ndim == 2:
+        img = img[None].expand(3, -1, -1).contiguous()  # cv2.COLOR_GRAY2RGB
+    if gamma != 1.:
+        img = _lut(img, (np.arange(0, 256. / 255, 1. / 255) ** gamma * 255).astype(np.uint8))
+    if contrast != 1.:
+        lut = np.arange(0, 256).astype('float32')
+        lut *= contrast
+        if brightness != 0:
+            lut += (contrast * brightness) * (int(img.sum(dtype=torch.int64).item()) / img.numel())  # np.mean: exact integer sum
+        img = _lut(img, np.clip(lut, 0, 255).astype(np.uint8))
     return img

@@ -35,3 +35,37 @@ def test_normalize_percentile_matches_numpy(dtype, pct):
     if dtype != 'uint8':  # the script's implicit normalisation of non-uint8 inputs
         with pytest.warns(UserWarning):
             np.testing.assert_array_equal(preprocess(t.cuda()).cpu().numpy(), po.normalize_percentile(x))
+
+
+def test_oracle_preprocess_steps():
+    rng = np.random.default_rng(0)
+    x = rng.integers(0, 256, (20, 30, 3)).astype(np.uint8)
+    g = po.preprocess(x, grayscale=True)
+    assert g.shape == (20, 30, 3) and (g[..., 0] == g[..., 1]).all() and (g[..., 0] == g[..., 2]).all()
+    assert abs(float(g[..., 0].mean()) - float((x * [.299, .587, .114]).sum(-1).mean())) < .6
+    white = np.full((4, 4, 3), 255, np.uint8)
+    assert (po.preprocess(white, grayscale=True) == 255).all()        # the fixed-point coefficients sum to 2^14
+    assert (po.preprocess(x, gamma=1.) == x).all() and po.preprocess(x, gamma=2.).mean() < x.mean()
+    assert (po.preprocess(x, contrast=1., brightness=.5) == x).all()  # the script ignores brightness when contrast == 1
+    assert po.preprocess(x, contrast=1.5).max() == 255
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kw', [dict(grayscale=True), dict(gamma=.7), dict(gamma=2.2, grayscale=True), dict(contrast=1.3),
+                                dict(contrast=.8, brightness=.2), dict(contrast=1., brightness=.5),
+                                dict(percentile=99., gamma=1.5, contrast=1.2, brightness=-.1, grayscale=True)])
+@pytest.mark.parametrize('channels', [1, 3, 4, 0])
+def test_preprocess_steps_match_restated_script(kw, channels):
+    """grayscale / gamma / contrast / brightness of the script's ``preprocess`` (cpn_inference.py:196-222) on the GPU against the
+    numpy statement of the same third-party arithmetic (oracle/preprocess_oracle.py); [C, H, W] here = channels-last there."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from celldetection_amd.preprocess import preprocess
+    rng = np.random.default_rng(5)
+    x = rng.integers(0, 256, (61, 83, channels) if channels else (61, 83)).astype(np.uint8)
+    t = torch.as_tensor(x).cuda()
+    got = preprocess(t.permute(2, 0, 1).contiguous() if channels else t, **kw)
+    exp = po.preprocess(x, **kw)
+    exp = exp.transpose(2, 0, 1) if exp.ndim == 3 else exp
+    assert got.dtype == torch.uint8 and tuple(got.shape) == exp.shape, (tuple(got.shape), exp.shape)
+    np.testing.assert_array_equal(got.cpu().numpy(), exp)
