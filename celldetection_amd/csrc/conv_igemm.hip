@@ -150,12 +150,12 @@ __device__ __forceinline__ void add_res8(float (&v)[8], const store8_t r, float)
 // the bridge level of the ResNet-UNets -- conv 3x3 (64 -> 64, bias-free, BN, ReLU) over the x2-upsampled 64-channel map, run as
 // four 2x2 phase convs (CPN_SUBPIXEL_SCATTER), followed by the second conv 3x3 of that TwoConvNormRelu block -- as ONE launch:
 // the 537 MB full-resolution intermediate of a 16 x 512^2 batch is neither written nor read (ConvArgs.pre_*).
-enum Mode : int { MODE_PW = 0, MODE_S1 = 1, MODE_S2 = 2, MODE_BL = 3, MODE_S1R = 4, MODE_PWR = 5, MODE_N = 6, MODE_S1F = 7, MODE_BR = 8 };
+enum Mode : int { MODE_PW = 0, MODE_S1 = 1, MODE_S2 = 2, MODE_BL = 3, MODE_S1R = 4, MODE_PWR = 5, MODE_N = 6, MODE_S1F = 7, MODE_BR = 8, MODE_BRF = 9 };
 
 template <int MODE>
 struct ModeCfg {
     static constexpr int S = MODE == MODE_S2 ? 2 : 1;                              // conv stride
-    static constexpr int PITCH = (MODE == MODE_PW || MODE == MODE_PWR || MODE == MODE_N) ? 32 : (MODE == MODE_S2 ? 80 : (MODE == MODE_S1F ? 36 : 48));  // halo row pitch (pixels)
+    static constexpr int PITCH = (MODE == MODE_PW || MODE == MODE_PWR || MODE == MODE_N) ? 32 : (MODE == MODE_S2 ? 80 : (MODE == MODE_S1F ? 36 : (MODE == MODE_BRF ? 34 : 48)));  // halo row pitch (pixels)
 };
 
 template <int TH, int BN, int WM, int WN>
@@ -351,15 +351,15 @@ __device__ __forceinline__ ItemState next_item(const ItemState I, int KH, int KW
 }
 
 template <int TH, int BN, int WM, int WN, int MODE>
-__global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), (MODE == MODE_S1F ? 2 : 1)) void conv_igemm_kernel(const ConvArgs a) {
+__global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE_S1F || MODE == MODE_BRF) ? 2 : 1)) void conv_igemm_kernel(const ConvArgs a) {
     using C = Cfg<TH, BN, WM, WN>;
     constexpr int S = ModeCfg<MODE>::S;
     constexpr int PITCH = ModeCfg<MODE>::PITCH;
     constexpr bool PW = MODE == MODE_PW || MODE == MODE_PWR;
     constexpr bool BL = MODE == MODE_BL;
     constexpr bool RW = MODE == MODE_S1R || MODE == MODE_PWR;  // weights: global -> registers (no weight tiles in LDS)
-    constexpr bool FL = MODE == MODE_S1F;  // flat halo tile (pitch 36), two 4-wave workgroups per CU
-    constexpr bool BR = MODE == MODE_BR;   // halo tiles computed in the kernel by the scattered phase conv in front (bridge fusion)
+    constexpr bool FL = MODE == MODE_S1F || MODE == MODE_BRF;  // flat halo tile (pitch 36 | 34), two 4-wave workgroups per CU
+    constexpr bool BR = MODE == MODE_BR || MODE == MODE_BRF;   // halo tiles computed in the kernel by the scattered phase conv in front (bridge fusion)
     constexpr bool NR = MODE == MODE_N;  // narrow output: fragment = 2 rows x 16 px; a.Hout / a.Wout are the virtual [H/2][32]
     constexpr int RPF = NR ? 2 : 1;      // output rows per pixel fragment
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -513,7 +513,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), (MODE == MODE_
     constexpr int FQ = FL ? (((8 - 1 + 5) * 36 * 4 + 63) / 64 + C::NWAVES - 1) / C::NWAVES : 1;
     unsigned f_voff[FQ];
     unsigned f_soff = 0;
-    if constexpr (FL) {
+    if constexpr (FL && !BR) {
         f_soff = (unsigned) (((size_t) n * a.Hs0 * a.Ws0 * a.c0_stride + cin0) * ES);
 #pragma unroll
         for (int it = 0; it < FQ; ++it) {
@@ -722,136 +722,126 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), (MODE == MODE_
     // low-resolution input tile staged by LDS-DMA.  Same K order (chunk-major, tap-minor, k-half-minor), bias, ReLU and bf16
     // rounding as the stand-alone op -> the main loop reads the bits the intermediate tensor would have held.
     if constexpr (BR) {
-        constexpr int PR = 12, PC = 20, PREC = PR * PC;           // input tile: rows x columns (records of 64 B), 15 DMA instr / chunk
-        static_assert(TH == 16 && BN == 64 && WM == 2 && WN == 2, "bridge stage: the <16,64,2,2> tile");
-        unsigned char *const pin = smem + ldsW_off + 2 * WBUF + 2 * IPR * 256;
+        // TH = 16 (MODE_BR, 8 waves): 9 rows of every phase = 5 fragments, wave w = phase w >> 1 x channel block w & 1;
+        // TH = 8 (MODE_BRF, 4 waves, two workgroups per CU): 5 rows = 3 fragments, wave w = phase w x BOTH channel blocks
+        static_assert(BN == 64 && WM == 2 && WN == 2 && (TH == 16 || TH == 8), "bridge stage: the <16,64,2,2> / <8,64,2,2> tile");
+        constexpr int NR1 = TH / 2 + 1, NPX1 = NR1 * 17, NF1 = (NPX1 + 31) / 32;   // rows, pixels, fragments of a phase
+        constexpr int NJ = TH == 16 ? 1 : 2;                                        // channel blocks per wave
+        constexpr int PR = NR1 + 2, PC = 20, PREC = PR * PC, PINSTR = (PREC + 15) / 16;   // input tile (records of 64 B)
+        constexpr int PBUF = PINSTR * 1024;
+        unsigned char *const pin = smem + ldsW_off + 2 * WBUF + (FL ? 0 : 2 * IPR * 256);
         const int pch = a.pre_cin >> 5;
         const int ly0 = (oy0 >> 1) - 2, lx0 = (ox0 >> 1) - 2;     // low-resolution pixel of input-tile record (0, 0)
         const rsrc_t rsp = make_rsrc(a.pre_src, (unsigned) ((size_t) a.N * a.pre_H * a.pre_W * a.pre_stride * ES));
         for (int c = 0; c < pch; ++c) {
             const unsigned so = (unsigned) (((size_t) n * a.pre_H * a.pre_W * a.pre_stride + c * 32) * ES);
-            for (int q = wave; q < PREC / 16; q += C::NWAVES) {
+            for (int q = wave; q < PINSTR; q += C::NWAVES) {
                 const int idx = (q << 6) + lane, rec = idx >> 2;
                 const int r = rec / PC, cc = rec - r * PC;
                 const int ly = ly0 + r, lx = lx0 + cc;
-                const bool valid = ly >= 0 && ly < a.pre_H && lx >= 0 && lx < a.pre_W;
+                const bool valid = rec < PREC && ly >= 0 && ly < a.pre_H && lx >= 0 && lx < a.pre_W;
                 const unsigned vo = valid ? (unsigned) (((ly * a.pre_W + lx) * a.pre_stride + ((idx & 3) ^ ((rec >> 2) & 3)) * EPP) * ES) : OOB_LANE;
-                bdma16(rsp, vo, so, pin + c * (PREC * REC) + (q << 10));
+                bdma16(rsp, vo, so, pin + c * PBUF + (q << 10));
             }
         }
-        // this wave's stage-1 weights: phase w >> 1, output channels (w & 1) * 32 .. + 31, per (chunk, tap) item two k-halves from
-        // L2 straight into registers (the packed slab rows ARE the A-fragment rows), requested step by step (all sixteen up front
-        // measured 3.5 % slower: 214 instead of 171 registers and one L2 burst per tile); the first weight slabs of the MAIN loop
-        // are requested here, in front of the stage, instead of behind it
-        const int ph = wave >> 1, jb = wave & 1, py = ph >> 1, px = ph & 1;
+        // this wave's stage-1 weights: its phase, its channel block(s), per (chunk, tap) item two k-halves from L2 straight into
+        // registers (the packed slab rows ARE the A-fragment rows), requested step by step (all sixteen up front measured 3.5 %
+        // slower: 214 instead of 171 registers and one L2 burst per tile); the first weight slabs of the MAIN loop are requested
+        // here, in front of the stage, instead of behind it
+        const int ph = TH == 16 ? wave >> 1 : wave, jb0 = TH == 16 ? (wave & 1) : 0, py = ph >> 1, px = ph & 1;
         const int l31b = lane & 31, lhib = lane >> 5;
-        frag_t wA[8][2];
-        {
-            const unsigned char *w1 = (const unsigned char *) a.pre_w + ((size_t) ph * (4 * pch) * 64 + jb * 32 + l31b) * REC + (lhib << 4);
-#ifdef CPN_BR_EARLY_W  // (tuning ablation, profiles/r05_kernel_experiments.txt #3: all 16 weight fragments requested up front -- 3.5 % slower)
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const unsigned char *wp = w1 + (size_t) (s < 4 * pch ? s : 0) * 64 * REC;
-                wA[s][0] = *(const frag_t *) wp;
-                wA[s][1] = *(const frag_t *) (wp + 32);
-            }
-#endif
-        }
         W_DMA(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        f32x16 acc1[5];
+        f32x16 acc1[NJ][NF1];
 #pragma unroll
-        for (int f = 0; f < 5; ++f)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[f][r] = 0.f;
-        // output pixel o = 32 f + lane of this phase = (ri, rj) of its 9 x 17 grid = low-resolution pixel ((oy0 >> 1) - py + ri,
+            for (int f = 0; f < NF1; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[j][f][r] = 0.f;
+        // output pixel o = 32 f + lane of this phase = (ri, rj) of its NR1 x 17 grid = low-resolution pixel ((oy0 >> 1) - py + ri,
         // (ox0 >> 1) - px + rj); its tap (ty, tx) reads input row i - 1 + py + ty = input-tile row ri + 1 + ty (likewise the columns)
-        int ri[5], rj[5];
-        unsigned base[5];
+        int ri[NF1], rj[NF1];
+        unsigned base[NF1];
 #pragma unroll
-        for (int f = 0; f < 5; ++f) {
+        for (int f = 0; f < NF1; ++f) {
             const int o = f * 32 + l31b;
-            ri[f] = o < 153 ? o / 17 : 0;
-            rj[f] = o < 153 ? o - ri[f] * 17 : 0;
+            ri[f] = o < NPX1 ? o / 17 : 0;
+            rj[f] = o < NPX1 ? o - ri[f] * 17 : 0;
             base[f] = (unsigned) ((ri[f] + 1) * PC + rj[f] + 1);
         }
         const int nit1 = 4 * pch;  // items of a phase bundle (even)
         const unsigned lds_pin = (unsigned) (size_t) (__attribute__((address_space(3))) unsigned char *) pin;
-        // fragment reads of K step s = (chunk s >> 2, tap s & 3): k-half 0 and 1 of the five pixel fragments
-#define BR_READ(S, P0, P1)                                                                                     \
-    {                                                                                                          \
-        const int toff_ = (((S) >> 1) & 1) * PC + ((S) & 1);                                                   \
-        _Pragma("unroll") for (int f = 0; f < 5; ++f) {                                                        \
-            const unsigned rec_ = base[f] + toff_;                                                             \
-            const unsigned ad_ = lds_pin + (unsigned) (((S) >> 2) * (PREC * REC)) + rec_ * REC +               \
-                                 (((unsigned) lhib ^ ((rec_ >> 2) & 3u)) << 4);                                \
-            ds_read16<0>(P0[f], ad_);                                                                          \
-            ds_read16<0>(P1[f], ad_ ^ 32u);                                                                    \
-        }                                                                                                      \
-    }
-#define BR_WAIT(N, P0, P1)                                                                                     \
-    asm volatile("s_waitcnt lgkmcnt(%10)" : "+v"(P0[0]), "+v"(P0[1]), "+v"(P0[2]), "+v"(P0[3]), "+v"(P0[4]),  \
-                 "+v"(P1[0]), "+v"(P1[1]), "+v"(P1[2]), "+v"(P1[3]), "+v"(P1[4]) : "n"(N))
-#define BR_MMA(S, P0, P1)                                                                                      \
-    {                                                                                                          \
-        _Pragma("unroll") for (int f = 0; f < 5; ++f)                                                          \
-            acc1[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA[S][0], P0[f], acc1[f], 0, 0, 0);              \
-        _Pragma("unroll") for (int f = 0; f < 5; ++f)                                                          \
-            acc1[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA[S][1], P1[f], acc1[f], 0, 0, 0);              \
-    }
-        // (one fragment set: the two waves of a SIMD belong to different phases and cover each other's read latency; a second set
-        //  pushed the kernel past 256 registers next to the 64 of prefetched weights)
-        frag_t pa0[5], pa1[5];
+        const unsigned char *const w1 = (const unsigned char *) a.pre_w + ((size_t) ph * nit1 * 64 + jb0 * 32 + l31b) * REC + (lhib << 4);
+        // (one fragment set: the two waves of a SIMD belong to different phases / workgroups and cover each other's read latency)
+        frag_t pa0[NF1], pa1[NF1];
 #pragma unroll
-        for (int s1 = 0; s1 < 8; ++s1) {
+        for (int s1 = 0; s1 < 8; ++s1) {   // K step s1 = (chunk s1 >> 2, tap s1 & 3): k-half 0 and 1
             if (s1 < nit1) {
-#ifndef CPN_BR_EARLY_W
-                {
-                    const unsigned char *wp = (const unsigned char *) a.pre_w + ((size_t) ph * (4 * pch) * 64 + jb * 32 + l31b) * REC +
-                                              (lhib << 4) + (size_t) s1 * 64 * REC;
-                    wA[s1][0] = *(const frag_t *) wp;
-                    wA[s1][1] = *(const frag_t *) (wp + 32);
+                frag_t wA[NJ][2];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const unsigned char *wp = w1 + ((size_t) s1 * 64 + j * 32) * REC;
+                    wA[j][0] = *(const frag_t *) wp;
+                    wA[j][1] = *(const frag_t *) (wp + 32);
                 }
-#endif
 #ifndef CPN_BR_NOSTAGE1  // (ablation: no stage-1 reads / MFMAs -- wrong results by construction)
-                BR_READ(s1, pa0, pa1);
-                BR_WAIT(0, pa0, pa1);
-                BR_MMA(s1, pa0, pa1);
+                const int toff = ((s1 >> 1) & 1) * PC + (s1 & 1);
+#pragma unroll
+                for (int f = 0; f < NF1; ++f) {
+                    const unsigned rec = base[f] + toff;
+                    const unsigned ad = lds_pin + (unsigned) ((s1 >> 2) * PBUF) + rec * REC + (((unsigned) lhib ^ ((rec >> 2) & 3u)) << 4);
+                    ds_read16<0>(pa0[f], ad);
+                    ds_read16<0>(pa1[f], ad ^ 32u);
+                }
+                if constexpr (NF1 == 5)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pa0[0]), "+v"(pa0[1]), "+v"(pa0[2]), "+v"(pa0[3]), "+v"(pa0[4]),
+                                 "+v"(pa1[0]), "+v"(pa1[1]), "+v"(pa1[2]), "+v"(pa1[3]), "+v"(pa1[4]));
+                else
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pa0[0]), "+v"(pa0[1]), "+v"(pa0[2]), "+v"(pa1[0]), "+v"(pa1[1]), "+v"(pa1[2]));
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+                    for (int f = 0; f < NF1; ++f) acc1[j][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA[j][0], pa0[f], acc1[j][f], 0, 0, 0);
+#pragma unroll
+                    for (int f = 0; f < NF1; ++f) acc1[j][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA[j][1], pa1[f], acc1[j][f], 0, 0, 0);
+                }
 #endif
             }
         }
-#undef BR_READ
-#undef BR_WAIT
-#undef BR_MMA
-        // bias + ReLU -> bf16 -> the main loop's halo record of (row 1 - py + 2 ri, column 1 - px + 2 rj), chunk jb; pixels outside
-        // the image are the 3x3 conv's zero padding
-        float b1[4][4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) b1[q][e] = a.pre_b ? a.pre_b[jb * 32 + 8 * q + 4 * lhib + e] : 0.f;
+        // bias + ReLU -> bf16 -> the main loop's halo record of (row 1 - py + 2 ri, column 1 - px + 2 rj), chunk = channel block;
+        // pixels outside the image are the 3x3 conv's zero padding
         typedef __attribute__((address_space(3))) u32x2 lds_u32x2_t;
 #pragma unroll
-        for (int f = 0; f < 5; ++f) {
-            const int o = f * 32 + l31b;
-            if (o >= 153) continue;
-            const int r = 1 - py + 2 * ri[f], cc = 1 - px + 2 * rj[f];
-            const int Y = oy0 - 1 + r, X = ox0 - 1 + cc;
-            const bool in_img = Y >= 0 && Y < a.Hin && X >= 0 && X < a.Win;
-            unsigned char *rec = smem + jb * halo_buf + (r * PITCH + cc) * REC + lhib * 8;
+        for (int j = 0; j < NJ; ++j) {
+            const int jb = jb0 + j;
+            float b1[4][4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float v[4];
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = acc1[f][q * 4 + e] + b1[q][e];
-                    v[e] = in_img ? __int_as_float(max(__float_as_int(v[e]), 0)) : 0.f;   // (the stand-alone epilogue's ReLU)
+                for (int e = 0; e < 4; ++e) b1[q][e] = a.pre_b ? a.pre_b[jb * 32 + 8 * q + 4 * lhib + e] : 0.f;
+#pragma unroll
+            for (int f = 0; f < NF1; ++f) {
+                const int o = f * 32 + l31b;
+                if (o >= NPX1) continue;
+                const int r = 1 - py + 2 * ri[f], cc = 1 - px + 2 * rj[f];
+                const int Y = oy0 - 1 + r, X = ox0 - 1 + cc;
+                const bool in_img = Y >= 0 && Y < a.Hin && X >= 0 && X < a.Win;
+                unsigned char *rec = smem + jb * halo_buf + (r * PITCH + cc) * REC + lhib * 8;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc1[j][f][q * 4 + e] + b1[q][e];
+                        v[e] = in_img ? __int_as_float(max(__float_as_int(v[e]), 0)) : 0.f;   // (the stand-alone epilogue's ReLU)
+                    }
+                    u32x2 w2;
+                    w2.x = pack_bf16x2(v[0], v[1]);
+                    w2.y = pack_bf16x2(v[2], v[3]);
+                    *(lds_u32x2_t *) (rec + ((q ^ ((cc >> 2) & 3)) << 4)) = w2;
                 }
-                u32x2 w2;
-                w2.x = pack_bf16x2(v[0], v[1]);
-                w2.y = pack_bf16x2(v[2], v[3]);
-                *(lds_u32x2_t *) (rec + ((q ^ ((cc >> 2) & 3)) << 4)) = w2;
             }
         }
     }
@@ -1415,8 +1405,12 @@ static int conv_mode(const ConvArgs &a) {
 static size_t lds_bytes(const ConvArgs &a, int TH, int BN) {
     const int mode = conv_mode(a);
     const int S = mode == MODE_S2 ? 2 : 1;
-    if (mode == MODE_BR)  // the <16,64,2,2> tile of a 3x3 conv + the 12 x 20 low-resolution input tile of the bridge stage (two chunks)
-        return 2 * (size_t) (((TH - 1 + 3) * 48 * 4 + 63) / 64) * 1024 + 2 * 2 * (size_t) BN * REC + 2 * 3 * 256 + 2 * 15 * 1024;
+    if (mode == MODE_BR) {  // two halo tiles of a 3x3 conv + slabs + the low-resolution input tile of the bridge stage (two chunks)
+        const size_t pin = 2 * (size_t) (((TH / 2 + 3) * 20 + 15) / 16) * 1024;
+        if (TH == 8)  // MODE_BRF: flat pitch-34 halo tiles, no column table: 22 + 22 + 16 + 18 = 78 KiB -> two workgroups per CU
+            return 2 * (size_t) (((TH - 1 + 3) * 34 * 4 + 63) / 64) * 1024 + 2 * 2 * (size_t) BN * REC + pin;
+        return 2 * (size_t) (((TH - 1 + 3) * 48 * 4 + 63) / 64) * 1024 + 2 * 2 * (size_t) BN * REC + 2 * 3 * 256 + pin;
+    }
     if (mode == MODE_S1F) {  // flat pitch-36 halo tiles, no column table
         const size_t halo_buf = (size_t) (((TH - 1 + a.KH) * 36 * 4 + 63) / 64) * 1024;
         return (a.cin_b / 32 > 1 ? 2 : 1) * halo_buf + 2 * 2 * (size_t) BN * REC;
@@ -1454,7 +1448,7 @@ static int launch_mode(const ConvArgs &a, hipStream_t stream) {
     const int tiles_x = (a.Wout + TW - 1) / TW, tiles_y = (a.Hout + TH - 1) / TH;
     const int ntiles = a.region == 2 ? frame_tiles(a.Hout, a.Wout, a.region_margin, TH, TW, frame_kw(a)).total : tiles_x * tiles_y;
     dim3 grid((unsigned) (ntiles * a.N), (unsigned) ((a.cout_b + BN - 1) / BN), (unsigned) a.bundles);
-    if constexpr (MODE == MODE_S1F) {  // cout blocks folded into x (see the kernel's block coordinates)
+    if constexpr (MODE == MODE_S1F || MODE == MODE_BRF) {  // cout blocks folded into x (see the kernel's block coordinates)
         if (lds > LDS_MAX / 2) return (int) hipErrorInvalidValue;  // (two workgroups per CU is the point of the mode)
         grid = dim3((unsigned) (((ntiles * a.N + 7) / 8) * 8 * ((a.cout_b + BN - 1) / BN)), 1u, (unsigned) a.bundles);
     }
@@ -1532,6 +1526,12 @@ int launch_conv(const ConvArgs &a_in, hipStream_t stream) {
 #if !CPN_FP8
     if (a.pre_src) {  // bridge fusion (see ConvArgs.pre_*): checked by conv_bridge_supported
         if (!conv_bridge_supported(a)) return (int) hipErrorInvalidValue;
+        // MODE_BRF (opt-in: CPN_BRF=1, read per call -- kernel A/B and tests): 8-row tiles on 4 waves, flat pitch-34 halo tiles,
+        // 78 KiB = two co-resident workgroups per CU.  Bit-identical, measured NEUTRAL against the <16,64,2,2> tile (580 vs 575 us,
+        // profiles/r05_kernel_experiments.txt #6): unlike the 256-channel decoder convs this kernel is not waiting on a tile's head
+        // and tail -- the default stays the one-workgroup tile
+        const char *e = getenv("CPN_BRF");
+        if (e && atoi(e) == 1) return launch_mode<8, 64, 2, 2, MODE_BRF>(a, stream);
         return launch_mode<16, 64, 2, 2, MODE_BR>(a, stream);
     }
     if (conv_mode(a) == MODE_S1F) return launch_mode<8, 128, 4, 2, MODE_S1F>(a, stream);

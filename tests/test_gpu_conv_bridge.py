@@ -58,9 +58,13 @@ CASES = {
 }
 
 
+@pytest.mark.parametrize('brf', ['0', '1'], ids=['one_workgroup_per_cu', 'two_workgroups_per_cu'])
 @pytest.mark.parametrize('name', list(CASES))
-def test_conv_bridge_kernel(dev, name):
+def test_conv_bridge_kernel(dev, name, brf, monkeypatch):
+    """Both tiles of the fused kernel: MODE_BR (default: the <16,64,2,2> tile) and MODE_BRF (CPN_BRF=1: 8-row tiles on 4 waves,
+    flat pitch-34 halo tiles, two workgroups per CU -- measured neutral, kept as an opt-in)."""
     from celldetection_amd import _lib, graph
+    monkeypatch.setenv('CPN_BRF', brf)
     cfg = dict(seed=0)
     cfg.update(CASES[name])
     n, h, w, cin = (cfg[k] for k in ('n', 'h', 'w', 'cin'))
