@@ -14,9 +14,10 @@ ABI_VERSION = 11
 PRECISION_BF16, PRECISION_F32, PRECISION_FP8 = 0, 1, 2
 E_INVALID, E_UNSUPPORTED, E_WORKSPACE = -1, -2, -3
 
-OP_INPUT, OP_CONV, OP_MAXPOOL, OP_BILINEAR, OP_CONV_DEFERRED, OP_INPUT_STEM, OP_STEM7, OP_CONV_PAIR, OP_CONV_BRIDGE = \
-    0, 1, 2, 3, 4, 5, 6, 7, 8
+OP_INPUT, OP_CONV, OP_MAXPOOL, OP_BILINEAR, OP_CONV_DEFERRED, OP_INPUT_STEM, OP_STEM7, OP_CONV_PAIR, OP_CONV_BRIDGE, OP_ACT = \
+    0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH_SCALED = 0, 1, 2, 3
+ACT_LEAKY_RELU, ACT_SILU, ACT_GELU, ACT_ELU, ACT_TANH, ACT_HARDSWISH, ACT_MISH, ACT_SELU, ACT_SOFTPLUS = 4, 5, 6, 7, 8, 9, 10, 11, 12
 SUBPIXEL_NONE, SUBPIXEL_HEAD, SUBPIXEL_PHASE, SUBPIXEL_LATERAL, SUBPIXEL_SCATTER = 0, 1, 2, 3, 4
 SUBPIXEL_BL_HEAD, SUBPIXEL_BL_PHASE, SUBPIXEL_BL_FRAME = 5, 6, 7
 OUT_SCORES, OUT_LOCATIONS, OUT_FOURIER, OUT_REFINEMENT, OUT_UNCERTAINTY = 0, 1, 2, 3, 4

@@ -352,14 +352,16 @@ class CPN(nn.Module):
         unsupported = {k: v for k, v in kwargs.items() if (k in ('contour_head_stride', 'refinement_head_stride')
                                                            and v not in (None, 1, 2))
                        or (k == 'refinement_interpolation' and v != 'bilinear')
-                       or (k == 'refinement_full_res' and v is not True) or (k == 'fuse_kwargs' and v)
-                       or (k.startswith('head_activation') and v != 'relu')}
+                       or (k == 'refinement_full_res' and v is not True) or (k == 'fuse_kwargs' and v)}
         if unsupported:
             raise NotImplementedError(f'Unsupported CPN options on the HIP path: {unsupported}')
         features = {name: kwargs[key] for name, key in (('score', 'score_features'), ('location', 'location_features'),
                                                         ('contour', 'contour_features'), ('uncertainty', 'uncertainty_features'),
                                                         ('refinement', 'refinement_features')) if kwargs.get(key) is not None}
         kernel_sizes = {k[len('kernel_size_'):]: int(v) for k, v in kwargs.items() if k.startswith('kernel_size_')}
+        # hidden activation of the ReadOut heads: `head_activation_<head>`, else `head_activation`, else ReLU (cpn.py:183-233)
+        head_act = {h: graph.head_activation_name(kwargs.get(f'head_activation_{h}', kwargs.get('head_activation', 'relu')))
+                    for h in ('score', 'location', 'fourier', 'uncertainty', 'refinement')}
         self.order = order
         self.nms_thresh = nms_thresh
         self.samples = samples
@@ -383,7 +385,8 @@ class CPN(nn.Module):
                                  refinement_head_channels=kwargs.get('refinement_head_channels'),
                                  kernel_sizes=kernel_sizes, features=features or None,
                                  contour_head_stride=int(kwargs.get('contour_head_stride') or 1),
-                                 refinement_head_stride=int(kwargs.get('refinement_head_stride') or 1))
+                                 refinement_head_stride=int(kwargs.get('refinement_head_stride') or 1),
+                                 head_activations=head_act if any(v != 'relu' for v in head_act.values()) else None)
         # 'bf16' (MFMA performance path) | 'fp32' (verification path, ~100x slower) | 'fp8' (e4m3 activations and
         # weights on the K=64 scaled MFMA, 2x the bf16 rate; static activation scales from ``calibrate_fp8`` or, if
         # that was not called, from the first batch that is forwarded)

@@ -196,4 +196,15 @@ int launch_bilinear_f32(const ResizeArgs &a, hipStream_t stream) {
     return (int) hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void act_f32_kernel(const ActArgs a) {
+    for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < a.count; i += (long) gridDim.x * blockDim.x)
+        ((float *) a.dst)[i] = act_apply(((const float *) a.src)[i], a.act);
+}
+int launch_act_f32(const ActArgs &a, hipStream_t stream) {
+    long blocks = (a.count + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(act_f32_kernel, dim3((unsigned) (blocks < 1 ? 1 : blocks)), dim3(256), 0, stream, a);
+    return (int) hipGetLastError();
+}
+
 }  // namespace cpn

@@ -217,6 +217,10 @@ static void propagate_dims(const cpn_plan *p, int N, int H, int W, ShapePlan &sp
                 if (sp.th[o.src0] + 2 * o.pad < o.kh || sp.tw[o.src0] + 2 * o.pad < o.kw) bad("input too small for the max-pool");
                 break;
             case CPN_OP_BILINEAR: sp.th[o.dst] = H; sp.tw[o.dst] = W; break;
+            case CPN_OP_ACT:
+                if (o.dst < 0 || o.src0 < 0) { bad("activation op: missing tensors"); break; }
+                sp.th[o.dst] = sp.th[o.src0]; sp.tw[o.dst] = sp.tw[o.src0];
+                break;
             case CPN_OP_CONV:
             case CPN_OP_CONV_DEFERRED: {
                 int hv, wv;
@@ -556,6 +560,16 @@ int cpn_plan_create(cpn_plan **plan, const cpn_tensor_desc *tensors, int32_t n_t
                                            "the tensor between them must have no other reader");
             }
         }
+        if (o.op == CPN_OP_ACT && (o.src0 < 0 || o.dst < 0 || o.act < CPN_ACT_RELU || o.act > CPN_ACT_SOFTPLUS || o.act == CPN_ACT_TANH_SCALED ||
+                                   p->tensors[o.src0].channels != p->tensors[o.dst].channels)) {
+            delete p;
+            return fail(CPN_E_INVALID, "cpn_plan_create: an activation op needs source and destination tensors of equal channel count "
+                                       "and one of the elementwise activations");
+        }
+        if ((o.op == CPN_OP_CONV || o.op == CPN_OP_CONV_DEFERRED) && (o.act > CPN_ACT_TANH_SCALED || o.fuse_act > CPN_ACT_TANH_SCALED)) {
+            delete p;
+            return fail(CPN_E_INVALID, "cpn_plan_create: conv ops take CPN_ACT_NONE .. CPN_ACT_TANH_SCALED (other activations are CPN_OP_ACT ops)");
+        }
         if (o.alt < 0 || o.alt > 2) {
             delete p;
             return fail(CPN_E_INVALID, "cpn_plan_create: alt must be 0, 1 or 2");
@@ -694,6 +708,14 @@ static int run_or_count(cpn_plan *plan, const void *input, int32_t in_dtype, int
                            tch(o.src0), o.kh, o.stride, o.pad};
                 rc = check_hip((hipError_t) (f32 ? launch_maxpool_f32(a, st) : fp8 ? launch_maxpool_fp8(a, st)
                                                                                   : launch_maxpool(a, st)), "maxpool kernel");
+                break;
+            }
+            case CPN_OP_ACT: {
+                if (flops) break;
+                ActArgs a{tptr(o.src0), tptr(o.dst), (long) N * sp.th[o.src0] * sp.tw[o.src0] * tch(o.src0), o.act,
+                          fp8 ? plan->tensors[o.src0].scale : 1.f, fp8 ? 1.f / plan->tensors[o.dst].scale : 1.f};
+                rc = check_hip((hipError_t) (f32 ? launch_act_f32(a, st) : fp8 ? launch_act_fp8(a, st) : launch_act(a, st)),
+                               "activation kernel");
                 break;
             }
             case CPN_OP_BILINEAR: {

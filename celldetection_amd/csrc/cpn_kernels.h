@@ -10,7 +10,28 @@ namespace cpn {
 // Implicit-GEMM convolution (NHWC bf16 activations, packed bf16 weights, fp32 accumulate on MFMA)
 // ---------------------------------------------------------------------------------------------------------
 enum OutMode : int { OUT_BF16_NHWC = 0, OUT_F32_NCHW = 1, OUT_FUSED_HEAD = 2 };
-enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_TANH_SCALED = 3 };
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_TANH_SCALED = 3,
+                 // hidden activations of the ReadOut heads beyond ReLU (round 5; `head_activation*` of models/cpn.py:183-233 ->
+                 // lookup_nn(name): torch.nn modules with their default arguments)
+                 ACT_LEAKY_RELU = 4, ACT_SILU = 5, ACT_GELU = 6, ACT_ELU = 7, ACT_TANH = 8, ACT_HARDSWISH = 9, ACT_MISH = 10,
+                 ACT_SELU = 11, ACT_SOFTPLUS = 12 };
+// the activations above ACT_TANH_SCALED, as torch.nn computes them in fp32 (LeakyReLU slope 0.01, GELU exact (erf), ELU alpha 1,
+// Softplus beta 1 / threshold 20); the first four keep their own code at the call sites
+__host__ __device__ inline float act_apply(float x, int act) {
+    switch (act) {
+        case ACT_SIGMOID: return 1.f / (1.f + expf(-x));
+        case ACT_LEAKY_RELU: return x > 0.f ? x : 0.01f * x;
+        case ACT_SILU: return x / (1.f + expf(-x));
+        case ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+        case ACT_ELU: return x > 0.f ? x : expm1f(x);
+        case ACT_TANH: return tanhf(x);
+        case ACT_HARDSWISH: return x * fminf(fmaxf(x + 3.f, 0.f), 6.f) / 6.f;
+        case ACT_MISH: return x * tanhf(x > 20.f ? x : log1pf(expf(x)));
+        case ACT_SELU: return 1.0507009873554804934193349852946f * (x > 0.f ? x : 1.6732632423543772848170429916717f * expm1f(x));
+        case ACT_SOFTPLUS: return x > 20.f ? x : log1pf(expf(x));
+        default: return x;
+    }
+}
 
 struct ConvArgs {
     // sources (NHWC bf16).  The conv input is the virtual channel concat [src0 | src1]; a source flagged "up"
@@ -145,6 +166,18 @@ struct PoolArgs {
     int k, stride, pad;
 };
 int launch_maxpool(const PoolArgs &a, hipStream_t stream);
+
+// elementwise activation of an NHWC tensor (CPN_OP_ACT: the hidden activation of a ReadOut head other than ReLU; the kernels that
+// carry the libm code are these three alone -- inlined into the conv epilogues it multiplied their compile time)
+struct ActArgs {
+    const void *src; void *dst;
+    long count;              // elements (multiple of 8)
+    int act;                 // ACT_* (act_apply)
+    float in_scale, out_inv_scale;   // fp8: value = code * in_scale; code' = e4m3(act(value) * out_inv_scale)
+};
+int launch_act(const ActArgs &a, hipStream_t stream);       // bf16
+int launch_act_f32(const ActArgs &a, hipStream_t stream);
+int launch_act_fp8(const ActArgs &a, hipStream_t stream);
 
 struct ResizeArgs {
     const void *src; void *dst;

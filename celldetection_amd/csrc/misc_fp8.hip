@@ -180,4 +180,21 @@ int launch_absmax_bf16(const void *x, long count, float *out, hipStream_t stream
     return (int) hipGetLastError();
 }
 
+// ---- elementwise activation on e4m3 codes (CPN_OP_ACT): decode with the source tensor's scale, encode with the destination's
+__global__ __launch_bounds__(256) void act_fp8_kernel(const ActArgs a) {
+    const long groups = a.count >> 3;
+    for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < groups; i += (long) gridDim.x * blockDim.x) {
+        float v[8];
+        decode8(((const u32x2 *) a.src)[i], v);
+#pragma unroll 1
+        for (int e = 0; e < 8; ++e) v[e] = act_apply(v[e] * a.in_scale, a.act) * a.out_inv_scale;
+        ((u32x2 *) a.dst)[i] = encode8(v);
+    }
+}
+int launch_act_fp8(const ActArgs &a, hipStream_t stream) {
+    if (a.count % 8) return (int) hipErrorInvalidValue;
+    hipLaunchKernelGGL(act_fp8_kernel, dim3(grid_for(a.count >> 3)), dim3(256), 0, stream, a);
+    return (int) hipGetLastError();
+}
+
 }  // namespace cpn

@@ -217,4 +217,30 @@ int launch_rescale_u8(const void *x, int dtype, long n, double low, double high,
     return (int) hipGetLastError();
 }
 
+// ---- elementwise activation (CPN_OP_ACT): 8 bf16 per thread, fp32 math as torch.nn computes it, one rounding
+__global__ __launch_bounds__(256) void act_bf16_kernel(const ActArgs a) {
+    const long groups = a.count >> 3;
+    for (long i = blockIdx.x * (long) blockDim.x + threadIdx.x; i < groups; i += (long) gridDim.x * blockDim.x) {
+        const uint4 r = ((const uint4 *) a.src)[i];
+        const unsigned in[4] = {r.x, r.y, r.z, r.w};
+        unsigned out[4];
+#pragma unroll 1
+        for (int e = 0; e < 4; ++e) {
+            const float lo = act_apply(__uint_as_float(in[e] << 16), a.act), hi = act_apply(__uint_as_float(in[e] & 0xffff0000u), a.act);
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+            typedef __attribute__((ext_vector_type(2))) float f2;
+            const f2 v = {lo, hi};
+            out[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2));
+        }
+        ((uint4 *) a.dst)[i] = make_uint4(out[0], out[1], out[2], out[3]);
+    }
+}
+int launch_act(const ActArgs &a, hipStream_t stream) {
+    if (a.count % 8) return (int) hipErrorInvalidValue;
+    long blocks = ((a.count >> 3) + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(act_bf16_kernel, dim3((unsigned) (blocks < 1 ? 1 : blocks)), dim3(256), 0, stream, a);
+    return (int) hipGetLastError();
+}
+
 }  // namespace cpn

@@ -127,6 +127,13 @@ class Plan:
                                  w=c1['w'] + '+' + c2['w'].rsplit('.', 2)[-2] + '.'))
         return ok
 
+    def act(self, src, name):
+        """Elementwise activation as an op of its own (CPN_OP_ACT): the hidden activation of a ReadOut head other than ReLU."""
+        t = self.tensors[src]
+        dst = self.tensor(t['c'], t['down'])
+        self.ops.append(dict(op='act', src0=src, dst=dst, act=name))
+        return dst
+
     def maxpool(self, src, k, stride, pad):
         t = self.tensors[src]
         dst = self.tensor(t['c'], t['down'] * stride)
@@ -397,12 +404,23 @@ BACKBONES['U22'] = ('unet', 'U22')
 
 
 def _readout(P, x, cmid, cout, prefix, act, act_scale, out_index, k=7, fuse=True, up0=False, stride=1, deferred=False,
-             bilinear_phases=False, bl_source=None):
-    """ReadOut (commons.py:461-511): conv kxk(bias) -> BN -> ReLU -> Dropout2d(eval: identity) -> conv 1x1(bias).
+             bilinear_phases=False, bl_source=None, hidden='relu'):
+    """ReadOut (commons.py:461-511): conv kxk(bias) -> BN -> ``hidden`` activation (default ReLU) -> Dropout2d(eval: identity) ->
+    conv 1x1(bias).
     ``bilinear_phases`` (fused heads over a bilinear source, k = 3 (mod 4)): the op additionally carries its decomposition for
     the exact x2 case (include/cpn_hip.h CPN_SUBPIXEL_BL_*): four k2 x k2 phase convs on the low-resolution map + the same
     conv restricted to the image frame.  ``bl_source`` (fp8 plans, whose resize is an op of its own): the tensor in front of
     that resize -- the phase convs read it, head and frame conv read ``x``, the materialised resized map."""
+    if hidden != 'relu':
+        # any other hidden activation: conv k x k + BN (no activation, NHWC) -> CPN_OP_ACT -> conv 1x1 + final activation.  The
+        # heads' fused forms (ReadOut tail in the conv kernel, score gate, bilinear phases) are ReLU-only: the libm code of the
+        # other activations lives in three small elementwise kernels instead of every conv epilogue
+        assert not deferred, 'only fused ReLU ReadOut heads can be deferred'
+        t = P.conv(x, cmid, k, w=prefix + 'block.0.', bn=prefix + 'block.1.', bias=True, act='none', up0=up0, stride=stride)
+        if hidden != 'none':
+            t = P.act(t, hidden)
+        P.conv(t, cout, 1, w=prefix + 'block.4.', bias=True, act=act, act_scale=act_scale, out_index=out_index)
+        return
     if fuse and FUSE_READOUT and _pad32(cmid) in (32, 64, 128, 256) and cout <= 32:
         # one kernel: conv kxk + BN + ReLU -> (bf16, LDS) -> 1x1 conv + final activation -> fp32 NCHW head map
         kw = dict(w=prefix + 'block.0.', bn=prefix + 'block.1.', bias=True, act='relu', out_index=out_index,
@@ -426,7 +444,7 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
                kernel_sizes: dict = None, fuse_bilinear: bool = True, contour_head_stride: int = 1,
                refinement_head_stride: int = 1, features: dict = None, sparse_heads: bool = False,
                subpixel: bool = False, stem_fast: bool = False, fuse_blocks: bool = False,
-               bilinear_phases: bool = False) -> Plan:
+               bilinear_phases: bool = False, head_activations: dict = None) -> Plan:
     """Plan of ``Cpn<backbone>`` (celldetection/models/cpn.py:287-439,771-2061; heads: CPNCore.__init__
     cpn.py:125-236).  ``kernel_sizes``: optional {'score'|'location'|'fourier'|'uncertainty'|'refinement': k}
     (the reference's ``kernel_size_<head>`` kwargs, default 7).  ``contour_head_stride`` / ``refinement_head_stride``: stride
@@ -446,7 +464,13 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
     ``fuse_blocks`` (bf16 plans, ResNeXt encoders): every bottleneck block additionally carries conv1 -> grouped conv2 as
     one fused op (``Plan.conv_pair``).
     ``bilinear_phases`` (bf16 / fp8 plans): the refinement head over the bilinear-resized feature map (FPN models) additionally
-    carries its sub-pixel decomposition (``_readout``)."""
+    carries its sub-pixel decomposition (``_readout``).  ``head_activations``: optional {'score'|'location'|'fourier'|
+    'uncertainty'|'refinement': plan activation name} = the reference's ``head_activation`` / ``head_activation_<head>`` kwargs
+    (cpn.py:183-233; default 'relu'; see ``head_activation_name``)."""
+    ha = dict(score='relu', location='relu', fourier='relu', uncertainty='relu', refinement='relu')
+    ha.update(head_activations or {})
+    if any(v not in _ACT or v == 'tanh_scaled' for v in ha.values()):
+        raise ValueError(f'unknown head activation in {ha}')
     if contour_head_stride not in (1, 2) or refinement_head_stride not in (1, 2):
         raise NotImplementedError('head strides other than 1 and 2 are not supported by the HIP conv kernel')
     feats_cfg = dict(score='1', location='1', contour='1', uncertainty='1', refinement='0')
@@ -524,24 +548,25 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
     # binary: sigmoid fused into the head; multi-class: raw logits, softmax/argmax in cpn_class_scores (cpn.py:583-585)
     hs = contour_head_stride
     _readout(P, f1s, cm1 or c1, score_channels, 'core.score_head.', 'sigmoid' if score_channels == 1 else 'none', 0.,
-             _lib.OUT_SCORES, k=ks.get('score', 7), fuse=fuse_readout, stride=hs)
+             _lib.OUT_SCORES, k=ks.get('score', 7), fuse=fuse_readout, stride=hs, hidden=ha['score'])
     fl, cl = _head_input('location', 'core.location_fuse.')
     # score-gated heads: both heads on the same single feature key (then `_head_input` adds no op and the two share fl)
     same_src = _keys(feats_cfg['contour']) == _keys(feats_cfg['location']) and len(_keys(feats_cfg['location'])) == 1
     gate = bool(sparse_heads) and fuse_readout and FUSE_READOUT and same_src and hs == 1 and order * 4 <= 32 and \
-        _pad32(cm1 or cl) in (128, 256) and ks.get('location', 7) == ks.get('fourier', 7) and ks.get('location', 7) > 1
+        _pad32(cm1 or cl) in (128, 256) and ks.get('location', 7) == ks.get('fourier', 7) and ks.get('location', 7) > 1 and \
+        ha['location'] == ha['fourier'] == 'relu'  # (the gathered kernel's hidden activation is ReLU)
     first_head_op = len(P.ops)
     _readout(P, fl, cm1 or cl, 2, 'core.location_head.', 'none', 0., _lib.OUT_LOCATIONS, k=ks.get('location', 7),
-             fuse=fuse_readout, stride=hs, deferred=gate)
+             fuse=fuse_readout, stride=hs, deferred=gate, hidden=ha['location'])
     ff, cf = _head_input('contour', 'core.fourier_fuse.')
     _readout(P, ff, cm1 or cf, order * 4, 'core.fourier_head.', 'none', 0., _lib.OUT_FOURIER, k=ks.get('fourier', 7),
-             fuse=fuse_readout, stride=hs, deferred=gate)
+             fuse=fuse_readout, stride=hs, deferred=gate, hidden=ha['fourier'])
     assert not gate or (ff == fl and cf == cl)
     sparse_meta = dict(ops=(first_head_op, first_head_op + 1), src=fl) if gate else None
     if uncertainty_head:  # cpn.py:209-221: 4 channels, sigmoid
         fu, cu = _head_input('uncertainty', 'core.uncertainty_fuse.')
         _readout(P, fu, cm1 or cu, 4, 'core.uncertainty_head.', 'sigmoid', 0., _lib.OUT_UNCERTAINTY,
-                 k=ks.get('uncertainty', 7), fuse=fuse_readout, stride=hs)
+                 k=ks.get('uncertainty', 7), fuse=fuse_readout, stride=hs, hidden=ha['uncertainty'])
     if refinement:
         r, c0 = _head_input('refinement', 'core.refinement_fuse.')
         cm0 = cm0 or c0
@@ -561,7 +586,8 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
         _readout(P, r, cm0, 2 * refinement_buckets, 'core.refinement_head.', 'tanh_scaled', float(refinement_margin),
                  _lib.OUT_REFINEMENT, k=kr, fuse=fuse_readout, up0='bilinear' if fused_resize else False,
                  stride=refinement_head_stride, bilinear_phases=bilinear_phases and (fused_resize or r_low is not None),
-                 bl_source=r_low if (bilinear_phases and kr > 1 and refinement_head_stride == 1) else None)
+                 bl_source=r_low if (bilinear_phases and kr > 1 and refinement_head_stride == 1) else None,
+                 hidden=ha['refinement'])
         if r_low is not None and any(op.get('sub') == 'blhead' for op in P.ops[-3:]):
             resize_op['ring_for_bl'] = True  # (the executor writes only the frame's neighbourhood of that map when the phases run)
     P.meta = dict(backbone=backbone, order=order, head_down=scale, refinement=refinement, in_channels=in_channels,
@@ -573,7 +599,24 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
 # ---------------------------------------------------------------------------------------------------------------------
 # packing
 # ---------------------------------------------------------------------------------------------------------------------
-_ACT = {'none': _lib.ACT_NONE, 'relu': _lib.ACT_RELU, 'sigmoid': _lib.ACT_SIGMOID, 'tanh_scaled': _lib.ACT_TANH_SCALED}
+_ACT = {'none': _lib.ACT_NONE, 'relu': _lib.ACT_RELU, 'sigmoid': _lib.ACT_SIGMOID, 'tanh_scaled': _lib.ACT_TANH_SCALED,
+        'leaky_relu': _lib.ACT_LEAKY_RELU, 'silu': _lib.ACT_SILU, 'gelu': _lib.ACT_GELU, 'elu': _lib.ACT_ELU, 'tanh': _lib.ACT_TANH,
+        'hardswish': _lib.ACT_HARDSWISH, 'mish': _lib.ACT_MISH, 'selu': _lib.ACT_SELU, 'softplus': _lib.ACT_SOFTPLUS}
+# hidden activations of the ReadOut heads (``head_activation*`` of models/cpn.py:183-233 -> ``lookup_nn(name)``: the torch.nn module
+# of that name, case-insensitive, default arguments) -> activation names of the plan
+HEAD_ACTIVATIONS = {'relu': 'relu', 'leakyrelu': 'leaky_relu', 'silu': 'silu', 'gelu': 'gelu', 'elu': 'elu', 'tanh': 'tanh',
+                    'sigmoid': 'sigmoid', 'hardswish': 'hardswish', 'mish': 'mish', 'selu': 'selu', 'softplus': 'softplus',
+                    'identity': 'none'}
+
+
+def head_activation_name(value) -> str:
+    """Plan activation for a ``head_activation*`` value of the reference (a torch.nn class name as ``lookup_nn`` resolves it)."""
+    key = value.__name__ if isinstance(value, type) else str(value)
+    key = key.lower().replace('_', '')
+    if key not in HEAD_ACTIVATIONS:
+        raise NotImplementedError(f'head activation {value!r} is not supported by the HIP engine '
+                                  f'(supported: {sorted(HEAD_ACTIVATIONS)})')
+    return HEAD_ACTIVATIONS[key]
 
 
 def _fold(sd, op):
@@ -701,6 +744,9 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=Non
             d.res_up, d.act, d.act_scale, d.out_index, d.cout_real = c2.res_up, c2.act, c2.act_scale, -1, c2.cout_real
             d.weight_offset, d.bias_offset = c1.weight_offset, c1.bias_offset
             d.fuse_weight_offset, d.fuse_bias_offset, d.fuse_cout = c2.weight_offset, c2.bias_offset, 0
+            continue
+        if op['op'] == 'act':
+            d.op, d.src0, d.dst, d.act = _lib.OP_ACT, op['src0'], op['dst'], _ACT[op['act']]
             continue
         if op['op'] == 'maxpool':
             d.op, d.src0, d.dst = _lib.OP_MAXPOOL, op['src0'], op['dst']

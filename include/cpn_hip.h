@@ -83,8 +83,14 @@ typedef struct {
  * wherever the output is at least 16 x 32 pixels and nothing else reads the tensor in between (CPN_BRIDGE=0 in the
  * environment: never); same operands, K order and rounding points as the two launches. */
 enum { CPN_OP_INPUT = 0, CPN_OP_CONV = 1, CPN_OP_MAXPOOL = 2, CPN_OP_BILINEAR = 3, CPN_OP_CONV_DEFERRED = 4,
-       CPN_OP_INPUT_STEM = 5, CPN_OP_STEM7 = 6, CPN_OP_CONV_PAIR = 7, CPN_OP_CONV_BRIDGE = 8 };
-enum { CPN_ACT_NONE = 0, CPN_ACT_RELU = 1, CPN_ACT_SIGMOID = 2, CPN_ACT_TANH_SCALED = 3 };
+       CPN_OP_INPUT_STEM = 5, CPN_OP_STEM7 = 6, CPN_OP_CONV_PAIR = 7, CPN_OP_CONV_BRIDGE = 8, CPN_OP_ACT = 9 };
+/* 4..12 (ABI 11): hidden activations of the ReadOut heads other than ReLU (`head_activation*`, celldetection/models/cpn.py:183-233), as
+ * the torch.nn modules of those names compute them with default arguments.  They are ops of their own -- CPN_OP_ACT: dst = act(src0),
+ * elementwise on an NHWC tensor of any precision -- between the head's k x k conv (act NONE, not fused) and its 1x1 conv; conv ops
+ * take CPN_ACT_NONE .. CPN_ACT_TANH_SCALED only */
+enum { CPN_ACT_NONE = 0, CPN_ACT_RELU = 1, CPN_ACT_SIGMOID = 2, CPN_ACT_TANH_SCALED = 3, CPN_ACT_LEAKY_RELU = 4, CPN_ACT_SILU = 5,
+       CPN_ACT_GELU = 6, CPN_ACT_ELU = 7, CPN_ACT_TANH = 8, CPN_ACT_HARDSWISH = 9, CPN_ACT_MISH = 10, CPN_ACT_SELU = 11,
+       CPN_ACT_SOFTPLUS = 12 };
 /* Sub-pixel decomposition of a k = 3 conv over cat(lateral, nearest-x2-upsampled top-down map) -- the first conv of every
  * GeneralizedUNet decoder level (celldetection/models/unet.py:213-224).  Output pixel (2i+py, 2j+px) sees the upsampled
  * map through 2 x 2 distinct low-resolution pixels only, so that part of the conv is FOUR 2 x 2 convs on the

@@ -147,10 +147,20 @@ def _fpn(feats, sd, p):
     return OrderedDict((str(i), r) for i, r in enumerate(results))
 
 
-def _readout(x, sd, p, stride=1):
-    """ReadOut: conv kxk (bias, pad k//2, stride) -> BN -> ReLU -> Dropout(eval: id) -> conv1x1, commons.py:461-511."""
+def _hidden_act(name):
+    """``lookup_nn(name)`` of the reference for the hidden activation of a ReadOut head: the torch.nn module of that name
+    (case-insensitive) with default arguments (util/util.py:140-200)."""
+    key = str(name).lower().replace('_', '')
+    mods = {n.lower(): getattr(torch.nn, n) for n in ('ReLU', 'LeakyReLU', 'SiLU', 'GELU', 'ELU', 'Tanh', 'Sigmoid', 'Hardswish',
+                                                      'Mish', 'SELU', 'Softplus', 'Identity')}
+    return mods[key]()
+
+
+def _readout(x, sd, p, stride=1, act='relu'):
+    """ReadOut: conv kxk (bias, pad k//2, stride) -> BN -> activation (default ReLU) -> Dropout(eval: id) -> conv1x1,
+    commons.py:461-511."""
     k = sd[p + 'block.0.weight'].shape[-1]
-    x = F.relu(_bn(_conv(x, sd, p + 'block.0.', stride=stride, padding=k // 2), sd, p + 'block.1.'))
+    x = _hidden_act(act)(_bn(_conv(x, sd, p + 'block.0.', stride=stride, padding=k // 2), sd, p + 'block.1.'))
     return _conv(x, sd, p + 'block.4.')
 
 
@@ -168,7 +178,7 @@ def _head_features(feats, keys, sd, fuse_prefix):
 
 
 def core_forward(state_dict, x, refinement_margin=3., with_uncertainty=False, contour_head_stride=1,
-                 refinement_head_stride=1, features=None):
+                 refinement_head_stride=1, features=None, head_activations=None):
     """CPNCore.forward, models/cpn.py:238-283 -> (raw scores, locations, refinement, fourier), all fp32 NCHW
     (+ the sigmoid uncertainty map [N,4,h,w] or None as fifth element when ``with_uncertainty``).
 
@@ -196,17 +206,21 @@ def core_forward(state_dict, x, refinement_margin=3., with_uncertainty=False, co
         fk = dict(score='1', location='1', contour='1', uncertainty='1', refinement='0')
         fk.update(features or {})  # the <head>_features kwargs of CPNCore (cpn.py:135-139)
         hs = contour_head_stride
-        scores = _readout(_head_features(feats, fk['score'], sd, 'core.score_fuse.'), sd, 'core.score_head.', hs)
-        locations = _readout(_head_features(feats, fk['location'], sd, 'core.location_fuse.'), sd, 'core.location_head.', hs)
-        fourier = _readout(_head_features(feats, fk['contour'], sd, 'core.fourier_fuse.'), sd, 'core.fourier_head.', hs)
+        ha = dict(score='relu', location='relu', fourier='relu', uncertainty='relu', refinement='relu')
+        ha.update(head_activations or {})  # head_activation / head_activation_<head> (cpn.py:183-233)
+        scores = _readout(_head_features(feats, fk['score'], sd, 'core.score_fuse.'), sd, 'core.score_head.', hs, ha['score'])
+        locations = _readout(_head_features(feats, fk['location'], sd, 'core.location_fuse.'), sd, 'core.location_head.', hs,
+                             ha['location'])
+        fourier = _readout(_head_features(feats, fk['contour'], sd, 'core.fourier_fuse.'), sd, 'core.fourier_head.', hs,
+                           ha['fourier'])
         uncertainty = None
         if _has(sd, 'core.uncertainty_head.'):  # cpn.py:209-221,266-271: ReadOut with final sigmoid
             uncertainty = torch.sigmoid(_readout(_head_features(feats, fk['uncertainty'], sd, 'core.uncertainty_fuse.'), sd,
-                                                 'core.uncertainty_head.', hs))
+                                                 'core.uncertainty_head.', hs, ha['uncertainty']))
         f0 = _head_features(feats, fk['refinement'], sd, 'core.refinement_fuse.')
         if f0.shape[2:] != x.shape[2:]:  # cpn.py:277-278
             f0 = F.interpolate(f0, x.shape[2:], mode='bilinear', align_corners=False)
-        refinement = torch.tanh(_readout(f0, sd, 'core.refinement_head.', refinement_head_stride)) * refinement_margin
+        refinement = torch.tanh(_readout(f0, sd, 'core.refinement_head.', refinement_head_stride, ha['refinement'])) * refinement_margin
         if refinement.shape[2:] != x.shape[2:]:
             refinement = F.interpolate(refinement, x.shape[2:], mode='bilinear', align_corners=False)
     if with_uncertainty:

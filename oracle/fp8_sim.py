@@ -23,7 +23,9 @@ def _act(t, act, act_scale):
         return torch.sigmoid(t)
     if act == 'tanh_scaled':
         return torch.tanh(t) * act_scale
-    return t
+    fn = dict(sigmoid=torch.sigmoid, leaky_relu=F.leaky_relu, silu=F.silu, gelu=F.gelu, elu=F.elu, tanh=torch.tanh, hardswish=F.hardswish, mish=F.mish,
+              selu=F.selu, softplus=F.softplus).get(act)
+    return fn(t) if fn is not None else t
 
 
 def calibrate(plan, state_dict, x):
@@ -90,6 +92,8 @@ def _simulate(plan, state_dict, effective_weights, act_scales, x, T, outs, ei, _
             continue
         if kind == 'input':
             T[op['dst']] = _q(x, act_scales[op['dst']])
+        elif kind == 'act':  # elementwise activation op (hidden activation of a head other than ReLU): decode, act, re-quantise
+            T[op['dst']] = _q(_act(T[op['src0']], op['act'], 0.), act_scales[op['dst']])
         elif kind == 'maxpool':
             T[op['dst']] = F.max_pool2d(T[op['src0']], op['k'], op['stride'], op['pad'])  # codes unchanged
         elif kind == 'bilinear':

@@ -71,6 +71,17 @@ HEAD_SPECS = {
         backbone_kwargs={'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}), cpn_kwargs=dict(_DEF),
         core_kwargs=dict(features=dict(score=['1', '2', '3'], contour=['1', '2', '3'], location=['1', '3', '2'],
                                        refinement=['0', '1', '2']))),
+    'CpnU22_headact': dict(cls='CpnU22', kwargs=dict(in_channels=3, head_activation='silu', head_activation_score='gelu',
+                                                     head_activation_refinement='LeakyReLU', backbone_kwargs=_U8),
+                           cpn_kwargs=dict(_DEF),
+                           core_kwargs=dict(head_activations=dict(score='gelu', location='silu', fourier='silu',
+                                                                  uncertainty='silu', refinement='LeakyReLU'))),
+    'CpnResNet18FPN_headact': dict(cls='CpnResNet18FPN', kwargs=dict(
+        in_channels=3, head_activation='elu', head_activation_fourier='tanh', head_activation_location='mish',
+        head_activation_refinement='hardswish',
+        backbone_kwargs={'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}), cpn_kwargs=dict(_DEF),
+        core_kwargs=dict(head_activations=dict(score='elu', location='mish', fourier='tanh', uncertainty='elu',
+                                               refinement='hardswish'))),
     'CpnResNet50UNet_feats': dict(cls='CpnResNet50UNet', kwargs=dict(
         in_channels=3, score_features='2', contour_features='2', location_features='2',
         refinement_features=['0', 'encoder.0'], backbone_kwargs=_R8), cpn_kwargs=dict(_DEF),

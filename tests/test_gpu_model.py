@@ -586,7 +586,7 @@ def test_full_size_properties(dev):
     assert abs(n_ref - len(got8['scores'][0])) <= 0.2 * n_ref and rate8 > .8  # measured 0.897
 
 
-@pytest.mark.parametrize('name', ['CpnU22', 'CpnU22_wide', 'CpnResNeXt101UNet', 'CpnResNet18FPN', 'CpnResNet50FPN'])
+@pytest.mark.parametrize('name', ['CpnU22', 'CpnU22_wide', 'CpnResNeXt101UNet', 'CpnResNet18FPN', 'CpnResNet50FPN', 'CpnU22_headact'])
 def test_fp8_precision_vs_reference_maps(dev, name):
     """fp8 (e4m3 activations + weights, K=64 scaled MFMA) conv stack against the reference's fp32 head maps: e4m3 has a
     3-bit mantissa (2^-4 relative rounding per value), so the check is a relative L2 bound per head map plus an
