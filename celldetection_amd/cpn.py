@@ -350,7 +350,7 @@ class CPN(nn.Module):
                  backbone_kwargs: dict = None, **kwargs):
         super().__init__()
         unsupported = {k: v for k, v in kwargs.items() if (k in ('contour_head_stride', 'refinement_head_stride')
-                                                           and v not in (None, 1, 2))
+                                                           and v not in (None, 1, 2, 4, 8))
                        or (k == 'refinement_interpolation' and v != 'bilinear')
                        or (k == 'refinement_full_res' and v is not True) or (k == 'fuse_kwargs' and v)}
         if unsupported:

@@ -1519,7 +1519,8 @@ int launch_conv(const ConvArgs &a_in, hipStream_t stream) {
     if (a.phase == 3 && (a.out_mode != OUT_FUSED_HEAD || a.bundles != 4 || a.stride != 1)) return (int) hipErrorInvalidValue;
     if ((a.region == 1 || a.region == 2) ? (a.out_mode != OUT_FUSED_HEAD || a.region_margin < 0) : a.region != 0)
         return (int) hipErrorInvalidValue;  // (region masks live in the fused-head epilogue)
-    if (a.stride != 1 && a.stride != 2) return (int) hipErrorInvalidValue;
+    // (k x k: stride 1 | 2; a 1x1 conv's tile gathers only its outputs: any stride -- the 1x1 tail of a ReadOut head at stride 4 / 8)
+    if (a.stride != 1 && a.stride != 2 && !(a.KH == 1 && a.KW == 1 && a.pad == 0 && a.stride >= 1)) return (int) hipErrorInvalidValue;
     if (a.up0 == 2 && (CPN_FP8 || a.stride != 1 || a.src1 || a.up1 || (a.KH == 1 && a.KW == 1)))
         return (int) hipErrorInvalidValue;  // bilinear source: single-source KxK stride-1 convs of the bf16 path only
     if ((a.stride == 1 && a.KW > 17) || (a.stride == 2 && a.KW > 18)) return (int) hipErrorInvalidValue;

@@ -411,6 +411,18 @@ def _readout(P, x, cmid, cout, prefix, act, act_scale, out_index, k=7, fuse=True
     the exact x2 case (include/cpn_hip.h CPN_SUBPIXEL_BL_*): four k2 x k2 phase convs on the low-resolution map + the same
     conv restricted to the image frame.  ``bl_source`` (fp8 plans, whose resize is an op of its own): the tensor in front of
     that resize -- the phase convs read it, head and frame conv read ``x``, the materialised resized map."""
+    if stride > 2:
+        # the conv kernel's k x k strides are 1 and 2.  A pointwise conv commutes with subsampling, so ReadOut at stride s = the k x k
+        # conv at stride 2 (+ BN + activation) followed by the 1x1 conv AT STRIDE s / 2: the same taps and sums per output pixel
+        # (floor(floor(a / 2) / (s / 2)) = floor(a / s): the same output size), 4 / s^2 of the hidden pixels are computed in vain
+        assert not deferred and up0 != 'bilinear'
+        t = P.conv(x, cmid, k, w=prefix + 'block.0.', bn=prefix + 'block.1.', bias=True, act='relu' if hidden == 'relu' else 'none',
+                   up0=up0, stride=2)
+        if hidden not in ('relu', 'none'):
+            t = P.act(t, hidden)
+        P.conv(t, cout, 1, w=prefix + 'block.4.', bias=True, act=act, act_scale=act_scale, out_index=out_index, stride=stride // 2,
+               pad=0)
+        return
     if hidden != 'relu':
         # any other hidden activation: conv k x k + BN (no activation, NHWC) -> CPN_OP_ACT -> conv 1x1 + final activation.  The
         # heads' fused forms (ReadOut tail in the conv kernel, score gate, bilinear phases) are ReLU-only: the libm code of the
@@ -471,8 +483,8 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
     ha.update(head_activations or {})
     if any(v not in _ACT or v == 'tanh_scaled' for v in ha.values()):
         raise ValueError(f'unknown head activation in {ha}')
-    if contour_head_stride not in (1, 2) or refinement_head_stride not in (1, 2):
-        raise NotImplementedError('head strides other than 1 and 2 are not supported by the HIP conv kernel')
+    if contour_head_stride not in (1, 2, 4, 8) or refinement_head_stride not in (1, 2, 4, 8):
+        raise NotImplementedError('head strides other than 1, 2, 4 and 8 are not supported by the HIP engine')
     feats_cfg = dict(score='1', location='1', contour='1', uncertainty='1', refinement='0')
     feats_cfg.update(features or {})
     if backbone not in BACKBONES:

@@ -100,6 +100,9 @@ MODEL_SPECS = {
                                                     refinement_features=['0', '1', '2'], backbone_kwargs={
                                                         'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}),
                              (1, 3, 64, 96)),
+    # head strides 4 / 8 (the HIP plan: k x k conv at stride 2 + the 1x1 conv at stride s / 2)
+    'CpnU22_stride4': ('CpnU22', dict(in_channels=3, contour_head_stride=4, refinement_head_stride=8,
+                                      backbone_kwargs={'backbone_kwargs': {'base_channels': 8}}), (2, 3, 128, 160)),
     # hidden activations of the ReadOut heads other than ReLU (head_activation / head_activation_<head>, cpn.py:183-233)
     'CpnU22_headact': ('CpnU22', dict(in_channels=3, head_activation='silu', head_activation_score='gelu',
                                       head_activation_refinement='LeakyReLU',
@@ -267,6 +270,7 @@ MODEL_CALIBRATION = {'CpnU22_classes4': dict(score_shift=-3.5),
                      'CpnU22_strided': dict(score_shift=0., fourier_std=.12, location_std=.3),
                      'CpnU22_odd': dict(score_shift=-1.5, fourier_std=.25, location_std=.4),
                      'CpnResNet50UNet_feats': dict(score_shift=-.3, fourier_std=.25, location_std=.4),
+                     'CpnU22_stride4': dict(score_shift=1.2, fourier_std=.07, location_std=.3, refinement_raw_std=.3),
                      'CpnU22_headact': _U22_SMALL, 'CpnResNet18FPN_headact': _FPN_DENSE,
                      'CpnResNet18FPN_fuse': dict(score_shift=-.5, fourier_std=.4, location_std=.4),
                      'CpnResNet18FPN_fuse3': dict(score_shift=.5, fourier_std=.4, location_std=.4, refinement_raw_std=.3)}

@@ -71,6 +71,9 @@ HEAD_SPECS = {
         backbone_kwargs={'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}), cpn_kwargs=dict(_DEF),
         core_kwargs=dict(features=dict(score=['1', '2', '3'], contour=['1', '2', '3'], location=['1', '3', '2'],
                                        refinement=['0', '1', '2']))),
+    'CpnU22_stride4': dict(cls='CpnU22', kwargs=dict(in_channels=3, contour_head_stride=4, refinement_head_stride=8,
+                                                     backbone_kwargs=_U8), cpn_kwargs=dict(_DEF),
+                           core_kwargs=dict(contour_head_stride=4, refinement_head_stride=8)),
     'CpnU22_headact': dict(cls='CpnU22', kwargs=dict(in_channels=3, head_activation='silu', head_activation_score='gelu',
                                                      head_activation_refinement='LeakyReLU', backbone_kwargs=_U8),
                            cpn_kwargs=dict(_DEF),
