@@ -8,7 +8,8 @@ import os
 import pytest
 
 P = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles')
-LINES = sorted(glob.glob(os.path.join(P, 'r03_bench_*.json')) + glob.glob(os.path.join(P, 'r04_bench_*.json')))
+LINES = sorted(glob.glob(os.path.join(P, 'r03_bench_*.json')) + glob.glob(os.path.join(P, 'r04_bench_*.json')) +
+               glob.glob(os.path.join(P, 'r05_bench_*.json')))
 
 
 def _load(path):
@@ -115,3 +116,45 @@ def test_round_four_slide_lines():
         g = d['gated']
         assert g['identical_to_dense'] is True and g['value'] > 1.2 * d['value']
     assert _load(os.path.join(P, 'r04_bench_slide_4096_rccl_1rank.json'))['config']['world_size_seen_by_rccl'] == 1
+
+
+def test_round_five_lines_are_committed():
+    names = {os.path.basename(p) for p in LINES}
+    for want in ('r05_bench_n1.json', 'r05_bench_slide_n1.json', 'r05_bench_slide_4096_rccl_1rank.json',
+                 'r05_bench_configs1_resnet18fpn.json', 'r05_bench_configs4_resnet50fpn_bf16.json',
+                 'r05_bench_configs4_resnet50fpn_fp8.json', 'r05_bench_fp8_n1.json'):
+        assert want in names, want
+
+
+def test_round_five_headline_carries_the_other_baseline_configs_and_the_setup_phases():
+    """BASELINE configs[1] (bf16) and configs[4] (fp8, the per-GPU share) are timed by the default run, under the
+    same clock as the headline and outside its timed region; `setup_s` says where the wall time of the run went; the dominant-kernel
+    statistics separate the flagship tile (three fused 7x7 heads) from MODE_S1F (the decoder convs on two workgroups per CU)."""
+    d = _load(os.path.join(P, 'r05_bench_n1.json'))
+    assert 'configs[2]' in d['config']['workload'] and d['config']['heads'] == 'dense (reference graph)'
+    assert {'gated', 'sync_forward', 'configs', 'setup_s', 'cpu_baseline'} <= set(d)
+    lines = d['configs']['lines']
+    assert [(l['model'], l['batch'], l['tile'], l['dtype']) for l in lines] == [('CpnResNet18FPN', 8, 512, 'bf16'),
+                                                                                ('CpnResNet50FPN', 8, 1024, 'fp8')]
+    for l in lines:
+        assert abs(l['value'] - l['batch'] / (l['ms_per_step'] / 1e3)) / l['value'] < 1e-6 and l['conv_graph_ms'] <= l['ms_per_step'] * 1.01
+        assert l['peak'] == (5000. if l['dtype'] == 'fp8' else 2500.)
+        assert abs(l['frac'] - l['algorithmic_gflop_per_launch'] / l['conv_graph_ms'] / l['peak']) < 1e-9
+        assert abs(l['executed_frac'] - l['executed_gflop_per_launch'] / l['conv_graph_ms'] / l['peak']) < 1e-9
+        assert 0.3 < l['executed_frac'] < l['frac'] < 0.9 and l['traffic'] and l['detections_last_step'] > 50
+    assert lines[0]['value'] > 700 and lines[1]['value'] > 330
+    s = d['setup_s']
+    assert {'import_torch', 'build_model', 'pack_and_warm', 'timed_region', 'per_op_profile', 'extras', 'configs', 'cpu_baseline'} <= set(s)
+    assert abs(s['timed_region'] - (d['steps'] + d['warmup'] + 2) * d['ms_per_step'] / 1e3) < 1.5   # the timed steps + their warm-up
+    dom = d['roofline']['dominant_kernel']
+    assert dom['kernel'] == 'conv_igemm_kernel<8,256,4,2,1>' and dom['launches_per_graph'] == 3 and 0.4 < dom['share_of_graph_time'] < 0.6
+    sec = dom['second_kernel']
+    assert 'MODE_S1F' in sec['kernel'] and sec['launches_per_graph'] == 11 and 0.45 < sec['frac'] < 0.7
+    assert d['value'] > 560 and d['roofline']['frac'] > 0.54 and d['roofline']['backbone_stack']['frac'] > 0.5
+
+
+def test_round_five_slide_lines():
+    for name, floor in (('r05_bench_slide_n1.json', 500.), ('r05_bench_slide_4096_rccl_1rank.json', 500.)):
+        d = _load(os.path.join(P, name))
+        assert d['scaling'] == 'strong' and d['value'] > floor, (name, d['value'])
+        assert d['gated']['identical_to_dense'] is True and d['gated']['value'] > 1.2 * d['value']
