@@ -59,6 +59,15 @@ def test_contours2labels_matches_reference_loop_goldens():
             assert list(got_keep) == list(keep), name
 
 
+def test_empty_contour_in_a_list_raises_like_the_reference():
+    """a zero-length contour must not be dropped silently (labels and returned indices would refer to positions of
+    the filtered list); the reference fails on it as well (np.min of an empty array in render_contour, data/cpn.py:248)."""
+    import celldetection_amd as cda
+    sq = np.array([[1, 1], [5, 1], [5, 5], [1, 5]], np.float32)
+    with pytest.raises(ValueError, match='zero-length contour at position 1'):
+        cda.contours2labels([sq, np.zeros((0, 2), np.float32), sq + 8], (20, 20))
+
+
 def random_contours(rng, k, size, s=16, rmin=2., rmax=9., spread=1.):
     H, W = size
     t = np.linspace(0, 2 * np.pi, s, endpoint=False)
