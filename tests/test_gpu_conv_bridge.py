@@ -112,18 +112,19 @@ def test_conv_bridge_in_the_plan_and_switch(dev, monkeypatch):
     m.load_state_dict(synth_state_dict(m.state_dict(), seed=0))
     m = m.to(dev)
     assert sum(o['op'] == 'conv_bridge' for o in m.plan_for('bf16').ops) == 1
-    x = torch.rand(2, 3, 96, 128, generator=torch.Generator().manual_seed(1)).to(dev)
-    maps = {}
-    for mode in ('1', '0'):
-        monkeypatch.setenv('CPN_BRIDGE', mode)
-        maps[mode] = [t.clone() for t in m.core_forward(x)]
-        prof = m.engine(dev).profile(x, m.core.order, True)
-        ran = [p['gflop'] > 0 for p in prof if p['op'] == 'conv_bridge']
-        assert ran == [mode == '1'], (mode, ran)
-        two = [p['gflop'] > 0 for p in prof if p['op'] == 'conv' and 'layer_blocks.0.' in (p['name'] or '')]
-        assert two == [mode == '0'] * 2, (mode, two)
-    for a, b in zip(maps['1'], maps['0']):
-        assert torch.equal(a, b)
+    for size in ((96, 128), (75, 101)):  # (odd input: the bridge output is 2 * ceil(H / 2) = 76 x 102 -- ragged tiles inside a plan)
+        x = torch.rand(2, 3, *size, generator=torch.Generator().manual_seed(1)).to(dev)
+        maps = {}
+        for mode in ('1', '0'):
+            monkeypatch.setenv('CPN_BRIDGE', mode)
+            maps[mode] = [t.clone() for t in m.core_forward(x)]
+            prof = m.engine(dev).profile(x, m.core.order, True)
+            ran = [p['gflop'] > 0 for p in prof if p['op'] == 'conv_bridge']
+            assert ran == [mode == '1'], (size, mode, ran)
+            two = [p['gflop'] > 0 for p in prof if p['op'] == 'conv' and 'layer_blocks.0.' in (p['name'] or '')]
+            assert two == [mode == '0'] * 2, (size, mode, two)
+        for a, b in zip(maps['1'], maps['0']):
+            assert torch.equal(a, b), size
     monkeypatch.setenv('CPN_BRIDGE', '1')
     tiny = torch.rand(1, 3, 8, 24, generator=torch.Generator().manual_seed(2)).to(dev)   # output 8 x 24: below one tile
     prof = m.engine(dev).profile(tiny, m.core.order, True)
