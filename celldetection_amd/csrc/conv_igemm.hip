@@ -146,16 +146,21 @@ __device__ __forceinline__ void add_res8(float (&v)[8], const store8_t r, float)
 // of 36 records (34 used by a 3x3 conv) instead of 48 -- a DMA instruction covers 16 consecutive records across row ends, its
 // per-lane source offsets are six loop-invariant registers per wave (no column table) -- and 128-row weight slabs: 2 x 23 + 32
 // = 78 KiB.  Single-source stride-1 k x k convs, 2 <= k <= 5, NHWC output.
+// MODE_S1Q (round 5) = MODE_S1 on the <16,64,2,2> tile with FOUR K items per pipeline step: the 64-channel 7x7 ReadOut head runs 32
+// MFMAs per SIMD between two step boundaries (barrier + DMA landing + drained fragment pipeline: ~950 cycles against 1024 of MFMA
+// work), twice as many halve that share.  Four items x two buffers of 4-KiB slabs fit because the halo tiles are FLAT at pitch 40
+// (38 used by a 7x7 conv): 2 x 55 + 32 = 142 KiB.  Same K order and MFMA sequence per output element as the two-item loop; items
+// past the packed count read zeros through the weight descriptor's bounds.
 // MODE_BR (round 5) = MODE_S1 on the <16,64,2,2> tile whose two halo tiles (cin = 64 = both chunks) are COMPUTED in the kernel:
 // the bridge level of the ResNet-UNets -- conv 3x3 (64 -> 64, bias-free, BN, ReLU) over the x2-upsampled 64-channel map, run as
 // four 2x2 phase convs (CPN_SUBPIXEL_SCATTER), followed by the second conv 3x3 of that TwoConvNormRelu block -- as ONE launch:
 // the 537 MB full-resolution intermediate of a 16 x 512^2 batch is neither written nor read (ConvArgs.pre_*).
-enum Mode : int { MODE_PW = 0, MODE_S1 = 1, MODE_S2 = 2, MODE_BL = 3, MODE_S1R = 4, MODE_PWR = 5, MODE_N = 6, MODE_S1F = 7, MODE_BR = 8, MODE_BRF = 9 };
+enum Mode : int { MODE_PW = 0, MODE_S1 = 1, MODE_S2 = 2, MODE_BL = 3, MODE_S1R = 4, MODE_PWR = 5, MODE_N = 6, MODE_S1F = 7, MODE_BR = 8, MODE_BRF = 9, MODE_S1Q = 10 };
 
 template <int MODE>
 struct ModeCfg {
     static constexpr int S = MODE == MODE_S2 ? 2 : 1;                              // conv stride
-    static constexpr int PITCH = (MODE == MODE_PW || MODE == MODE_PWR || MODE == MODE_N) ? 32 : (MODE == MODE_S2 ? 80 : (MODE == MODE_S1F ? 36 : (MODE == MODE_BRF ? 34 : 48)));  // halo row pitch (pixels)
+    static constexpr int PITCH = (MODE == MODE_PW || MODE == MODE_PWR || MODE == MODE_N) ? 32 : (MODE == MODE_S2 ? 80 : (MODE == MODE_S1F ? 36 : (MODE == MODE_BRF ? 34 : (MODE == MODE_S1Q ? 40 : 48))));  // halo row pitch (pixels)
 };
 
 template <int TH, int BN, int WM, int WN>
@@ -358,7 +363,8 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
     constexpr bool PW = MODE == MODE_PW || MODE == MODE_PWR;
     constexpr bool BL = MODE == MODE_BL;
     constexpr bool RW = MODE == MODE_S1R || MODE == MODE_PWR;  // weights: global -> registers (no weight tiles in LDS)
-    constexpr bool FL = MODE == MODE_S1F || MODE == MODE_BRF;  // flat halo tile (pitch 36 | 34), two 4-wave workgroups per CU
+    constexpr bool FL = MODE == MODE_S1F || MODE == MODE_BRF || MODE == MODE_S1Q;  // flat halo tile (pitch 36 | 34 | 40)
+    constexpr int IPS = MODE == MODE_S1Q ? 4 : 2;  // K items per pipeline step
     constexpr bool BR = MODE == MODE_BR || MODE == MODE_BRF;   // halo tiles computed in the kernel by the scattered phase conv in front (bridge fusion)
     constexpr bool NR = MODE == MODE_N;  // narrow output: fragment = 2 rows x 16 px; a.Hout / a.Wout are the virtual [H/2][32]
     constexpr int RPF = NR ? 2 : 1;      // output rows per pixel fragment
@@ -434,16 +440,16 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
     const int nhb = pw ? 4 : (nchunks > 1 ? 2 : 1);   // halo ring size (chunk c lives in buffer c & (nhb-1))
     const int nhb_mask = nhb - 1;
     const int nreal = nchunks * ntaps;                // flattened K items; a pipeline step covers two of them
-    const int nitems = nreal + (nreal & 1);           // + one all-zero weight slab: every step holds two items
-    const int nsteps = nitems >> 1;                   // (the packer pads an odd item count with an all-zero slab, so
-                                                      // the K loop has no conditional tail)
+    const int nitems_packed = nreal + (nreal & 1);    // + one all-zero weight slab: the packer pads an odd item count
+    const int nitems = (nreal + IPS - 1) / IPS * IPS; // every step holds IPS items: the K loop has no conditional tail (IPS = 4:
+    const int nsteps = nitems / IPS;                  // items past the packed count read zeros through the descriptor's bounds)
     const int cout_b = a.cout_b;
     const int cin0 = a.phase ? 0 : g * a.cin_b;  // (sub-pixel phase conv: the four phases read the same channels)
     const bool shift_pad = a.phase == 1 || a.phase == 2;  // (phase 3, bilinear phases: one symmetric support for all four)
     const int pad_y = a.pad - (shift_pad ? (g >> 1) : 0), pad_x = a.pad - (shift_pad ? (g & 1) : 0);
     const int c0_used = a.c0_used;
     constexpr int WITEM = BN * REC;   // one item's weight slab tile
-    constexpr int WBUF = 2 * WITEM;   // one step's weights
+    constexpr int WBUF = IPS * WITEM; // one step's weights
     const int ldsW_off = nhb * halo_buf;
     constexpr int IPR = FL ? 1 : PITCH / 16;  // halo DMA instructions per halo row (16 pixel records of 64 B each)
     static_assert(FL || PITCH % 16 == 0, "a halo row must be a whole number of DMA instructions");
@@ -476,22 +482,24 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
     // computed once (the loop is instruction-issue bound): item selector, LDS destination, per-lane source offset
     // (rows past cout_b read row 0 -- their outputs are never stored).
     const unsigned w_dma_lane = (unsigned) ((lane >> 2) * REC + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));
-    bool w_k[C::W_INSTR_WAVE];
-    int w_m0[C::W_INSTR_WAVE];
-    unsigned w_voff[C::W_INSTR_WAVE];
+    constexpr int W_IW = IPS * C::W_INSTR_ITEM / C::NWAVES;  // weight DMA instructions per wave per step
+    static_assert((IPS * C::W_INSTR_ITEM) % C::NWAVES == 0, "weight DMA must divide evenly over the waves");
+    int w_k[W_IW];
+    int w_m0[W_IW];
+    unsigned w_voff[W_IW];
 #pragma unroll
-    for (int it = 0; it < C::W_INSTR_WAVE; ++it) {
+    for (int it = 0; it < W_IW; ++it) {
         const int q = wave + it * C::NWAVES;
         const int k = q / C::W_INSTR_ITEM, qi = q % C::W_INSTR_ITEM;
-        w_k[it] = k != 0;
+        w_k[it] = k;
         w_m0[it] = ldsW_off + k * WITEM + (qi << 10);
         w_voff[it] = (n0 + qi * 16 + (lane >> 2) < cout_b) ? (unsigned) (qi << 10) + w_dma_lane
                                                            : (w_dma_lane & 63u);
     }
     const unsigned item_bytes = (unsigned) cout_b * REC;
-    const rsrc_t rsw = make_rsrc(a.weights, (unsigned) ((size_t) a.bundles * nitems * cout_b * REC));
+    const rsrc_t rsw = make_rsrc(a.weights, (unsigned) ((size_t) a.bundles * nitems_packed * cout_b * REC));
     // byte offset of the slab of the first item of the NEXT step to be staged (steps are staged in order, two items each)
-    unsigned wsoff = (unsigned) (((size_t) g * nitems * cout_b + n0) * REC);
+    unsigned wsoff = (unsigned) (((size_t) g * nitems_packed * cout_b + n0) * REC);
 
     // 1x1 fast path of the activation-tile DMA: single full-resolution source -> per-lane offsets are loop constants
     constexpr int A_INSTR_WAVE = PW ? (TH * 2 + C::NWAVES - 1) / C::NWAVES : 1;
@@ -510,7 +518,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
     // r % 36): lane -> (record, 16-byte slot), the slot holds channel part slot ^ ((column >> 2) & 3) -- the same column-only
     // swizzle the fragment reads undo.  Per-lane byte offsets within the image are loop constants of the tile (one register per
     // instruction of this wave); image + channel chunk travel in the scalar offset.  Single source, no resize.
-    constexpr int FQ = FL ? (((8 - 1 + 5) * 36 * 4 + 63) / 64 + C::NWAVES - 1) / C::NWAVES : 1;
+    constexpr int FQ = FL ? (((TH - 1 + (MODE == MODE_S1Q ? 7 : 5)) * PITCH * 4 + 63) / 64 + C::NWAVES - 1) / C::NWAVES : 1;
     unsigned f_voff[FQ];
     unsigned f_soff = 0;
     if constexpr (FL && !BR) {
@@ -588,10 +596,9 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
     // stages the (two) weight slabs of the next step in order into weight buffer BUF
 #define W_DMA(BUF)                                                                                             \
     if constexpr (!RW) {                                                                                       \
-        const unsigned s0_ = wsoff, s1_ = wsoff + item_bytes;                                                  \
-        _Pragma("unroll") for (int it = 0; it < C::W_INSTR_WAVE; ++it)                                         \
-            bdma16(rsw, w_voff[it], w_k[it] ? s1_ : s0_, smem + w_m0[it] + (BUF) * WBUF);                      \
-        wsoff += 2 * item_bytes;                                                                               \
+        _Pragma("unroll") for (int it = 0; it < W_IW; ++it)                                                    \
+            bdma16(rsw, w_voff[it], wsoff + (unsigned) w_k[it] * item_bytes, smem + w_m0[it] + (BUF) * WBUF);  \
+        wsoff += IPS * item_bytes;                                                                             \
     }
 
     // ---- accumulators
@@ -656,7 +663,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
     // ST1+1 and the halo tiles that step ST1+1 (1x1) / the next chunk (KxK) will need
 #define ISSUE_AT_TRANSITION(IA, ST1, CHUNK_CHANGED)                                                            \
     {                                                                                                          \
-        const int idx2_ = 2 * (ST1) + 2; /* first item of step ST1+1 */                                        \
+        const int idx2_ = IPS * (ST1) + IPS; /* first item of step ST1+1 */                                    \
         if (idx2_ < nitems) {                                                                                  \
             if (pw_fast) {                                                                                     \
                 if (idx2_ < nreal) CPN_EXP_H(PW_HALO_DMA(idx2_));                                              \
@@ -996,6 +1003,49 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
     unsigned wa = (unsigned) ldsW_off + w_lane;
     LOAD_GROUP(wA, pA, pa, wa);
 
+    if constexpr (IPS == 4) {
+    // ---- MODE_S1Q: four items per step -- the two-item body below with two more (item, k-half) group pairs in front of the
+    // boundary; the fragment sets still alternate A / B and the boundary still sits between the loads and the MFMAs of the LAST group
+    // (ONE running item state: four live ItemStates next to the kernel's other scalars cost 151 SGPR spills)
+    ItemState cur = i0;
+#define QSTEP_NEXT() { cur = next_item(cur, KH, KW); pa = ITEM_PADDR(cur.c, cur.ky, cur.kx); wa += WITEM; }
+#define QSTEP_HEAD()                                                                                           \
+        LOAD_GROUP(wB, pB, pa ^ 32u, wa ^ 32u);      /* item 0, k-half 1 */                                     \
+        MMA_GROUP(wA, pA, NF);                        /* item 0, k-half 0 */                                     \
+        QSTEP_NEXT();                                                                                           \
+        LOAD_GROUP(wA, pA, pa, wa);                   /* item 1, k-half 0 */                                     \
+        MMA_GROUP(wB, pB, NF);                        /* item 0, k-half 1 */                                     \
+        LOAD_GROUP(wB, pB, pa ^ 32u, wa ^ 32u);      /* item 1, k-half 1 */                                     \
+        MMA_GROUP(wA, pA, NF);                        /* item 1, k-half 0 */                                     \
+        QSTEP_NEXT();                                                                                           \
+        LOAD_GROUP(wA, pA, pa, wa);                   /* item 2, k-half 0 */                                     \
+        MMA_GROUP(wB, pB, NF);                        /* item 1, k-half 1 */                                     \
+        LOAD_GROUP(wB, pB, pa ^ 32u, wa ^ 32u);      /* item 2, k-half 1 */                                     \
+        MMA_GROUP(wA, pA, NF);                        /* item 2, k-half 0 */                                     \
+        QSTEP_NEXT();                                                                                           \
+        LOAD_GROUP(wA, pA, pa, wa);                   /* item 3, k-half 0 */                                     \
+        MMA_GROUP(wB, pB, NF);                        /* item 2, k-half 1 */                                     \
+        LOAD_GROUP(wB, pB, pa ^ 32u, wa ^ 32u);      /* item 3, k-half 1 */                                     \
+        MMA_GROUP(wA, pA, NF);                        /* item 3, k-half 0 */
+    int c_first = 0;                                  // chunk of the current step's first item
+    for (int st = 0; st + 1 < nsteps; ++st) {
+        QSTEP_HEAD();
+        cur = next_item(cur, KH, KW);                 // first item of step st+1
+        wait_all<WN, WM>(wB, pB);                     // my DMA for step st+1 landed, all my LDS reads of step st returned
+        __builtin_amdgcn_s_barrier();
+        ISSUE_AT_TRANSITION(cur, st + 1, cur.c != c_first);
+        c_first = cur.c;
+        pa = ITEM_PADDR(cur.c, cur.ky, cur.kx);
+        wa = (unsigned) (ldsW_off + ((st + 1) & 1) * WBUF) + w_lane;
+        LOAD_GROUP(wA, pA, pa, wa);                   // first group of step st+1
+        MMA_GROUP(wB, pB, NF);                        // item 3, k-half 1 (operands already in registers)
+        wait_frags<0, WN, WM>(wA, pA);
+    }
+    QSTEP_HEAD();                                     // last step
+    MMA_GROUP(wB, pB, 0);
+#undef QSTEP_NEXT
+#undef QSTEP_HEAD
+    } else {
     // every step that is followed by another step holds two items: the loop body is branch-free with respect to
     // the accumulators and fragment sets (conditional MFMA groups made hipcc rename/spill accumulators)
     for (int st = 0; st + 1 < nsteps; ++st) {
@@ -1031,6 +1081,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
     LOAD_GROUP(wB, pB, pa ^ 32u, wa ^ 32u);
     MMA_GROUP(wA, pA, NF);
     MMA_GROUP(wB, pB, 0);
+    }
     }
 #endif
 #undef HALO_DMA
@@ -1381,8 +1432,21 @@ static bool flat_ok(const ConvArgs &a) {
     return mode == 2 || blocks >= 1024;
 }
 
+// MODE_S1Q: single-source stride-1 5x5 / 7x7 convs into exactly 64 output channels (the refinement ReadOut head of the UNet models
+// and the 64-channel fused heads in general) on the <16,64,2,2> tile; CPN_S1Q=0 (read per call): the two-item loop -- kernel A/B
+static bool quad_ok(const ConvArgs &a) {
+    if (CPN_FP8) return false;
+    const char *e = getenv("CPN_S1Q");
+    if (e && atoi(e) == 0) return false;
+    return a.stride == 1 && a.KH == a.KW && (a.KH == 5 || a.KH == 7) && !a.src1 && !a.up0 && !a.up1 && a.region == 0 && !a.narrow &&
+           a.phase == 0 && a.bundles == 1 && a.cout_b == 64 && a.Hout >= 16 &&
+           (a.out_mode == OUT_BF16_NHWC || a.out_mode == OUT_FUSED_HEAD) &&
+           (long) ((a.Wout + TW - 1) / TW) * ((a.Hout + 15) / 16) * a.N >= 448;
+}
+
 static int conv_mode(const ConvArgs &a) {
     if (a.pre_src) return MODE_BR;
+    if (quad_ok(a)) return MODE_S1Q;
     if (a.narrow) return MODE_N;
     if (flat_ok(a)) return MODE_S1F;
     if (a.KH == 1 && a.KW == 1 && a.pad == 0) {  // incl. strided 1x1: the tile gathers only its outputs
@@ -1411,6 +1475,8 @@ static size_t lds_bytes(const ConvArgs &a, int TH, int BN) {
             return 2 * (size_t) (((TH - 1 + 3) * 34 * 4 + 63) / 64) * 1024 + 2 * 2 * (size_t) BN * REC + pin;
         return 2 * (size_t) (((TH - 1 + 3) * 48 * 4 + 63) / 64) * 1024 + 2 * 2 * (size_t) BN * REC + 2 * 3 * 256 + pin;
     }
+    if (mode == MODE_S1Q)  // flat pitch-40 halo tiles (two chunks in flight), four items x two buffers of slabs, no column table
+        return (a.cin_b / 32 > 1 ? 2 : 1) * (size_t) (((TH - 1 + a.KH) * 40 * 4 + 63) / 64) * 1024 + 2 * 4 * (size_t) BN * REC;
     if (mode == MODE_S1F) {  // flat pitch-36 halo tiles, no column table
         const size_t halo_buf = (size_t) (((TH - 1 + a.KH) * 36 * 4 + 63) / 64) * 1024;
         return (a.cin_b / 32 > 1 ? 2 : 1) * halo_buf + 2 * 2 * (size_t) BN * REC;
@@ -1448,8 +1514,8 @@ static int launch_mode(const ConvArgs &a, hipStream_t stream) {
     const int tiles_x = (a.Wout + TW - 1) / TW, tiles_y = (a.Hout + TH - 1) / TH;
     const int ntiles = a.region == 2 ? frame_tiles(a.Hout, a.Wout, a.region_margin, TH, TW, frame_kw(a)).total : tiles_x * tiles_y;
     dim3 grid((unsigned) (ntiles * a.N), (unsigned) ((a.cout_b + BN - 1) / BN), (unsigned) a.bundles);
-    if constexpr (MODE == MODE_S1F || MODE == MODE_BRF) {  // cout blocks folded into x (see the kernel's block coordinates)
-        if (lds > LDS_MAX / 2) return (int) hipErrorInvalidValue;  // (two workgroups per CU is the point of the mode)
+    if constexpr (MODE == MODE_S1F || MODE == MODE_BRF || MODE == MODE_S1Q) {  // cout blocks folded into x (see the kernel's block coordinates)
+        if (MODE != MODE_S1Q && lds > LDS_MAX / 2) return (int) hipErrorInvalidValue;  // (two workgroups per CU is the point of those modes)
         grid = dim3((unsigned) (((ntiles * a.N + 7) / 8) * 8 * ((a.cout_b + BN - 1) / BN)), 1u, (unsigned) a.bundles);
     }
     hipLaunchKernelGGL(kern, grid, dim3(C::THREADS), lds, stream, a);
@@ -1536,6 +1602,10 @@ int launch_conv(const ConvArgs &a_in, hipStream_t stream) {
         return launch_mode<16, 64, 2, 2, MODE_BR>(a, stream);
     }
     if (conv_mode(a) == MODE_S1F) return launch_mode<8, 128, 4, 2, MODE_S1F>(a, stream);
+    if (conv_mode(a) == MODE_S1Q) {
+        if (lds_bytes(a, 16, 64) > LDS_MAX) return (int) hipErrorInvalidValue;
+        return launch_mode<16, 64, 2, 2, MODE_S1Q>(a, stream);
+    }
 #else
     if (a.pre_src) return (int) hipErrorInvalidValue;
 #endif

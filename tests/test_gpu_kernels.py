@@ -262,6 +262,32 @@ def test_conv_two_workgroups_per_cu_mode(dev, name, monkeypatch):
     assert (got - ref).abs().max().item() < 5e-2 * scale
 
 
+S1Q_CASES = {
+    # MODE_S1Q (four K items per pipeline step, flat pitch-40 halo tiles) on the 64-output-channel 5x5 / 7x7 convs
+    's1q_7x7_64_64': dict(n=4, h=256, w=256, cin=64, cout=64, k=7, seed=41),                      # 98 items -> 100 (two read zeros)
+    's1q_7x7_fused_head': dict(n=4, h=256, w=256, cin=64, cout=64, k=7, fuse_cout=2, fuse_act='tanh_scaled', seed=42),
+    's1q_7x7_one_chunk': dict(n=8, h=128, w=160, cin=32, cout=64, k=7, seed=43),                   # 49 items -> 52 (three read zeros)
+    's1q_5x5_three_chunks_ragged': dict(n=6, h=120, w=176, cin=96, cout=64, k=5, seed=44),         # 75 items, partial tiles
+    's1q_7x7_res': dict(n=4, h=128, w=256, cin=64, cout=64, k=7, res=True, seed=45),
+}
+
+
+@pytest.mark.parametrize('name', list(S1Q_CASES))
+def test_conv_four_items_per_step_mode(dev, name, monkeypatch):
+    """MODE_S1Q against the two-items-per-step loop (CPN_S1Q=0): same K order and MFMA sequence per output element -> bit-identical;
+    and within the usual tolerance of the fp32 conv."""
+    cfg = S1Q_CASES[name]
+    monkeypatch.setenv('CPN_S1Q', '0')
+    base, ref, _ = run_conv(dev, **cfg)
+    monkeypatch.setenv('CPN_S1Q', '1')
+    got, _, _ = run_conv(dev, **cfg)
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, base), f'{name}: MODE_S1Q differs from the two-item loop (max abs {(got - base).abs().max().item():.3e}, ' \
+                                   f'{(got != base).float().mean().item():.2e} of the outputs)'
+    scale = max(ref.abs().max().item(), 1.)
+    assert (got - ref).abs().max().item() < 5e-2 * scale
+
+
 SUBPIXEL_CASES = {
     'sp_64_128_64': dict(n=2, h=32, w=32, c0=64, c1=128, cout=64),
     'sp_padded_channels': dict(n=1, h=64, w=64, c0=8, c1=16, cout=16),
