@@ -293,7 +293,7 @@ class _Engine:
         if _timed is None and _absmax is None and nb == n and self.precision != 'fp32':
             # kernel-selection switches that are read per launch are frozen into a captured graph: part of the key
             env = tuple(os.environ.get(k) for k in ('CPN_RW', 'CPN_PWR', 'CPN_PAIR_CPS', 'CPN_TH64', 'CPN_BLPHASE', 'CPN_PAIR',
-                                                      'CPN_S1F', 'CPN_BRF', 'CPN_S1Q'))
+                                                      'CPN_S1F', 'CPN_BRF', 'CPN_S1Q', 'CPN_BRIDGE'))
             slot = self._graph_slot((n, x.shape[1], h, w, dt, order_total, bool(refinement), env), x, dt, order_total,
                                     refinement, gated)
         if slot is not None and 'graph' in slot:
