@@ -57,7 +57,8 @@ class Plan:
         c0) / ('lateral', c0) = its decomposition (they share the head's state-dict entries and add none); ``dst``: write
         into an existing tensor (the lateral op writes the head's destination).  ``share`` = (first, last input channel of
         the conv stated by the keys ``w`` / ``bn``, with_bias): the op applies only that channel range of a conv whose state-dict
-        entries the caller registers itself (``_head_input``: Fuse2d over three features as two partial 1x1 convs)."""
+        entries the caller registers itself (``_head_input``: Fuse2d over three and more features as partial 1x1 convs); a
+        fourth element c = the first source is the running sum of the parts so far (c channels, identity weights)."""
         pad = k // 2 if pad is None else pad
         t0 = self.tensors[src0]
         if up0 == 'bilinear':  # source read through a bilinear resize to the input size (nominal down factor 1)
@@ -535,22 +536,36 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
         (t0, ch0) = level[keys[0]]
         if len(keys) == 1:
             return t0, ch0
-        if len(keys) > 3:
-            raise NotImplementedError('Fuse2d over more than three features is not supported on the HIP path')
-        (t1, ch1) = level[keys[1]]
+        ts = [level[k] for k in keys]
+        (t1, ch1) = ts[1]
         w_, bn_ = fuse_prefix + 'block.0.', fuse_prefix + 'block.1.'
         if len(keys) == 2:
             t = P.conv(t0, ch0, 1, w=w_, bn=bn_, bias=True, act='relu', src1=t1, up1=True)
             return t, ch0
         # three features: conv1x1(cat(f0, f1^, f2^)) = conv1x1 over [f0 | f1^] + (conv1x1 over f2)^ -- a 1x1 conv commutes with
         # the nearest resize, so the third feature's share runs at ITS resolution (no bias, BN scale folded) and joins as a
-        # nearest-resized residual in front of bias + ReLU (the conv kernel reads two concat sources and one residual)
-        (t2, ch2) = level[keys[2]]
-        P.conv_keys(w_, ch0, ch0 + ch1 + ch2, 1, True)
+        # nearest-resized residual in front of bias + ReLU (the conv kernel reads two concat sources and one residual).
+        # More features: the sum continues in steps of two -- [running sum | f_i^] (identity block over the running sum, the
+        # share of f_i) + (conv1x1 over f_i+1)^ -- every feature is resized from ITS size to the first one's in one step, as
+        # Fuse2d does (a chain of resizes would pick other pixels at odd sizes); bias + ReLU close the last step
+        off = [0]
+        for (_, c) in ts:
+            off.append(off[-1] + c)
+        P.conv_keys(w_, ch0, off[-1], 1, True)
         P.bn_keys(bn_, ch0)
-        part = P.conv(t2, ch0, 1, w=w_, bn=bn_, bias=True, share=(ch0 + ch1, ch0 + ch1 + ch2, False))
-        t = P.conv(t0, ch0, 1, w=w_, bn=bn_, bias=True, act='relu', src1=t1, up1=True, res=part, res_up=True,
-                   share=(0, ch0 + ch1, True))
+        n = len(ts)
+
+        def part(i):
+            return P.conv(ts[i][0], ch0, 1, w=w_, bn=bn_, bias=True, share=(off[i], off[i + 1], False))
+
+        res = part(2)
+        t = P.conv(t0, ch0, 1, w=w_, bn=bn_, bias=True, act='relu' if n == 3 else 'none', src1=t1, up1=True, res=res,
+                   res_up=True, share=(0, off[2], n == 3))
+        for i in range(3, n, 2):
+            res = part(i + 1) if i + 1 < n else None
+            last = i + 2 >= n
+            t = P.conv(t, ch0, 1, w=w_, bn=bn_, bias=True, act='relu' if last else 'none', src1=ts[i][0], up1=True, res=res,
+                       res_up=res is not None, share=(off[i], off[i + 1], last, ch0))
         return t, ch0
 
     f1s, c1 = _head_input('score', 'core.score_fuse.')
@@ -780,8 +795,11 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=Non
         if isinstance(sub, tuple) and sub[0] == 'lateral':  # the lateral's share of the head conv's weights (+ its bias)
             w = w[:, :sub[1]]
         if op.get('share') is not None:  # a channel range of the stated conv; its (BN-folded) bias travels with ONE of the parts
-            lo, hi, with_bias = op['share']
+            lo, hi, with_bias = op['share'][:3]
             w = w[:, lo:hi]
+            if len(op['share']) > 3:  # [running sum | feature]: identity block in front (Fuse2d over more than three features)
+                eye = torch.eye(cout, op['share'][3], dtype=w.dtype)[:, :, None, None]
+                w = torch.cat((eye, w), 1)
             if not with_bias:
                 b = torch.zeros_like(b)
         phase = isinstance(sub, tuple) and sub[0] in ('phase', 'scatter', 'blphase')

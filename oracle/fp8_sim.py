@@ -113,11 +113,11 @@ def _simulate(plan, state_dict, effective_weights, act_scales, x, T, outs, ei, _
                     F.interpolate(t0, x.shape[2:], mode='bilinear', align_corners=False), act_scales[op['src0']])
             else:
                 xin = up(T[op['src0']]) if op['up0'] else T[op['src0']]
-            if op['src1'] is not None:
-                xin = torch.cat((xin, up(T[op['src1']]) if op['up1'] else T[op['src1']]), 1)
+            if op['src1'] is not None:  # (a resized second source / residual takes the first source's / the output's size)
+                xin = torch.cat((xin, F.interpolate(T[op['src1']], xin.shape[2:]) if op['up1'] else T[op['src1']]), 1)
             y = F.conv2d(xin.double(), e['w'], e['b'], op['stride'], op['pad'], 1, op['groups']).float()
             if op['res'] is not None:
-                y = y + (up(T[op['res']]) if op['res_up'] else T[op['res']])
+                y = y + (F.interpolate(T[op['res']], y.shape[2:]) if op['res_up'] else T[op['res']])
             y = _act(y, op['act'], op['act_scale'])
             if op['dst'] is not None:
                 T[op['dst']] = _q(y, act_scales[op['dst']])

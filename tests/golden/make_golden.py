@@ -100,6 +100,13 @@ MODEL_SPECS = {
                                                     refinement_features=['0', '1', '2'], backbone_kwargs={
                                                         'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}),
                              (1, 3, 64, 96)),
+    # Fuse2d over FOUR / FIVE features, finer and coarser than the first one (the HIP plan continues the sum in steps of two)
+    'CpnResNet18FPN_fuse5': ('CpnResNet18FPN', dict(in_channels=3, score_features=['1', '2', '3', '0'],
+                                                    contour_features=['1', '0', '2', '3', '2'],
+                                                    location_features=['1', '3', '0', '2'],
+                                                    refinement_features=['0', '1', '2', '3'], backbone_kwargs={
+                                                        'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}),
+                             (1, 3, 75, 101)),
     # head strides 4 / 8 (the HIP plan: k x k conv at stride 2 + the 1x1 conv at stride s / 2)
     'CpnU22_stride4': ('CpnU22', dict(in_channels=3, contour_head_stride=4, refinement_head_stride=8,
                                       backbone_kwargs={'backbone_kwargs': {'base_channels': 8}}), (2, 3, 128, 160)),
@@ -273,7 +280,8 @@ MODEL_CALIBRATION = {'CpnU22_classes4': dict(score_shift=-3.5),
                      'CpnU22_stride4': dict(score_shift=1.2, fourier_std=.07, location_std=.3, refinement_raw_std=.3),
                      'CpnU22_headact': _U22_SMALL, 'CpnResNet18FPN_headact': _FPN_DENSE,
                      'CpnResNet18FPN_fuse': dict(score_shift=-.5, fourier_std=.4, location_std=.4),
-                     'CpnResNet18FPN_fuse3': dict(score_shift=.5, fourier_std=.4, location_std=.4, refinement_raw_std=.3)}
+                     'CpnResNet18FPN_fuse3': dict(score_shift=.5, fourier_std=.4, location_std=.4, refinement_raw_std=.3),
+                     'CpnResNet18FPN_fuse5': dict(score_shift=.5, fourier_std=.4, location_std=.4, refinement_raw_std=.3)}
 
 
 def gen_model(name, seed=0):

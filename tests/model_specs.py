@@ -71,6 +71,12 @@ HEAD_SPECS = {
         backbone_kwargs={'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}), cpn_kwargs=dict(_DEF),
         core_kwargs=dict(features=dict(score=['1', '2', '3'], contour=['1', '2', '3'], location=['1', '3', '2'],
                                        refinement=['0', '1', '2']))),
+    'CpnResNet18FPN_fuse5': dict(cls='CpnResNet18FPN', kwargs=dict(
+        in_channels=3, score_features=['1', '2', '3', '0'], contour_features=['1', '0', '2', '3', '2'],
+        location_features=['1', '3', '0', '2'], refinement_features=['0', '1', '2', '3'],
+        backbone_kwargs={'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}), cpn_kwargs=dict(_DEF),
+        core_kwargs=dict(features=dict(score=['1', '2', '3', '0'], contour=['1', '0', '2', '3', '2'],
+                                       location=['1', '3', '0', '2'], refinement=['0', '1', '2', '3']))),
     'CpnU22_stride4': dict(cls='CpnU22', kwargs=dict(in_channels=3, contour_head_stride=4, refinement_head_stride=8,
                                                      backbone_kwargs=_U8), cpn_kwargs=dict(_DEF),
                            core_kwargs=dict(contour_head_stride=4, refinement_head_stride=8)),

@@ -586,7 +586,8 @@ def test_full_size_properties(dev):
     assert abs(n_ref - len(got8['scores'][0])) <= 0.2 * n_ref and rate8 > .8  # measured 0.897
 
 
-@pytest.mark.parametrize('name', ['CpnU22', 'CpnU22_wide', 'CpnResNeXt101UNet', 'CpnResNet18FPN', 'CpnResNet50FPN', 'CpnU22_headact'])
+@pytest.mark.parametrize('name', ['CpnU22', 'CpnU22_wide', 'CpnResNeXt101UNet', 'CpnResNet18FPN', 'CpnResNet50FPN', 'CpnU22_headact',
+                                  'CpnResNet18FPN_fuse5'])
 def test_fp8_precision_vs_reference_maps(dev, name):
     """fp8 (e4m3 activations + weights, K=64 scaled MFMA) conv stack against the reference's fp32 head maps: e4m3 has a
     3-bit mantissa (2^-4 relative rounding per value), so the check is a relative L2 bound per head map plus an
@@ -611,7 +612,9 @@ def test_fp8_precision_vs_reference_maps(dev, name):
     y = model(x, nms=False)
     rates = [_iou_match_rate(y['boxes'][i].cpu().numpy(), g[f'nonms.boxes.{i}']) for i in range(x.shape[0])]
     print(name, 'fp8 proposal IoU>0.5 match rates', rates)
-    assert min(rates) > .8, rates  # measured 0.89 .. 0.99
+    # measured 0.89 .. 0.99; the fused-feature toy model: 0.74 (its two-feature sibling 0.65, Fuse2d over three 0.87 -- the CPU
+    # simulation below shows the same error level map by map, so it is e4m3 on this model, not the split of the fusion conv)
+    assert min(rates) > (.65 if name.endswith('_fuse5') else .8), rates
     # the same fp8 algorithm restated on the CPU (oracle/fp8_sim.py: identical codes, scales and weights).  A deep
     # quantised graph is chaotic -- one e4m3 rounding that differs because of the fp32 summation order shifts ~1
     # rounding decision in the next layer, so after 30..120 layers the two noise realisations are decorrelated
