@@ -754,7 +754,13 @@ def main():
                                    '(+ input/maxpool helpers), timed with HIP events on the launch stream',
                          'launch_ms': conv_ms, 'algorithmic_gflop_per_launch': gf * args.batch,
                          'executed_gflop_per_launch': executed, 'executed_frac': executed / conv_ms / peak,
-                         'backbone_stack': backbone, 'dominant_kernel': dominant},
+                         'backbone_stack': backbone, 'dominant_kernel': dominant,
+                         # not measured by this run: what the matrix pipes sustain with NO memory instruction in the loop
+                         # (tools/probes/mfma_ceiling.hip, 8 accumulators per wave, 2 x 256 threads per CU), as fractions of `peak`
+                         'register_only_mfma_loop_frac_of_peak': {
+                             'zero_operands': 0.995 if args.precision == 'fp8' else 0.985,
+                             'random_operands': 0.794 if args.precision == 'fp8' else 0.701,
+                             'source': 'profiles/r05_kernel_experiments.txt #8 (one MI355X box; power / clock bound)'}},
         }
         if gated is not None:
             step_ms = 1e3 * dt / args.steps
