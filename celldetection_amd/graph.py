@@ -14,6 +14,8 @@ Reference structures mirrored (file:line relative to the reference repository):
 """
 import math
 
+import os
+
 import torch
 
 from . import _lib
@@ -152,6 +154,29 @@ class Plan:
         dst = self.tensor(in_channels, 1)
         self.ops.append(dict(op='input', dst=dst, in_channels=in_channels))
         return dst
+
+    def hoist(self, begin, end):
+        """Moves ops [begin, end) to the earliest position at which every tensor they read from outside the block has been written
+        (execution order only: tensors, state-dict entries and results are untouched; the arena planner follows the new
+        lifetimes).  Returns the number of positions the block moved up."""
+        block = self.ops[begin:end]
+        written = {o['dst'] for o in block if o.get('dst') is not None}
+        reads = {o[k] for o in block for k in ('src0', 'src1', 'res') if o.get(k) is not None} - written
+        ready = 0  # first position behind the last producer of a tensor the block reads
+        for i, o in enumerate(self.ops[:begin]):
+            if o.get('dst') in reads:
+                ready = i + 1
+        # (members of a sub-pixel triple / alternatives / fused pairs that restate the ops in front of them stay together)
+        while ready < begin and (self.ops[ready].get('op') in ('conv_pair', 'conv_bridge') or self.ops[ready].get('alt') == 2 or
+                                 isinstance(self.ops[ready].get('sub'), tuple)):
+            ready += 1
+        if ready >= begin:
+            return 0
+        self.ops[ready:end] = block + self.ops[ready:begin]
+        for i, o in enumerate(self.ops):
+            if o['op'] in ('conv_pair', 'conv_bridge'):
+                o['first'] = i - 2
+        return begin - ready
 
     def stem_fast_path(self, conv_index):
         """Marks the plan's input op + the conv op ``conv_index`` (a 7x7 stride-2 pad-3 stem conv on the input tensor,
@@ -456,7 +481,7 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
                contour_head_channels: int = None, refinement_head_channels: int = None,
                kernel_sizes: dict = None, fuse_bilinear: bool = True, contour_head_stride: int = 1,
                refinement_head_stride: int = 1, features: dict = None, sparse_heads: bool = False,
-               subpixel: bool = False, stem_fast: bool = False, fuse_blocks: bool = False,
+               subpixel: bool = False, stem_fast: bool = False, fuse_blocks: bool = False, hoist_heads: bool = True,
                bilinear_phases: bool = False, head_activations: dict = None) -> Plan:
     """Plan of ``Cpn<backbone>`` (celldetection/models/cpn.py:287-439,771-2061; heads: CPNCore.__init__
     cpn.py:125-236).  ``kernel_sizes``: optional {'score'|'location'|'fourier'|'uncertainty'|'refinement': k}
@@ -568,6 +593,7 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
                        res_up=res is not None, share=(off[i], off[i + 1], last, ch0))
         return t, ch0
 
+    heads_begin = len(P.ops)
     f1s, c1 = _head_input('score', 'core.score_fuse.')
     scale = P.tensors[f1s]['down'] * contour_head_stride
     cm1 = None if contour_head_channels is None else int(contour_head_channels)
@@ -594,6 +620,7 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
         fu, cu = _head_input('uncertainty', 'core.uncertainty_fuse.')
         _readout(P, fu, cm1 or cu, 4, 'core.uncertainty_head.', 'sigmoid', 0., _lib.OUT_UNCERTAINTY,
                  k=ks.get('uncertainty', 7), fuse=fuse_readout, stride=hs, hidden=ha['uncertainty'])
+    heads_end = len(P.ops)
     if refinement:
         r, c0 = _head_input('refinement', 'core.refinement_fuse.')
         cm0 = cm0 or c0
@@ -617,6 +644,10 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
                  hidden=ha['refinement'])
         if r_low is not None and any(op.get('sub') == 'blhead' for op in P.ops[-3:]):
             resize_op['ring_for_bl'] = True  # (the executor writes only the frame's neighbourhood of that map when the phases run)
+    if hoist_heads and os.environ.get('CPN_HOIST', '1') != '0':  # the score / location / Fourier (/ uncertainty) heads run as soon as their features exist
+        shift = P.hoist(heads_begin, heads_end)
+        if sparse_meta is not None:
+            sparse_meta['ops'] = tuple(i - shift for i in sparse_meta['ops'])
     P.meta = dict(backbone=backbone, order=order, head_down=scale, refinement=refinement, in_channels=in_channels,
                   score_channels=score_channels, refinement_buckets=refinement_buckets,
                   uncertainty_head=bool(uncertainty_head), sparse_heads=sparse_meta)
