@@ -13,7 +13,6 @@ Reference structures mirrored (file:line relative to the reference repository):
   ReadOut heads / CPNCore     celldetection/models/commons.py:461-511, celldetection/models/cpn.py:126-283
 """
 import math
-
 import os
 
 import torch
@@ -644,7 +643,8 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
                  hidden=ha['refinement'])
         if r_low is not None and any(op.get('sub') == 'blhead' for op in P.ops[-3:]):
             resize_op['ring_for_bl'] = True  # (the executor writes only the frame's neighbourhood of that map when the phases run)
-    if hoist_heads and os.environ.get('CPN_HOIST', '1') != '0':  # the score / location / Fourier (/ uncertainty) heads run as soon as their features exist
+    # the score / location / Fourier (/ uncertainty) heads run as soon as their features exist (CPN_HOIST=0: the reference's order)
+    if hoist_heads and os.environ.get('CPN_HOIST', '1') != '0':
         shift = P.hoist(heads_begin, heads_end)
         if sparse_meta is not None:
             sparse_meta['ops'] = tuple(i - shift for i in sparse_meta['ops'])
