@@ -500,6 +500,9 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
     its dedicated kernel on a padded 4-channel input layout (``Plan.stem_fast_path``).
     ``fuse_blocks`` (bf16 plans, ResNeXt encoders): every bottleneck block additionally carries conv1 -> grouped conv2 as
     one fused op (``Plan.conv_pair``).
+    ``hoist_heads``: the score / location / Fourier / uncertainty head ops are placed right behind the op that completes their
+    input feature (``Plan.hoist``) instead of behind the whole backbone (CPNCore.forward, cpn.py:238-283, runs the backbone
+    first): same ops, same results, the heads of the UNet models no longer wait for decoder level 0.
     ``bilinear_phases`` (bf16 / fp8 plans): the refinement head over the bilinear-resized feature map (FPN models) additionally
     carries its sub-pixel decomposition (``_readout``).  ``head_activations``: optional {'score'|'location'|'fourier'|
     'uncertainty'|'refinement': plan activation name} = the reference's ``head_activation`` / ``head_activation_<head>`` kwargs
