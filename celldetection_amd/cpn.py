@@ -501,6 +501,12 @@ class CPN(nn.Module):
         if self._engine is None or self._engine.device != device or self._engine.precision != self.precision or \
                 self._engine.sparse_requested != sparse:
             if self.precision == 'fp8':
+                if self._fp8_scales is not None and getattr(self, '_fp8_scales_key', None) != self._fp8_plan_key():
+                    # the scales are indexed by the tensor ids of the plan they were calibrated with; `subpixel` changes that plan
+                    # (one more tensor per decoder level): scales of another plan must never be applied silently
+                    warnings.warn("precision 'fp8': `subpixel` changed after calibrate_fp8(); the activation scales belong to "
+                                  'another plan and are dropped', RuntimeWarning, stacklevel=3)
+                    self._fp8_scales = None
                 if self._fp8_scales is None:
                     if calibration_input is None:
                         raise RuntimeError("precision 'fp8' needs activation scales: call calibrate_fp8(batch) first")
@@ -531,6 +537,7 @@ class CPN(nn.Module):
         eng = _Engine(plan, self.state_dict(), inputs.device, 'bf16')
         absmax = eng.activation_absmax(inputs, self.core.order, self.refinement)
         self._fp8_scales = [max(float(v), 1e-12) / 448. for v in absmax.tolist()]
+        self._fp8_scales_key = self._fp8_plan_key()
         for op in plan.ops:  # max-pool / bilinear kernels work on the codes: output scale == input scale
             if op['op'] in ('maxpool', 'bilinear'):
                 self._fp8_scales[op['dst']] = self._fp8_scales[op['src0']]
@@ -539,6 +546,10 @@ class CPN(nn.Module):
         if self._engine is not None and self._engine.precision == 'fp8':
             self._engine = None
         return self._fp8_scales
+
+    def _fp8_plan_key(self):
+        """What the tensor ids of the fp8 plan (= the indices of ``_fp8_scales``) depend on."""
+        return bool(self.subpixel), len(self.plan_for('fp8').tensors)
 
     def order_weights_device(self):
         return next(self.parameters()).device

@@ -19,6 +19,7 @@ enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_TANH_SCALED = 
 // Softplus beta 1 / threshold 20); the first four keep their own code at the call sites
 __host__ __device__ inline float act_apply(float x, int act) {
     switch (act) {
+        case ACT_RELU: return fmaxf(x, 0.f);
         case ACT_SIGMOID: return 1.f / (1.f + expf(-x));
         case ACT_LEAKY_RELU: return x > 0.f ? x : 0.01f * x;
         case ACT_SILU: return x / (1.f + expf(-x));

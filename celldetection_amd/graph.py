@@ -166,9 +166,17 @@ class Plan:
             if o.get('dst') in reads:
                 ready = i + 1
         # (members of a sub-pixel triple / alternatives / fused pairs that restate the ops in front of them stay together)
-        while ready < begin and (self.ops[ready].get('op') in ('conv_pair', 'conv_bridge') or self.ops[ready].get('alt') == 2 or
-                                 isinstance(self.ops[ready].get('sub'), tuple)):
-            ready += 1
+        moved = True
+        while moved:
+            moved = False
+            while ready < begin and (self.ops[ready].get('op') in ('conv_pair', 'conv_bridge') or self.ops[ready].get('alt') == 2 or
+                                     (isinstance(self.ops[ready].get('sub'), tuple) and self.ops[ready]['sub'][0] != 'scatter')):
+                ready += 1  # (a scatter conv OPENS a unit -- the block may go in front of it)
+            # a fused op + the two convs it restates ([first, first + 1, fused]) are one unit: never insert inside it (the
+            # ResNet18/34-UNets have no inner_blocks.0, so their bridge's scatter conv directly follows the heads' producer)
+            for i, o in enumerate(self.ops[:begin]):
+                if o['op'] in ('conv_pair', 'conv_bridge') and o['first'] < ready <= i:
+                    ready, moved = i + 1, True
         if ready >= begin:
             return 0
         self.ops[ready:end] = block + self.ops[ready:begin]
@@ -786,6 +794,7 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=Non
                 raise ValueError('fused bottleneck heads are a bf16-plan feature')
             c1, c2 = ops[op['first']], ops[op['first'] + 1]
             assert op['first'] == i - 2 and c2.bundles * c2.cout_b == c1.cout_b and c2.cin_b == c2.cout_b
+            assert c1.dst == c2.src0 and op['w'].startswith(plan.ops[op['first']]['w']), 'conv_pair must directly follow its two convs'
             d.op, d.src0, d.dst = _lib.OP_CONV_PAIR, op['src0'], op['dst']
             d.kh = d.kw = 3
             d.stride, d.pad = c2.stride, 1
@@ -799,6 +808,8 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=Non
                 raise ValueError('the fused bridge level is a bf16-plan feature')
             c1, c2 = ops[op['first']], ops[op['first'] + 1]
             assert op['first'] == i - 2 and c1.cout_b == c2.cin_b == c2.cout_b == 64
+            assert c1.subpixel == _lib.SUBPIXEL_SCATTER and c1.dst == c2.src0 and \
+                op['w'].startswith(plan.ops[op['first']]['w']), 'conv_bridge must directly follow its scatter conv + 3x3 conv'
             d.op, d.src0, d.dst, d.res = _lib.OP_CONV_BRIDGE, op['src0'], op['dst'], c2.res
             d.kh = d.kw = 3
             d.stride, d.pad, d.bundles, d.cin_b, d.cout_b, d.c0_used = 1, 1, 1, c1.cin_b, 64, c1.cin_b

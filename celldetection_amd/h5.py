@@ -538,9 +538,9 @@ def _read_dataset(lib, f, key, index=None):
         try:
             shape = _space_shape(lib, space)
             dt = _dtype_of(lib, t)
-            plan = None if index is None else _plan_index(index, shape)
             if index is not None and shape == ():
                 raise ValueError('Illegal slicing argument for scalar dataspace')  # (h5py's message)
+            plan = None if index is None else _plan_index(index, shape)
             if plan is None:
                 arr = np.empty(shape, dt)
                 if arr.size:
@@ -568,17 +568,16 @@ def _read_dataset(lib, f, key, index=None):
     return arr, attrs
 
 
-def from_h5(filename, *keys, file_kwargs=None, driver=None, return_attrs=False, attributes=None, **keys_slices):
+def from_h5(filename, *keys, file_kwargs=None, driver=None, return_attrs=False, **keys_slices):
     """``cd.from_h5`` (util/util.py:1459-1488), same signature and return value: the datasets named in ``keys`` in full and
     those of ``keys_slices`` indexed (``from_h5('file.h5', 'key0', key=slice(0, 42))``: ints, slices and ``...`` become ONE
     hyperslab read, anything else is indexed in memory) -> a single array, or a tuple when more than one was asked for; with
     ``return_attrs=True`` -> ``(res, attrs)``, ``attrs`` = one ``dict(dataset.attrs)`` per returned array.  Without any key
     the available keys are printed and ``()`` is returned, as there.  ``file_kwargs`` / ``driver`` configure h5py's file
     object in the reference; the libhdf5 binding opens with the default (sec2) driver and warns about anything else.
-    ``attributes=`` is the round-2..4 spelling of ``return_attrs`` (kept as an alias)."""
+    (``attributes`` -- this package's round-2..4 spelling with another return layout -- is no keyword any more: as in the
+    reference, it would name a dataset.)"""
     lib = _lib()
-    if attributes is not None:
-        return_attrs = bool(attributes) or return_attrs
     file_kwargs = dict(file_kwargs or {})
     if driver is not None:
         file_kwargs['driver'] = driver

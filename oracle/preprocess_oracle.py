@@ -1,8 +1,11 @@
-"""CPU ORACLE -- TEST INFRASTRUCTURE ONLY: ``normalize_percentile`` (celldetection/data/misc.py:156-161) with numpy.
+"""CPU ORACLE -- TEST INFRASTRUCTURE ONLY: ``normalize_percentile`` (celldetection/data/misc.py:156-161) and the inference
+script's ``preprocess`` (celldetection_scripts/cpn_inference.py:196-222) with numpy.
 
-``np.percentile`` is numpy's own (available here); ``skimage.util.img_as_ubyte`` is third-party and absent from the image
-and from /root/reference -- its float -> uint8 rule (clip(rint(x * 255), 0, 255), computed in float64) is restated:
-unpinned third party."""
+PINNED (round 6): tests/golden/preprocess.npz holds outputs of the reference's own two functions, imported by
+tests/golden/make_golden.py gen_preprocess; tests/test_preprocess.py checks this file against every case, bit for bit.
+Third-party arithmetic inside them -- ``skimage.img_as_ubyte`` (clip(rint(x * 255), 0, 255) in float64), cv2's 8-bit luma,
+albumentations' uint8 tables -- is absent from the image and from /root/reference: restated here and, identically, in the
+stand-ins of oracle/ref_shim.py the import ran through (third party: unpinned).  ``to_uint8=False`` involves numpy only."""
 import numpy as np
 
 
@@ -29,6 +32,8 @@ def preprocess(img, gamma=1., contrast=1., brightness=0., percentile=None, grays
         c = img.shape[-1]
         if c == 1:
             img = img.squeeze(-1)
+        elif c == 2:  # the script averages the two channels -> float64, which cv2.cvtColor(GRAY2RGB) rejects
+            raise TypeError('preprocess(grayscale=True): 2-channel images reach cv2.cvtColor as float64 (unsupported depth)')
         elif c in (3, 4):
             x = img.astype(np.int64)
             img = ((x[..., 0] * 4899 + x[..., 1] * 9617 + x[..., 2] * 1868 + (1 << 13)) >> 14).astype(np.uint8)

@@ -352,6 +352,70 @@ def cv2_drawContours(image, contours, contourIdx, color, thickness=1, lineType=8
     return image
 
 
+# --- third-party stand-ins of the slide preprocessing (celldetection/data/misc.py:156-161, celldetection_scripts/
+# cpn_inference.py:196-222).  Written from the published behaviour of skimage / OpenCV / albumentations 1.x; none of them is in
+# the image, so -- like ``nms_cpu`` and ``cv2_drawContours`` -- their arithmetic is third-party and UNPINNED.  What importing the
+# reference's own ``normalize_percentile`` / ``preprocess`` through them pins is the reference's code around them: the percentile
+# pair, np.percentile's interpolation, the clip / rescale expression, which step runs when and in which order.
+CV2_COLOR_RGB2GRAY, CV2_COLOR_RGBA2GRAY, CV2_COLOR_GRAY2RGB = 7, 11, 8  # (OpenCV's enum values; only compared, never computed on)
+
+
+def skimage_img_as_ubyte(image, force_copy=False):
+    """skimage.util.img_as_ubyte for the float images ``normalize_percentile`` hands it: rint(image * 255) clipped to 0..255,
+    computed in the float type of the input (float64 here)."""
+    image = np.asarray(image)
+    if image.dtype == np.uint8:
+        return image.copy() if force_copy else image
+    if image.dtype.kind != 'f':
+        raise NotImplementedError('stand-in: float (and uint8) images only')
+    if image.size and (image.min() < -1. or image.max() > 1.):
+        raise ValueError('Images of type float must be between -1 and 1.')
+    out = np.multiply(image, 255, dtype=image.dtype if image.dtype.itemsize >= 4 else np.float32)
+    np.rint(out, out=out)
+    np.clip(out, 0, 255, out=out)
+    return out.astype(np.uint8)
+
+
+def cv2_cvtColor(src, code):
+    """cv2.cvtColor for the three 8-bit conversions of the script: OpenCV's fixed-point luma (14 fractional bits) and the
+    channel replication of GRAY2RGB.  Other depths raise, as cv2 does for the float64 array of the script's 2-channel branch."""
+    src = np.asarray(src)
+    if src.dtype != np.uint8:
+        raise TypeError(f'stand-in cv2.cvtColor: unsupported depth {src.dtype} (cv2: "Unsupported depth of input image")')
+    if code in (CV2_COLOR_RGB2GRAY, CV2_COLOR_RGBA2GRAY):
+        assert src.ndim == 3 and src.shape[-1] == (3 if code == CV2_COLOR_RGB2GRAY else 4)
+        x = src.astype(np.int64)
+        return ((x[..., 0] * 4899 + x[..., 1] * 9617 + x[..., 2] * 1868 + (1 << 13)) >> 14).astype(np.uint8)
+    if code == CV2_COLOR_GRAY2RGB:
+        assert src.ndim == 2
+        return np.repeat(src[..., None], 3, -1)
+    raise NotImplementedError(f'stand-in cv2.cvtColor: code {code}')
+
+
+def cv2_LUT(src, lut):
+    return np.asarray(lut)[np.asarray(src)]
+
+
+def alb_gamma_transform(img, gamma):
+    """albumentations.augmentations.functional.gamma_transform (1.x): uint8 -> 256-entry table, floats -> power."""
+    if img.dtype == np.uint8:
+        table = (np.arange(0, 256.0 / 255, 1.0 / 255) ** gamma) * 255
+        return cv2_LUT(img, table.astype(np.uint8))
+    return np.power(img, gamma)
+
+
+def alb_brightness_contrast_adjust(img, alpha=1, beta=0, beta_by_max=False):
+    """albumentations.augmentations.functional.brightness_contrast_adjust (1.x), uint8 branch."""
+    if img.dtype != np.uint8:
+        raise NotImplementedError('stand-in: uint8 images only')
+    lut = np.arange(0, 256).astype('float32')
+    if alpha != 1:
+        lut *= alpha
+    if beta != 0:
+        lut += beta * 255 if beta_by_max else (alpha * beta) * np.mean(img)
+    return cv2_LUT(img, np.clip(lut, 0, 255).astype(np.uint8))
+
+
 _INSTALLED = False
 
 
@@ -413,6 +477,16 @@ def install():
     # cv2: everything a stub except the one call on the label path
     cv = mod('cv2')
     cv.drawContours = cv2_drawContours
+    cv.cvtColor, cv.LUT = cv2_cvtColor, cv2_LUT
+    cv.COLOR_RGB2GRAY, cv.COLOR_RGBA2GRAY, cv.COLOR_GRAY2RGB = CV2_COLOR_RGB2GRAY, CV2_COLOR_RGBA2GRAY, CV2_COLOR_GRAY2RGB
+
+    # skimage / albumentations: the calls of the slide preprocessing
+    sk = mod('skimage')
+    sk.img_as_ubyte = skimage_img_as_ubyte
+    mod('albumentations')
+    mod('albumentations.augmentations')
+    af = mod('albumentations.augmentations.functional')
+    af.gamma_transform, af.brightness_contrast_adjust = alb_gamma_transform, alb_brightness_contrast_adjust
 
     # dispatcher op torch.ops.torchvision.nms
     try:

@@ -14,6 +14,9 @@ Imports the read-only Python reference (celldetection 0.4.9) through ``oracle/re
                    inside it goes through ``ref_shim.cv2_drawContours`` = the restated fill, third-party unpinned):
                    overlapping / nested contours, gap 0 / 3, initial_depth 1 / 2, ioa_thresh None / .3 / .8 with
                    return_indices, sort_by ascending / descending, unrounded and unclipped inputs, ragged lists
+* ``preprocess.npz`` G11: ``cd.data.normalize_percentile`` (data/misc.py:156-161) and the script's ``preprocess``
+                   (cpn_inference.py:196-222), both IMPORTED; skimage / cv2 / albumentations calls inside them go through the
+                   stand-ins of ``ref_shim`` (third-party arithmetic: unpinned); ``to_uint8=False`` involves numpy only
 * ``stitch_dups.npz`` G8b: the stitching rule on synthetic per-tile detections WITH cross-tile duplicates (the global
                    NMS removes > 10 % of what survives the border rule)
 
@@ -497,6 +500,72 @@ def gen_labels():
     save('labels.npz', **out)
 
 
+PREPROCESS_KW = [dict(grayscale=True), dict(gamma=.7), dict(gamma=2.2, grayscale=True), dict(contrast=1.3),
+                 dict(contrast=.8, brightness=.2), dict(contrast=1., brightness=.5), dict(percentile=99.),
+                 dict(percentile=(2., 98.), gamma=1.5), dict(percentile=99., gamma=1.5, contrast=1.2, brightness=-.1, grayscale=True)]
+
+
+def preprocess_images():
+    """name -> channels-last numpy image (the script's layout); seeded, re-creatable, also stored in the fixture."""
+    rng = np.random.default_rng(2025)
+    h, w = 29, 37
+    imgs = {f'u8c{c}': rng.integers(0, 256, (h, w, c) if c else (h, w)).astype(np.uint8) for c in (0, 1, 3, 4)}
+    imgs['u8low'] = rng.integers(0, 40, (h, w, 3)).astype(np.uint8)          # many ties at the percentile positions
+    imgs['u16c3'] = rng.gamma(2., 900., (h, w, 3)).clip(0, 65535).astype(np.uint16)
+    imgs['u16c0'] = rng.gamma(2., 300., (h, w)).clip(0, 65535).astype(np.uint16)
+    imgs['f32c3'] = rng.standard_normal((h, w, 3)).astype(np.float32)
+    imgs['f32c1'] = (rng.gamma(1.5, 1., (h, w, 1)) * 1e-3).astype(np.float32)
+    return imgs
+
+
+def gen_preprocess():
+    """G11: pins SURVEY row f2.  normalize_percentile: every image x percentile {99.9, 99, (1, 99), (0, 100),
+    (2.5, 60)} x to_uint8 {False (numpy only: fully pinned), True (through the img_as_ubyte stand-in)}; preprocess: the script's
+    control flow (implicit normalisation of non-uint8 inputs, grayscale by channel count, GRAY2RGB, gamma, contrast / brightness
+    only when contrast != 1) incl. the inputs it rejects."""
+    import importlib
+    import json
+    importlib.import_module('celldetection_scripts.cpn_inference')
+    script = sys.modules['celldetection_scripts.cpn_inference']
+    imgs = preprocess_images()
+    out = {f'img.{k}': v for k, v in imgs.items()}
+    cases = []
+    for name, img in imgs.items():
+        for pi, pct in enumerate((99.9, 99, (1, 99), (0, 100), (2.5, 60))):
+            for u8 in (False, True):
+                key = f'np.{name}.{pi}.{int(u8)}'
+                out[key] = cd.data.normalize_percentile(img.copy(), pct, to_uint8=u8)
+                assert out[key].dtype == (np.uint8 if u8 else np.float64)
+                cases.append(dict(fn='normalize_percentile', img=name, key=key, percentile=pct, to_uint8=u8))
+    for name, img in imgs.items():
+        for ki, kw in enumerate(PREPROCESS_KW + [dict()]):
+            key = f'pp.{name}.{ki}'
+            with warnings.catch_warnings(record=True) as wl:
+                warnings.simplefilter('always')
+                try:
+                    res = script.preprocess(img.copy(), **kw)
+                    err = None
+                except Exception as e:  # (inputs the script rejects: recorded as such)
+                    res, err = None, type(e).__name__
+            if res is not None:
+                out[key] = res
+                assert res.dtype == np.uint8 and res.ndim == 3 and res.shape[-1] in (1, 3, 4)
+            cases.append(dict(fn='preprocess', img=name, key=key, kwargs=kw, error=err,
+                              warned=any('implicit percentile' in str(w_.message) for w_ in wl)))
+    # the 2-channel grayscale branch: mean over the channels -> float64 -> cv2.cvtColor rejects the depth
+    two = np.random.default_rng(1).integers(0, 256, (8, 9, 2)).astype(np.uint8)
+    try:
+        script.preprocess(two, grayscale=True)
+        err = None
+    except Exception as e:
+        err = type(e).__name__
+    cases.append(dict(fn='preprocess', img='two_channels', key=None, kwargs=dict(grayscale=True), error=err, warned=False))
+    out['img.two_channels'] = two
+    out['cases'] = np.array(json.dumps(cases))
+    print('preprocess:', len(cases), 'cases;', sum(1 for c in cases if c.get('error')), 'rejected inputs')
+    save('preprocess.npz', **out)
+
+
 def gen_checkpoint():
     """G9: a model file written by the reference's OWN ``save_fetchable_model`` (util/util.py:545-560) -- tiny CpnU22 with one
     attribute changed after construction (-> ``updated_kwargs``) -- plus the reference's outputs for one input.  The file
@@ -515,7 +584,9 @@ def gen_checkpoint():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['ops', 'tiling', 'models', 'stitch', 'checkpoint', 'labels']
+    which = sys.argv[1:] or ['ops', 'tiling', 'models', 'stitch', 'checkpoint', 'labels', 'preprocess']
+    if 'preprocess' in which:
+        gen_preprocess()
     if 'labels' in which:
         gen_labels()
     if 'checkpoint' in which:

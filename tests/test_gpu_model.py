@@ -989,6 +989,28 @@ def test_fp8_subpixel_triples_of_the_unet_decoders(dev, name):
             assert torch.equal(a, b), key
 
 
+def test_fp8_scales_of_another_plan_are_never_applied(dev):
+    """the fp8 activation scales are indexed by the tensor ids of the plan they were calibrated with, and toggling
+    ``model.subpixel`` changes that plan (one more tensor per decoder level).  A toggle after calibrate_fp8() must drop the scales
+    (warning + recalibration on the forwarded batch, or an error without one) -- never shift every scale by a tensor."""
+    m, g = build('CpnResNeXt101UNet', dev)
+    x = torch.as_tensor(g['x']).to(dev)
+    m.precision = 'fp8'
+    m.calibrate_fp8(x)
+    m.subpixel = False
+    with pytest.raises(RuntimeError, match='calibrate_fp8'), pytest.warns(RuntimeWarning, match='subpixel'):
+        m.engine(dev)
+    m.calibrate_fp8(x)
+    m.subpixel = True
+    with pytest.warns(RuntimeWarning):
+        got = [t.cpu() for t in m.core_forward(x)]  # recalibrates on x itself
+    m2, _ = build('CpnResNeXt101UNet', dev)
+    m2.precision = 'fp8'
+    m2.calibrate_fp8(x)
+    for a, b in zip(got, m2.core_forward(x)):
+        assert torch.equal(a, b.cpu())
+
+
 @pytest.mark.parametrize('size', [(64, 96), (100, 140), (48, 68), (130, 260), (24, 520)])
 def test_bilinear_phase_frame_pixels_identical_any_size(dev, size, monkeypatch):
     """Frame launches (CPN_SUBPIXEL_BL_FRAME) cut the two sides of a row into ONE wrap tile (output columns W - 16 .. W - 1 and

@@ -1,9 +1,88 @@
 """Percentile normalisation of the slide (cpn_inference.py:196-222): HIP path vs numpy."""
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
 
 import preprocess_oracle as po
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'preprocess.npz')
+
+
+def _golden():
+    g = np.load(G)
+    return g, json.loads(str(g['cases']))
+
+
+def test_oracle_matches_the_imported_reference():
+    """SURVEY row f2 pin: ``preprocess.npz`` holds outputs of the reference's OWN ``cd.data.normalize_percentile``
+    (data/misc.py:156-161) and ``preprocess`` (celldetection_scripts/cpn_inference.py:196-222), imported by
+    tests/golden/make_golden.py gen_preprocess; the oracle must reproduce every case -- bit for bit, float64 included (same
+    numpy expression) -- and reject what the script rejects."""
+    g, cases = _golden()
+    assert len(cases) > 150
+    for c in cases:
+        img = g[f'img.{c["img"]}']
+        if c['fn'] == 'normalize_percentile':
+            pct = tuple(c['percentile']) if isinstance(c['percentile'], list) else c['percentile']
+            got = po.normalize_percentile(img.copy(), pct, to_uint8=c['to_uint8'])
+            exp = g[c['key']]
+            assert got.dtype == exp.dtype and got.shape == exp.shape, c
+            np.testing.assert_array_equal(got, exp, err_msg=str(c))
+        else:
+            kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in c['kwargs'].items()}
+            if c['error']:
+                with pytest.raises(Exception):
+                    po.preprocess(img.copy(), **kw)
+                continue
+            got, exp = po.preprocess(img.copy(), **kw), g[c['key']]
+            assert got.dtype == exp.dtype and got.shape == exp.shape, c
+            np.testing.assert_array_equal(got, exp, err_msg=str(c))
+
+
+@pytest.mark.gpu
+def test_hip_preprocess_matches_the_imported_reference():
+    """The GPU path against the same fixture: uint8 results identical, ``to_uint8=False`` within float32 rounding of the
+    reference's float64 values; [C, H, W] here = channels-last there."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import warnings
+    from celldetection_amd.preprocess import normalize_percentile, preprocess
+    g, cases = _golden()
+
+    def dev_tensor(img):
+        t = torch.as_tensor(img.astype(np.int32)).to(torch.uint16) if img.dtype == np.uint16 else torch.as_tensor(img)
+        return t.cuda()
+
+    for c in cases:
+        img = g[f'img.{c["img"]}']
+        if c['fn'] == 'normalize_percentile':
+            pct = tuple(c['percentile']) if isinstance(c['percentile'], list) else c['percentile']
+            got = normalize_percentile(dev_tensor(img), pct, to_uint8=c['to_uint8']).cpu().numpy()
+            exp = g[c['key']]
+            assert got.shape == exp.shape, c
+            if c['to_uint8']:
+                assert got.dtype == np.uint8
+                np.testing.assert_array_equal(got, exp, err_msg=str(c))
+            else:
+                np.testing.assert_allclose(got, exp, rtol=0, atol=2e-7, err_msg=str(c))
+        else:
+            kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in c['kwargs'].items()}
+            t = dev_tensor(img)
+            t = t.permute(2, 0, 1).contiguous() if t.ndim == 3 else t
+            if c['error']:
+                with pytest.raises(Exception):
+                    preprocess(t, **kw)
+                continue
+            with warnings.catch_warnings(record=True) as wl:
+                warnings.simplefilter('always')
+                got = preprocess(t, **kw)
+            assert any('implicit percentile' in str(w.message) for w in wl) == c['warned'], c
+            exp = g[c['key']].transpose(2, 0, 1)
+            assert got.dtype == torch.uint8 and tuple(got.shape) == exp.shape, (c, tuple(got.shape), exp.shape)
+            np.testing.assert_array_equal(got.cpu().numpy(), exp, err_msg=str(c))
 
 
 def test_oracle_basic():
