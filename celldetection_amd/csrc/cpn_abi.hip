@@ -951,6 +951,13 @@ int cpn_histogram(const void *x, int32_t dtype, int64_t n, uint32_t *hist, void 
     return check_hip((hipError_t) launch_histogram(x, dtype, (long) n, hist, (hipStream_t) stream), "cpn_histogram");
 }
 
+int cpn_window_any(const void *mask, int32_t dtype, int32_t H, int32_t W, const int32_t *windows, int32_t n, int32_t *out,
+                   void *stream) {
+    if (!mask || (n > 0 && (!windows || !out)) || n < 0 || H <= 0 || W <= 0 || (dtype != 0 && dtype != 1))
+        return fail(CPN_E_INVALID, "cpn_window_any: dtype 0 (f32) or 1 (u8 / bool), H, W > 0");
+    return check_hip((hipError_t) launch_window_any(mask, dtype, W, windows, n, out, (hipStream_t) stream), "cpn_window_any");
+}
+
 int cpn_rescale_to_uint8(const void *x, int32_t dtype, int64_t n, double low, double high, uint8_t *out, void *stream) {
     if (!x || !out || n < 0 || dtype < 0 || dtype > 2) return fail(CPN_E_INVALID, "cpn_rescale_to_uint8: dtype 0 (f32), 1 (u8), 2 (u16)");
     if (!(high > low)) return fail(CPN_E_INVALID, "cpn_rescale_to_uint8: needs high > low");

@@ -218,6 +218,8 @@ int launch_bilinear_f32(const ResizeArgs &a, hipStream_t stream);
 
 // slide preprocessing: value histogram (dtype 1 = u8: 256 bins, 2 = u16: 65536 bins) and percentile rescale to uint8
 int launch_histogram(const void *x, int dtype, long n, unsigned int *hist, hipStream_t stream);
+// tile pre-filter: out[i] |= any(mask[y0:y1, x0:x1] != 0) for windows[i] = (y0, y1, x0, x1); dtype 0 = f32, 1 = u8 / bool
+int launch_window_any(const void *mask, int dtype, int W, const int *windows, int n, int *out, hipStream_t stream);
 int launch_rescale_u8(const void *x, int dtype, long n, double low, double high, unsigned char *out, hipStream_t stream);
 
 // fp8 (e4m3) helper kernels (csrc/misc_fp8.hip) and the calibration reduction

@@ -243,4 +243,32 @@ int launch_act(const ActArgs &a, hipStream_t stream) {
     return (int) hipGetLastError();
 }
 
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Tile pre-filter of the slide loop (TileLoader.__init__ skips tiles whose mask crop is empty,
+// celldetection_scripts/cpn_inference.py:88-100): any(mask[y0:y1, x0:x1] != 0) for every window of the tiling table in ONE
+// launch -- one workgroup per window, rows strided over the waves, 16 bytes per lane and step where the row allows it.
+// HBM-bound: a window is read once; overlapping windows (stride < crop) re-read the overlap from L2.
+template <typename T>
+__global__ __launch_bounds__(256) void window_any_kernel(const T *__restrict__ mask, int W, const int *__restrict__ win,
+                                                         int *__restrict__ out) {
+    const int *wv = win + 4 * blockIdx.x;
+    const int y0 = wv[0], y1 = wv[1], x0 = wv[2], x1 = wv[3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bool any = false;
+    for (int y = y0 + wave; y < y1 && !any; y += 4) {
+        const T *row = mask + (long) y * W;
+        for (int x = x0 + lane; x < x1; x += 64) any |= row[x] != (T) 0;
+    }
+    if (__ballot(any) != 0ull && lane == 0) atomicOr(out + blockIdx.x, 1);
+}
+
+int launch_window_any(const void *mask, int dtype, int W, const int *windows, int n, int *out, hipStream_t stream) {
+    if (n <= 0) return 0;
+    if (dtype == 0) hipLaunchKernelGGL(window_any_kernel<float>, dim3(n), dim3(256), 0, stream, (const float *) mask, W, windows, out);
+    else hipLaunchKernelGGL(window_any_kernel<unsigned char>, dim3(n), dim3(256), 0, stream, (const unsigned char *) mask, W, windows, out);
+    return (int) hipGetLastError();
+}
+
 }  // namespace cpn

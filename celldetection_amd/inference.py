@@ -141,6 +141,20 @@ def _undo_double_offset(model, flat, offs, dev):
     return flat
 
 
+def _non_empty_tiles(mask, slices, tile_ids):
+    """Tiles whose mask crop holds a non-zero value (TileLoader, cpn_inference.py:88-100).  GPU masks: ONE window-any launch over
+    the tiling table and one read-back (``ops.windows_any``) instead of a host synchronisation per tile (1849 on a 16384^2 slide);
+    host masks (the CPU tests of the sharding logic) are indexed in place."""
+    if not tile_ids:
+        return []
+    if mask.is_cuda:
+        from . import ops
+        flags = ops.windows_any(mask, [[slices[i][0].start, slices[i][0].stop, slices[i][1].start, slices[i][1].stop]
+                                       for i in tile_ids])
+        return [i for i, f in zip(tile_ids, flags) if f]
+    return [i for i in tile_ids if bool(torch.any(mask[slices[i]]))]
+
+
 def _sync(dev):
     if dev.type == 'cuda':
         torch.cuda.synchronize(dev)
@@ -207,10 +221,10 @@ def tiled_inference(model, img: torch.Tensor, crop_size=(1024, 1024), strides=(7
     tile_ids = list(range(len(slices)))
     if mask is not None:
         mask = mask.reshape(mask.shape[-2:])
-        tile_ids = [i for i in tile_ids if bool(torch.any(mask[slices[i]]))]
+        tile_ids = _non_empty_tiles(mask, slices, tile_ids)
     if point_mask is not None:
         point_mask = point_mask.reshape(point_mask.shape[-2:])
-        tile_ids = [i for i in tile_ids if bool(torch.any(point_mask[slices[i]]))]
+        tile_ids = _non_empty_tiles(point_mask, slices, tile_ids)
     mine = [tile_ids[j] for j in shard_tiles(len(tile_ids), rank, world_size)]
     nms_thresh = model.nms_thresh if nms_thresh is None else nms_thresh
     rules = stitching_rule.split(',')
@@ -321,60 +335,98 @@ def ensemble_inference(models, img: torch.Tensor, min_vote: float = 1, nms_thres
     return res
 
 
+def _small_box_keep(boxes: torch.Tensor, min_size: float) -> torch.Tensor:
+    """torchvision ``remove_small_boxes`` as a mask: both sides >= min_size (lightning_cpn.py:129)."""
+    return ((boxes[:, 2] - boxes[:, 0]) >= min_size) & ((boxes[:, 3] - boxes[:, 1]) >= min_size)
+
+
 @torch.no_grad()
 def forward_tiled(model, inputs: torch.Tensor, crop_size=1024, stride=512, border_removal: int = 6,
-                  min_box_size: float = 1., nms_thresh: Optional[float] = None, inputs_mask=None, batch_size: int = 8):
-    """In-model tiling variant (``LitCpn.forward_tiled``, celldetection/models/lightning_cpn.py:88-177): for a batch of
-    large images, tiles (default 1024 / 512) -> forward -> ``remove_small_boxes(min 1.0)`` -> border removal (6 px) ->
-    offsets -> concat -> ONE NMS per image.  Returns ``OrderedDict(contours, scores, boxes)`` of per-image lists."""
-    from . import ops
+                  min_box_size: float = 1., nms_thresh: Optional[float] = None, inputs_mask=None, batch_size: int = 8,
+                  extra_keys=(), extra_nms=None, forward_fn: Optional[Callable] = None, ops_fns=None, **kwargs):
+    """In-model tiling variant (``LitCpn.forward_tiled``, celldetection/models/lightning_cpn.py:88-177; pinned to outputs of the
+    imported reference method by tests/golden/forward_tiled.npz): for a batch of large images, tiles (default 1024 / 512) ->
+    forward (NO offsets: everything but contours / boxes stays tile-local, as there) -> ``remove_small_boxes(min 1.0)`` ->
+    border removal (6 px) -> tile origin added to contours and boxes -> concat in tile order -> ONE NMS per image.
+    ``inputs_mask``: a tile is skipped -- for every image of the batch -- iff its mask crop is empty in ALL images
+    (``torch.any(crop_m)`` over the batch, lightning_cpn.py:114-117).  ``extra_keys``: further ``CPN.forward`` outputs to carry
+    along (filtered like the others; ``extra_nms={key: False}`` exempts one from the final NMS selection); remaining ``kwargs`` go
+    to the model's forward, like there.  Returns ``OrderedDict(contours, scores, boxes, *extra_keys)`` of per-image lists.
+    ``forward_fn(tiles, **kw)`` -> per-image lists / ``ops_fns`` = (border_keep_batched, nms): injection points of the CPU tests.
+
+    MI355X mechanics: tiles of all images are batched (``batch_size`` per conv-graph run, pipelined against the filtering of the
+    previous batch); every forwarded batch is filtered by ONE border-rule launch; rows are selected once per COMPACT_EVERY
+    batches."""
     n_img = inputs.shape[0]
     H, W = inputs.shape[-2:]
     crop = (crop_size,) * 2 if np.isscalar(crop_size) else tuple(crop_size)
     strd = (stride,) * 2 if np.isscalar(stride) else tuple(stride)
     assert (np.array(crop) <= np.array(strd) * 2).all()
+    kwargs.pop('max_imsize', None)
+    kwargs.pop('targets', None)
     slices, shape = get_tiling_slices((H, W), crop, strd)
     slices = list(slices)
     h_tiles, w_tiles = shape
-    nms_thresh = model.nms_thresh if nms_thresh is None else nms_thresh
+    nms_thresh = getattr(model, 'nms_thresh', None) if nms_thresh is None else nms_thresh
+    assert nms_thresh is not None, 'Could not retrieve nms_thresh from model. Please specify it in forward method.'
+    extra_keys, extra_nms = tuple(extra_keys), dict(extra_nms or {})
+    out_keys = ('contours', 'scores', 'boxes') + extra_keys
+    if ops_fns is None:
+        from . import ops
+        border_fn, nms_fn = ops.remove_border_contours_batched, ops.nms
+    else:
+        border_fn, nms_fn = ops_fns
     dev = inputs.device
-    jobs = [(j, i) for i in range(len(slices)) for j in range(n_img)
-            if inputs_mask is None or bool(torch.any(inputs_mask[j][(...,) + slices[i]]))]
+    tile_ids = list(range(len(slices)))
+    if inputs_mask is not None:
+        any_img = (inputs_mask != 0).reshape((-1,) + tuple(inputs_mask.shape[-2:])).any(0)
+        tile_ids = _non_empty_tiles(any_img, slices, tile_ids)
+    jobs = [(j, i) for i in tile_ids for j in range(n_img)]
     meta = []
 
     def batches():
         for b0 in range(0, len(jobs), batch_size):
             chunk = jobs[b0:b0 + batch_size]
             tiles = torch.stack([inputs[j][(...,) + slices[i]] for j, i in chunk])
-            offs = torch.tensor([[slices[i][1].start, slices[i][0].start] for _, i in chunk], dtype=torch.int64)
-            meta.append((chunk, offs, tuple(tiles.shape[-2:])))
-            yield tiles, dict(offsets=offs)
+            meta.append((chunk, tuple(tiles.shape[-2:])))
+            yield tiles, dict(kwargs)
 
-    # like tiled_inference: all detections of a forwarded batch are filtered by ONE border-rule launch, rows are
-    # selected once per image at the end
+    if forward_fn is None:
+        results = model.forward_pipelined(batches(), flat_output=True)
+    else:
+        def lists_to_flat(y):
+            counts = [int(t.shape[0]) for t in y['scores']]
+            flat = {k: torch.cat(list(y[k])) for k in out_keys}
+            flat['b'] = torch.repeat_interleave(torch.arange(len(counts), dtype=torch.int32), torch.tensor(counts)).to(dev)
+            return flat, counts
+        results = (lists_to_flat(forward_fn(t, **kw)) for t, kw in batches())
     pending = []
-    for flat, _ in model.forward_pipelined(batches(), flat_output=True):
-        chunk, offs, size = meta.pop(0)
+    for flat, _ in results:
+        chunk, size = meta.pop(0)
         if flat['scores'].shape[0] == 0:
             continue
-        flat = _undo_double_offset(model, flat, offs, dev)
         sides = []
         for _, i in chunk:
             h_i, w_i = np.unravel_index(i, shape)
             sides.append((1 if h_i > 0 else 0) | (2 if w_i < (w_tiles - 1) else 0) |
                          (4 if h_i < (h_tiles - 1) else 0) | (8 if w_i > 0 else 0))
         sides_t = torch.tensor(sides, dtype=torch.int32).to(dev, non_blocking=True)
-        neg = (-offs).to(torch.float32).to(dev, non_blocking=True)
-        boxes = flat['boxes']
-        keep = ((boxes[:, 2] - boxes[:, 0]) >= min_box_size) & ((boxes[:, 3] - boxes[:, 1]) >= min_box_size)
-        keep &= ops.remove_border_contours_batched(flat['contours'], flat['b'], sides_t, neg, size, border_removal).bool()
-        img = torch.tensor([j for j, _ in chunk], dtype=torch.int64).to(dev, non_blocking=True)[flat['b'].long()]
-        pending.append(({k: flat[k] for k in ('contours', 'scores', 'boxes')}, keep, img))
+        zero = torch.zeros((len(chunk), 2), dtype=torch.float32, device=dev)
+        keep = _small_box_keep(flat['boxes'], min_box_size)
+        keep = keep & border_fn(flat['contours'], flat['b'], sides_t, zero, size, border_removal).bool()
+        b = flat['b'].long()
+        origin = torch.tensor([[slices[i][1].start, slices[i][0].start] for _, i in chunk], dtype=torch.float32).to(
+            dev, non_blocking=True)[b]                      # (w_start, h_start) per detection
+        rows = {k: flat[k] for k in out_keys}
+        rows['contours'] = flat['contours'] + origin[:, None]             # lightning_cpn.py:139-142
+        rows['boxes'] = flat['boxes'] + torch.cat((origin, origin), 1)
+        img = torch.tensor([j for j, _ in chunk], dtype=torch.int64).to(dev, non_blocking=True)[b]
+        pending.append((rows, keep, img))
         if len(pending) >= COMPACT_EVERY:
-            pending = _compact(pending, ('contours', 'scores', 'boxes'))
+            pending = _compact(pending, out_keys)
     coll = [None] * n_img
     if pending:
-        (cat, _, img_all), = _compact(pending, ('contours', 'scores', 'boxes'))
+        (cat, _, img_all), = _compact(pending, out_keys)
         # group the kept rows by image with ONE stable sort (tile order within an image is preserved) and one count
         # read-back, instead of a mask + nonzero (= a host sync) per image
         order_ = torch.sort(img_all, stable=True).indices
@@ -385,14 +437,17 @@ def forward_tiled(model, inputs: torch.Tensor, crop_size=1024, stride=512, borde
                 sel = order_[o:o + counts[j]]
                 coll[j] = {k: cat[k].index_select(0, sel) for k in cat}
             o += counts[j]
-    final = OrderedDict(contours=[], scores=[], boxes=[])
+    final = OrderedDict((k, []) for k in out_keys)
+    samples = getattr(model, 'samples', 32)
+    order = min(getattr(model, 'order', 5), getattr(getattr(model, 'core', model), 'order', 5))
+    empty = dict(contours=(0, samples, 2), scores=(0,), boxes=(0, 4), classes=(0,), locations=(0, 2), fourier=(0, order, 4),
+                 contour_proposals=(0, samples, 2))
     for j in range(n_img):
         if coll[j] is not None:
-            con, sco, box = (coll[j][k] for k in ('contours', 'scores', 'boxes'))
-            keep = ops.nms(box, sco, nms_thresh)
-            con, sco, box = con[keep], sco[keep], box[keep]
+            keep = nms_fn(coll[j]['boxes'], coll[j]['scores'], nms_thresh)
+            for k in out_keys:
+                final[k].append(coll[j][k][keep] if extra_nms.get(k, True) else coll[j][k])
         else:
-            con = torch.zeros((0, model.samples, 2), device=dev)
-            sco, box = torch.zeros((0,), device=dev), torch.zeros((0, 4), device=dev)
-        final['contours'].append(con), final['scores'].append(sco), final['boxes'].append(box)
+            for k in out_keys:
+                final[k].append(torch.zeros(empty.get(k, (0,)), device=dev, dtype=torch.int64 if k == 'classes' else torch.float32))
     return final

@@ -250,6 +250,33 @@ def remove_border_contours_batched(contours: Tensor, image_index: Tensor, sides:
     return keep
 
 
+def windows_any(mask: Tensor, windows) -> list:
+    """``[bool(mask[y0:y1, x0:x1].any()) for (y0, y1, x0, x1) in windows]`` in ONE launch and ONE read-back: the tile
+    pre-filter of the slide loop (TileLoader skips tiles whose mask crop is empty, celldetection_scripts/cpn_inference.py:88-100;
+    1849 windows on a 16384^2 slide).  ``mask``: [H, W] on the GPU, any dtype (non-float32 / non-byte masks are compared
+    with zero first)."""
+    _need_cuda(mask)
+    assert mask.ndim == 2
+    if mask.dtype == torch.bool:
+        m = mask.contiguous().view(torch.uint8)
+    elif mask.dtype in (torch.uint8, torch.float32):
+        m = mask.contiguous()
+    else:
+        m = (mask != 0).contiguous().view(torch.uint8)
+    win = torch.as_tensor(windows, dtype=torch.int32).reshape(-1, 4)
+    n = int(win.shape[0])
+    if n == 0:
+        return []
+    H, W = int(m.shape[0]), int(m.shape[1])
+    if int(win[:, 0].min()) < 0 or int(win[:, 2].min()) < 0 or int(win[:, 1].max()) > H or int(win[:, 3].max()) > W:
+        raise ValueError('windows_any: window outside the mask')
+    win = win.to(m.device)
+    out = torch.zeros(n, dtype=torch.int32, device=m.device)
+    check(_lib.load().cpn_window_any(ptr(m), 0 if m.dtype == torch.float32 else 1, H, W, ptr(win), n, ptr(out), stream_ptr()),
+          'window_any')
+    return [bool(v) for v in out.cpu().tolist()]
+
+
 def filter_contours_by_stitching_rule(contours: Tensor, tile_size, overlaps, rule='ex_br', offsets=None,
                                       indices=False):
     """celldetection/ops/cpn.py:293-325 (plain tensor arithmetic; not a hot spot)."""

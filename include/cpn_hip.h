@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CPN_ABI_VERSION 11
+#define CPN_ABI_VERSION 12
 
 #define CPN_E_INVALID (-1)
 #define CPN_E_UNSUPPORTED (-2)
@@ -407,6 +407,14 @@ int cpn_nms_binned(const float *boxes, const float *scores, int64_t P, float thr
  * (normalize_percentile + skimage.img_as_ubyte); x: dtype 0 = f32, 1 = u8, 2 = u16. */
 int cpn_histogram(const void *x, int32_t dtype, int64_t n, uint32_t *hist, void *stream);
 int cpn_rescale_to_uint8(const void *x, int32_t dtype, int64_t n, double low, double high, uint8_t *out, void *stream);
+
+/* Tile pre-filter of the slide loop.  Replaces the per-tile `mask[slices].any()` of TileLoader
+ * (celldetection_scripts/cpn_inference.py:88-100: tiles whose mask / point-mask crop is empty are skipped): for every
+ * window i = (y0, y1, x0, x1) of `windows` (int32 [n][4], device; bounds inside the H x W map -- the caller's tiling
+ * table) out[i] |= any(mask[y0:y1, x0:x1] != 0).  mask: [H][W] row-major, dtype 0 = f32, 1 = u8 / bool; out: int32 [n]
+ * device, pre-zeroed by the caller.  ONE launch and no host synchronisation for the whole table. */
+int cpn_window_any(const void *mask, int32_t dtype, int32_t H, int32_t W, const int32_t *windows, int32_t n, int32_t *out,
+                   void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Label rasterisation.  Replaces celldetection.data.contours2labels / render_contour

@@ -141,6 +141,20 @@ class HyperparametersMixin:
         return self._hparams_initial
 
 
+class LightningModule(nn.Module, HyperparametersMixin):
+    """pytorch_lightning.LightningModule as far as ``LitCpn.forward_tiled`` / ``LitBase.forward`` touch it: an nn.Module that
+    records hyper-parameters and knows the device of its parameters."""
+
+    @property
+    def device(self):
+        try:
+            return next(self.parameters()).device
+        except StopIteration:
+            return torch.device('cpu')
+
+    global_rank = 0
+
+
 class IntermediateLayerGetter(nn.ModuleDict):
     """torchvision.models._utils.IntermediateLayerGetter: run children in order, collect named outputs."""
 
@@ -443,7 +457,7 @@ def install():
     mod('pytorch_lightning.core')
     mix = mod('pytorch_lightning.core.mixins')
     mix.HyperparametersMixin = HyperparametersMixin
-    pl.LightningModule = type('LightningModule', (nn.Module, HyperparametersMixin), {})
+    pl.LightningModule = LightningModule
     pl.Callback = object
     lf = mod('lightning_fabric')
     mod('lightning_fabric.utilities')

@@ -17,6 +17,9 @@ Imports the read-only Python reference (celldetection 0.4.9) through ``oracle/re
 * ``preprocess.npz`` G11: ``cd.data.normalize_percentile`` (data/misc.py:156-161) and the script's ``preprocess``
                    (cpn_inference.py:196-222), both IMPORTED; skimage / cv2 / albumentations calls inside them go through the
                    stand-ins of ``ref_shim`` (third-party arithmetic: unpinned); ``to_uint8=False`` involves numpy only
+* ``forward_tiled.npz`` G12: ``LitCpn.forward_tiled`` (models/lightning_cpn.py:88-177), the reference's own method on the imported
+                   class (``ref_shim.LightningModule`` stands in for pytorch_lightning's base class): per-tile ``CPN.forward``
+                   outputs as the method saw them + its final per-image results, for masks / extra keys / other parameters
 * ``stitch_dups.npz`` G8b: the stitching rule on synthetic per-tile detections WITH cross-tile duplicates (the global
                    NMS removes > 10 % of what survives the border rule)
 
@@ -25,6 +28,8 @@ Run:  python tests/golden/make_golden.py
 import os
 import sys
 import warnings
+
+from collections import OrderedDict
 
 import numpy as np
 import torch
@@ -500,6 +505,75 @@ def gen_labels():
     save('labels.npz', **out)
 
 
+FORWARD_TILED_CASES = [
+    # name, crop, stride, kwargs of forward_tiled (inputs_mask: built below)
+    ('default', 96, 64, dict()),
+    ('mask', 96, 64, dict(inputs_mask=True)),
+    ('extra', 96, 64, dict(extra_keys=('classes', 'locations', 'fourier', 'contour_proposals'), extra_nms=dict(fourier=False))),
+    ('params', 128, 80, dict(border_removal=2, min_box_size=9., nms_thresh=.05)),  # (tuple crops trip the method's own assert)
+]
+
+
+def gen_forward_tiled():
+    """G12: the in-model tile loop pinned to the imported ``LitCpn.forward_tiled``."""
+    import json
+    from celldetection.models.lightning_cpn import LitCpn
+    model, overrides, _ = build_ref_model('CpnU22', 0, fourier_std=.6, location_std=.5, score_shift=-3.)
+    lit = LitCpn(model).eval()
+    H, W = 160, 224
+    # uint8 images: LitBase.forward -> prepare_inputs divides by 255 (lightning_base.py:774-780)
+    img = torch.randint(0, 256, (2, 3, H, W), generator=torch.Generator().manual_seed(21), dtype=torch.uint8)
+    mask = torch.zeros(2, 1, H, W)
+    mask[0, :, :, :100] = 1      # image 0: left part only
+    mask[1, :, 20:40, 30:50] = 1  # image 1: one blob in the first tile -> tiles empty in BOTH images are skipped, the others run
+    out = {f'override.{k}': npy(v) for k, v in overrides.items()}
+    tmpl = model.state_dict()
+    out['sd_keys'] = np.array(list(tmpl.keys()))
+    out['sd_shapes'] = np.array([','.join(str(int(d)) for d in v.shape) for v in tmpl.values()])
+    out['img'], out['mask'] = npy(img), npy(mask)
+    meta = []
+    calls = []
+    orig_forward = model.forward
+
+    def recording_forward(inputs, *a, **k):
+        y = orig_forward(inputs, *a, **k)
+        calls.append((inputs.clone(), OrderedDict((kk, [t.clone() for t in v]) for kk, v in y.items() if v is not None)))
+        return y
+
+    model.forward = recording_forward
+    try:
+        for name, crop, stride, kw in FORWARD_TILED_CASES:
+            kw = dict(kw)
+            if kw.get('inputs_mask') is True:
+                kw['inputs_mask'] = mask
+            calls.clear()
+            with torch.no_grad():
+                y = lit.forward_tiled(img, crop_size=crop, stride=stride, **kw)
+            slices, shape = cd.get_tiling_slices((H, W), crop, stride)
+            slices = list(slices)
+            called = []
+            for ci, (x_in, y_tile) in enumerate(calls):  # which tile was forwarded: match the crop
+                idx = next(i for i, sl in enumerate(slices)
+                           if i not in called and torch.equal(img[(...,) + tuple(sl)].float() / 255, x_in))
+                called.append(idx)
+                for kk, v in y_tile.items():
+                    for j, t in enumerate(v):
+                        key = f't{crop}_{stride}.tile{idx}.{kk}.{j}'  # (per-tile outputs depend on the tiling only: stored once)
+                        assert key not in out or np.array_equal(out[key], npy(t))
+                        out[key] = npy(t)
+            for kk, v in y.items():
+                for j, t in enumerate(v):
+                    out[f'{name}.final.{kk}.{j}'] = npy(t)
+            meta.append(dict(name=name, crop=crop, stride=stride, tiles_called=called, n_tiles=len(slices), tiles=f't{crop}_{stride}',
+                             kwargs={a: (list(b) if isinstance(b, tuple) else b) for a, b in kw.items() if a != 'inputs_mask'},
+                             use_mask='inputs_mask' in kw, keys=list(y.keys())))
+            print(f'forward_tiled/{name}: tiles forwarded {called} of {len(slices)}; final per image', [len(t) for t in y['scores']])
+    finally:
+        model.forward = orig_forward
+    out['cases'] = np.array(json.dumps(meta))
+    save('forward_tiled.npz', **out)
+
+
 PREPROCESS_KW = [dict(grayscale=True), dict(gamma=.7), dict(gamma=2.2, grayscale=True), dict(contrast=1.3),
                  dict(contrast=.8, brightness=.2), dict(contrast=1., brightness=.5), dict(percentile=99.),
                  dict(percentile=(2., 98.), gamma=1.5), dict(percentile=99., gamma=1.5, contrast=1.2, brightness=-.1, grayscale=True)]
@@ -584,7 +658,9 @@ def gen_checkpoint():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['ops', 'tiling', 'models', 'stitch', 'checkpoint', 'labels', 'preprocess']
+    which = sys.argv[1:] or ['ops', 'tiling', 'models', 'stitch', 'checkpoint', 'labels', 'preprocess', 'forward_tiled']
+    if 'forward_tiled' in which:
+        gen_forward_tiled()
     if 'preprocess' in which:
         gen_preprocess()
     if 'labels' in which:

@@ -1,0 +1,150 @@
+"""In-model tile loop against the reference's own method: tests/golden/forward_tiled.npz holds what the imported
+``LitCpn.forward_tiled`` (celldetection/models/lightning_cpn.py:88-177) saw per tile (``CPN.forward`` outputs of the reference)
+and what it returned, for a default call, ``inputs_mask``, ``extra_keys`` / ``extra_nms`` and other parameters (generator:
+tests/golden/make_golden.py gen_forward_tiled).  The loop around the forward -- which tiles run, small-box and border filters,
+origins added to contours / boxes only, concatenation order, one NMS per image -- is selection + one exact float add, so the
+product loop fed with the recorded per-tile outputs must reproduce the recorded results bit for bit:
+
+* CPU: ``inference.forward_tiled`` host logic with the oracle's border rule / NMS injected;
+* GPU: the same with the HIP kernels (batched border rule, segmented NMS), and end to end (uint8 tiles -> HIP fp32 graph)."""
+import json
+import os
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+import cpn_oracle as orc
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'forward_tiled.npz')
+KEYS = ('contours', 'boxes', 'scores', 'classes', 'locations', 'fourier', 'contour_proposals')
+
+
+class _Model:
+    nms_thresh, samples, order = .2, 32, 5
+
+    class core:
+        order = 5
+
+
+def _recorded_forward(g, case, dev, n_img=2):
+    """forward_fn(tiles, **kw) that answers with the reference's per-tile outputs, in the order the loop must ask for them:
+    for tile in tiles_called: for image in batch."""
+    jobs = [(j, i) for i in case['tiles_called'] for j in range(n_img)]
+    state = dict(pos=0, asked=[])
+    img = torch.as_tensor(g['img'])
+
+    def forward_fn(tiles, **kw):
+        out = OrderedDict((k, []) for k in KEYS)
+        for n in range(tiles.shape[0]):
+            j, i = jobs[state['pos']]
+            state['pos'] += 1
+            state['asked'].append((j, i))
+            for k in KEYS:
+                out[k].append(torch.as_tensor(g[f"{case['tiles']}.tile{i}.{k}.{j}"]).to(dev))
+        return out
+
+    return forward_fn, state, jobs, img
+
+
+def _oracle_ops():
+    def border(contours, image_index, sides, offsets, size, pad):
+        con, b, sd = contours.cpu().numpy(), image_index.cpu().numpy(), sides.cpu().numpy()
+        keep = np.zeros(len(con), bool)
+        for t in np.unique(b):
+            m = b == t
+            s = int(sd[t])
+            keep[m] = orc.remove_border_contours(con[m], size, pad, top=bool(s & 1), right=bool(s & 2), bottom=bool(s & 4),
+                                                 left=bool(s & 8), offsets=offsets[t].cpu().numpy())
+        return torch.as_tensor(keep)
+
+    def nms(boxes, scores, thr):
+        return torch.as_tensor(orc.nms(boxes.cpu().numpy(), scores.cpu().numpy(), thr), dtype=torch.int64)
+
+    return border, nms
+
+
+def _run_case(g, case, dev, ops_fns, batch_size):
+    from celldetection_amd import inference
+    forward_fn, state, jobs, img = _recorded_forward(g, case, dev)
+    kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in case['kwargs'].items()}
+    if case['use_mask']:
+        kw['inputs_mask'] = torch.as_tensor(g['mask']).to(dev)
+    res = inference.forward_tiled(_Model(), img.to(dev), crop_size=case['crop'], stride=case['stride'], batch_size=batch_size,
+                                  forward_fn=forward_fn, ops_fns=ops_fns, **kw)
+    assert state['asked'] == jobs, 'the loop forwarded other tiles (or another order) than the reference method'
+    assert list(res.keys()) == case['keys']
+    for k in case['keys']:
+        for j in range(2):
+            exp = g[f"{case['name']}.final.{k}.{j}"]
+            got = res[k][j].cpu().numpy()
+            assert got.shape == exp.shape and got.dtype == exp.dtype, (case['name'], k, j, got.shape, exp.shape, got.dtype)
+            np.testing.assert_array_equal(got, exp, err_msg=f"{case['name']}.{k}.{j}")
+
+
+def _cases():
+    g = np.load(G)
+    return g, json.loads(str(g['cases']))
+
+
+@pytest.mark.parametrize('batch_size', [8, 3])
+def test_forward_tiled_host_logic_reproduces_the_reference_method(batch_size):
+    g, cases = _cases()
+    assert [c['name'] for c in cases] == ['default', 'mask', 'extra', 'params']
+    assert cases[1]['tiles_called'] != list(range(cases[1]['n_tiles']))  # the mask case does skip tiles
+    for case in cases:
+        _run_case(g, case, torch.device('cpu'), _oracle_ops(), batch_size)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('batch_size', [8, 5])
+def test_forward_tiled_hip_kernels_reproduce_the_reference_method(batch_size):
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    g, cases = _cases()
+    for case in cases:
+        _run_case(g, case, torch.device('cuda:0'), None, batch_size)  # ops.remove_border_contours_batched, ops.nms
+
+
+@pytest.mark.gpu
+def test_forward_tiled_end_to_end_fp32_vs_the_reference_method():
+    """uint8 images -> on-device crops -> HIP fp32 conv graph -> decode -> filters -> NMS against the reference method's results:
+    identical detection sets (counts, order), coordinates within 1e-4 (pixel-snap flips of ``local_refinement`` bounded as in
+    tests/test_gpu_model.py north_star_check); bf16: IoU-matched."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import celldetection_amd as cda
+    from celldetection_amd.synth import synth_state_dict
+    from test_gpu_model import _iou_match_rate
+    g, cases = _cases()
+    dev = torch.device('cuda:0')
+    model = cda.models.CpnU22(3, backbone_kwargs={'backbone_kwargs': {'base_channels': 8}})
+    assert list(model.state_dict().keys()) == [str(k) for k in g['sd_keys']]
+    ov = {k[len('override.'):]: torch.as_tensor(g[k]) for k in g.files if k.startswith('override.')}
+    model.load_state_dict(synth_state_dict(model.state_dict(), seed=0, overrides=ov))
+    model = model.to(dev)
+    img = torch.as_tensor(g['img']).to(dev)
+    for case in cases:
+        kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in case['kwargs'].items()}
+        if case['use_mask']:
+            kw['inputs_mask'] = torch.as_tensor(g['mask']).to(dev)
+        model.precision = 'fp32'
+        res = model.forward_tiled(img, crop_size=case['crop'], stride=case['stride'], **kw)
+        assert list(res.keys()) == case['keys']
+        for j in range(2):
+            for k in case['keys']:
+                exp, got = g[f"{case['name']}.final.{k}.{j}"], res[k][j].cpu().numpy()
+                assert got.shape == exp.shape, (case['name'], k, j, got.shape, exp.shape)
+                if k == 'classes':
+                    np.testing.assert_array_equal(got, exp)
+                elif k in ('contours', 'boxes'):
+                    bad = float((np.abs(got - exp) > 1e-4).mean()) if exp.size else 0.
+                    assert bad <= 2e-3, (case['name'], k, j, bad)
+                else:
+                    np.testing.assert_allclose(got, exp, rtol=0, atol=1e-4 if k == 'scores' else 1e-3)
+        model.precision = 'bf16'
+        res = model.forward_tiled(img, crop_size=case['crop'], stride=case['stride'], **kw)
+        rates = [_iou_match_rate(res['boxes'][j].cpu().numpy(), g[f"{case['name']}.final.boxes.{j}"]) for j in range(2)]
+        print(case['name'], 'bf16 IoU>0.5 match rates', rates)
+        assert min(rates) > .85, (case['name'], rates)

@@ -966,3 +966,30 @@ def test_resize_bilinear_f32_vs_torch_cpu(dev, shape, size):
     m = (x > .5).float()  # 0/1 masks: what the slide loop passes as score bounds
     np.testing.assert_array_equal(_equal_size(m.to(dev), torch.empty(1, 1, *size)).cpu().numpy() > .9,
                                   F.interpolate(m, size, mode='bilinear', align_corners=False).numpy() > .9)
+
+
+@pytest.mark.parametrize('dtype', [torch.bool, torch.uint8, torch.float32, torch.int64, torch.float16])
+def test_windows_any_equals_per_tile_any(dev, dtype):
+    """Tile pre-filter of the slide loop (TileLoader skips tiles with an empty mask crop, cpn_inference.py:88-100): ONE window-any
+    launch over the tiling table == ``mask[slices].any()`` per tile -- sparse seeds, seeds on window borders, -0.0 / NaN floats."""
+    from celldetection_amd import ops, util
+    H, W = 700, 1000
+    slices = list(util.get_tiling_slices((H, W), (128, 160), (96, 100))[0])
+    win = [[s[0].start, s[0].stop, s[1].start, s[1].stop] for s in slices]
+    g = torch.Generator().manual_seed(5)
+    mask = torch.zeros(H, W)
+    ys, xs = torch.randint(0, H, (12,), generator=g), torch.randint(0, W, (12,), generator=g)
+    mask[ys, xs] = 1.
+    mask[127, 159] = 1.   # last pixel of the first window
+    mask[H - 1, W - 1] = 1.
+    m = mask.to(dtype).to(dev)
+    if dtype == torch.float32:
+        m[300, 500] = -0.      # zero
+        m[5, 700] = float('nan')  # non-zero
+    got = ops.windows_any(m, win)
+    exp = [bool(torch.any(m[s])) for s in slices]
+    assert got == exp and 0 < sum(exp) < len(exp)
+    assert ops.windows_any(torch.zeros(H, W, dtype=dtype, device=dev), win) == [False] * len(win)
+    assert ops.windows_any(m, []) == []
+    with pytest.raises(ValueError):
+        ops.windows_any(m, [[0, H + 1, 0, 10]])
