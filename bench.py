@@ -331,6 +331,21 @@ def _sclk_mhz(dev):
     return None
 
 
+def host_threads(world):
+    """CPU threads one rank may use: the CPUs this container may keep busy (cgroup quota, else the visible CPUs) shared by the
+    ranks of the node.  8 ranks x `os.cpu_count() // 8` = 32 threads each on a 16-CPU quota is the CFS throttling measured in
+    round 5 (10-100x slow-downs of weight synthesis / packing): the quota, not the host's core count, is what can run."""
+    cpus = os.cpu_count() or 1
+    try:
+        cpus = min(cpus, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = _cpu_quota()
+    if quota is not None:
+        cpus = min(cpus, max(1, int(quota)))
+    return max(1, cpus // max(world, 1))
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
@@ -344,6 +359,17 @@ def self_launch(args):
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     return subprocess.call(cmd, env=env)
+
+
+def setup_per_rank(dev, world, dist, keys=('import_torch', 'import_and_init', 'build_model', 'pack_and_warm')):
+    """Set-up seconds of every rank (a rank throttled by the container's CPU quota shows up here), or None on one rank."""
+    if not dist or world < 2:
+        return None
+    import torch.distributed as td
+    t = torch.tensor([PHASES.get(k, 0.) for k in keys], dtype=torch.float64, device=dev)
+    allt = [torch.zeros_like(t) for _ in range(world)]
+    td.all_gather(allt, t)
+    return {k: [round(float(a[i]), 2) for a in allt] for i, k in enumerate(keys)}
 
 
 def load_traffic(model, batch, tile, precision):
@@ -388,20 +414,19 @@ def dry_run_slide(args, world, rank):
             out['fourier'].append(torch.randn(k, O_, 4, generator=g))
         return out
 
-    def nms(boxes, scores, thr):  # greedy box NMS, O(K^2), descending score (stable)
-        order = torch.argsort(scores, descending=True, stable=True).tolist()
-        area = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+    def nms(boxes, scores, thr):  # greedy box NMS, descending score (stable); one vector pass per kept box
+        order = torch.argsort(scores, descending=True, stable=True)
+        b = boxes[order]
+        area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+        dead = torch.zeros(b.shape[0], dtype=torch.bool)
         keep = []
-        for i in order:
-            ok = True
-            for j in keep:
-                lt, rb = torch.maximum(boxes[i, :2], boxes[j, :2]), torch.minimum(boxes[i, 2:], boxes[j, 2:])
-                inter = (rb - lt).clamp(min=0).prod()
-                if float(inter / (area[i] + area[j] - inter)) > thr:
-                    ok = False
-                    break
-            if ok:
-                keep.append(i)
+        for i in range(b.shape[0]):
+            if dead[i]:
+                continue
+            keep.append(int(order[i]))
+            lt, rb = torch.maximum(b[i, :2], b[i + 1:, :2]), torch.minimum(b[i, 2:], b[i + 1:, 2:])
+            inter = (rb - lt).clamp(min=0).prod(1)
+            dead[i + 1:] |= inter / (area[i] + area[i + 1:] - inter) > thr
         return torch.tensor(keep, dtype=torch.int64)
 
     class Model:
@@ -513,6 +538,7 @@ def main():
     # nccl init / barrier / all-reduce calls of the N > 1 path)
     dist = world > 1 or (in_torchrun and os.environ.get('CPN_BENCH_FORCE_DIST') == '1')
     if args.dry_run:
+        torch.set_num_threads(host_threads(world))
         if dist:
             import torch.distributed as td
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -525,8 +551,8 @@ def main():
         raise SystemExit('bench.py: measurements run on RCCL (--backend nccl); gloo is for --dry-run only')
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
-    if world > 1:  # N ranks on one host: no N-fold oversubscription of the cores while the weights are synthesised
-        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
+    # N ranks on one host share what the container's CPU quota lets it keep busy (weight synthesis / packing are host work)
+    torch.set_num_threads(host_threads(world))
     if dist:
         import torch.distributed as td
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -619,6 +645,7 @@ def main():
     mem1 = torch.cuda.memory_stats(dev).get('num_device_alloc', 0)
     phase('timed_region')
     sclk = _sclk_mhz(dev)  # right after the timed region, per rank
+    setup_ranks = setup_per_rank(dev, world, dist)
     if dist:
         t = torch.tensor([sclk if sclk is not None else -1.], dtype=torch.float64, device=dev)
         allc = [torch.zeros_like(t) for _ in range(world)]
@@ -719,6 +746,7 @@ def main():
         # executed FLOPs of the profiled run tell which)
         n_launch = sum(1 for p in prof if p['op'] in ('conv', 'conv_pair', 'conv_bridge') and p['gflop'] > 0) - (2 if args.sparse_heads and eng.sparse else 0)
         rccl_world = td.get_world_size() if dist else None  # None: no process group exists (one rank, RCCL never initialised)
+        assert rccl_world is None or rccl_world == world == args.gpus, (rccl_world, world, args.gpus)
         gated = None
         if args.sparse_heads and eng.sparse:
             # score-gated line: the roofline fraction counts EXECUTED FLOPs (conv graph without the two deferred heads + the
@@ -792,6 +820,9 @@ def main():
             out['cpu_baseline'] = cpu_baseline(sd, args.tile)
             phase('cpu_baseline')
         out['setup_s'] = {k: round(v, 2) for k, v in PHASES.items()}
+        if setup_ranks is not None:
+            out['setup_s_per_rank'] = setup_ranks
+        out['host_threads_per_rank'] = host_threads(world)
         print(json.dumps(out), file=_JSON_OUT, flush=True)
     if dist:
         td.destroy_process_group()
@@ -964,7 +995,9 @@ def slide_workload(args, model, dev, world, rank, dist):
                  'identical_to_dense': bool(res_g['scores'].shape == res['scores'].shape and torch.equal(res_g['boxes'], res['boxes'])),
                  'mode': "model.sparse_heads = 'auto' (product default), one pass over the same slide"}
         model.sparse_heads = False
+    setup_ranks = setup_per_rank(dev, world, dist, keys=('import_torch', 'import_and_init', 'build_model'))
     if rank == 0:
+        assert not dist or td.get_world_size() == world == args.gpus
         gf = GFLOP_PER_TILE.get(args.model)
         value = ntiles * args.steps / dt
         peak = PEAK_BF16_TFLOPS
@@ -988,6 +1021,10 @@ def slide_workload(args, model, dev, world, rank, dist):
         }
         if gated is not None:
             out['gated'] = gated
+        out['setup_s'] = {k: round(v, 2) for k, v in PHASES.items()}
+        if setup_ranks is not None:
+            out['setup_s_per_rank'] = setup_ranks
+        out['host_threads_per_rank'] = host_threads(world)
         print(json.dumps(out), file=_JSON_OUT, flush=True)
     if dist:
         td.destroy_process_group()

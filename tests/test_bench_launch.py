@@ -57,3 +57,28 @@ def test_four_rank_slide_dry_run_ragged_counts(slide, tiles):
     assert d['gathered_detections'] == sum(d['detections_per_rank']) and d['final_detections'] <= d['gathered_detections']
     if slide == 900:
         assert 0 in d['detections_per_rank'] or min(d['detections_per_rank']) < max(d['detections_per_rank'])
+
+
+def test_eight_rank_slide_dry_run_at_configs3_geometry():
+    """BASELINE configs[3]'s own geometry -- 16384^2, tiles 512 / 384 = 1849 tiles, batch 16 -- on 8 gloo ranks:
+    231 / 232 tiles per rank (ragged last batches of 7 / 8 tiles), one packed all-gather, the global NMS on every rank, identical
+    results everywhere.  (CPU stand-ins for the kernels; the slide is a lazily mapped zero tensor.)"""
+    r = _run(['--gpus', '8', '--backend', 'gloo', '--dry-run', '--workload', 'slide', '--slide', '16384', '--tile', '512',
+              '--stride', '384', '--batch', '16'], timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert d['identical_on_all_ranks'] and d['n_gpus'] == 8 and d['world_size_seen'] == 8
+    assert sum(d['tiles_per_rank']) == 1849 and d['tiles_per_rank'] == [232] + [231] * 7
+    assert d['gathered_detections'] == sum(d['detections_per_rank']) > 1849
+    assert 0 < d['final_detections'] <= d['gathered_detections']
+
+
+def test_host_threads_follow_the_cpu_quota(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setattr(bench, '_cpu_quota', lambda: 16.)
+    monkeypatch.setattr(bench.os, 'cpu_count', lambda: 256)
+    monkeypatch.setattr(bench.os, 'sched_getaffinity', lambda pid: set(range(256)), raising=False)
+    assert [bench.host_threads(w) for w in (1, 2, 4, 8, 32)] == [16, 8, 4, 2, 1]
+    monkeypatch.setattr(bench, '_cpu_quota', lambda: None)
+    assert bench.host_threads(8) == 32
