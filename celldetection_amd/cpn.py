@@ -351,8 +351,7 @@ class CPN(nn.Module):
         super().__init__()
         unsupported = {k: v for k, v in kwargs.items() if (k in ('contour_head_stride', 'refinement_head_stride')
                                                            and v not in (None, 1, 2, 4, 8))
-                       or (k == 'refinement_interpolation' and v != 'bilinear')
-                       or (k == 'refinement_full_res' and v is not True) or (k == 'fuse_kwargs' and v)}
+                       or (k == 'refinement_interpolation' and v == 'bicubic') or (k == 'fuse_kwargs' and v)}
         if unsupported:
             raise NotImplementedError(f'Unsupported CPN options on the HIP path: {unsupported}')
         features = {name: kwargs[key] for name, key in (('score', 'score_features'), ('location', 'location_features'),
@@ -386,7 +385,12 @@ class CPN(nn.Module):
                                  kernel_sizes=kernel_sizes, features=features or None,
                                  contour_head_stride=int(kwargs.get('contour_head_stride') or 1),
                                  refinement_head_stride=int(kwargs.get('refinement_head_stride') or 1),
-                                 head_activations=head_act if any(v != 'relu' for v in head_act.values()) else None)
+                                 head_activations=head_act if any(v != 'relu' for v in head_act.values()) else None,
+                                 refinement_full_res=bool(kwargs.get('refinement_full_res', True)))
+        # `_equal_size(.., mode=refinement_interpolation, align_corners=False)` (cpn.py:109-115,277-279): torch accepts
+        # align_corners for the interpolating modes only, so in the reference every other mode ('nearest', 'area', ...) raises
+        # as soon as a resize is needed; reproduced in `_Engine.run` / `core_forward` (bicubic: not built)
+        self.refinement_interpolation = kwargs.get('refinement_interpolation', 'bilinear')
         # 'bf16' (MFMA performance path) | 'fp32' (verification path, ~100x slower) | 'fp8' (e4m3 activations and
         # weights on the K=64 scaled MFMA, 2x the bf16 rate; static activation scales from ``calibrate_fp8`` or, if
         # that was not called, from the first batch that is forwarded)
@@ -561,6 +565,8 @@ class CPN(nn.Module):
         (``_static_ok`` / ``_forward_path``: internal -- the forward paths consume the maps before the engine re-uses their
         hipGraph slot, and are the callers for which ``sparse_heads = 'auto'`` gates the location / Fourier heads.)"""
         eng = self.engine(inputs.device, calibration_input=inputs, _forward_path=_forward_path)
+        if self.refinement and getattr(self, 'refinement_interpolation', 'bilinear') != 'bilinear':
+            self._check_refinement_interpolation(eng, inputs)
         if eng.sparse and eng.max_batch(inputs.shape[0], *inputs.shape[-2:]) < inputs.shape[0]:
             # the engine has to split this batch (2^31-byte tensors), but the gathered heads read the heads' source of the
             # WHOLE batch after the run: such batches take the dense plan (same outputs)
@@ -572,8 +578,28 @@ class CPN(nn.Module):
         self._last_sparse = eng.last_sparse  # score-gated heads: locations / fourier are None, evaluated in postprocess
         return scores, locations, refinement, fourier
 
+    def _check_refinement_interpolation(self, eng, inputs):
+        """``refinement_interpolation`` other than 'bilinear': the reference calls F.interpolate(.., mode=mode, align_corners=False)
+        whenever the refinement feature or the head's output differs from the input size (cpn.py:109-115,277-279), and torch
+        rejects align_corners for every non-interpolating mode -- the same ValueError is raised here in that case; when no resize
+        is needed the mode is never used (there and here)."""
+        from ctypes import c_int32, c_int64
+        n, _, h, w = inputs.shape
+        sizes = [eng.output_size(h, w, _lib.OUT_REFINEMENT)]
+        for op in eng.plan.ops:  # the resize in front of the head: its own op, or fused into the head conv's loader
+            if op['op'] == 'bilinear' or (op['op'] == 'conv' and op.get('up0') == 'bilinear'):
+                off, th, tw, cs = c_int64(0), c_int32(0), c_int32(0), c_int32(0)
+                _lib.check(_lib.load().cpn_plan_tensor_info(eng.handle, n, h, w, int(op['src0']), off, th, tw, cs), 'plan_tensor_info')
+                sizes.append((int(th.value), int(tw.value)))
+        if any(tuple(sz) != (h, w) for sz in sizes):
+            if self.refinement_interpolation == 'bicubic':
+                raise NotImplementedError("refinement_interpolation='bicubic' is not built on the HIP path")
+            raise ValueError('align_corners option can only be set with the interpolating modes: linear | bilinear | bicubic | '
+                             'trilinear')
+
     @torch.no_grad()
     def forward(self, inputs, targets=None, nms=True, **kwargs):
+
         if targets is not None:
             raise NotImplementedError('Loss computation / training is out of scope of the HIP inference engine.')
         if not inputs.is_cuda:
@@ -666,8 +692,6 @@ class CPN(nn.Module):
         refinement [N,2*buckets,H,W] or None; fourier [N,4*O,h,w]; uncertainty [N,4,h,w] or None (cpn.py:209-221).
         ``flat_output``: return ``(dict of flat [K, ...] tensors incl. 'b' = image index int32 [K], per-image counts)``
         instead of per-image lists (the slide loop filters all tiles of a batch at once)."""
-        if self.functional:
-            raise NotImplementedError("the 'functional' Fourier layout (cpn.py:591-592) is not supported on the HIP path")
         n = scores.shape[0]
         lb, ub = kwargs.get('scores_lower_bound'), kwargs.get('scores_upper_bound')
         ub = None if ub is None else _equal_size(ub.to(scores), scores)  # cpn.py:118-123
@@ -690,6 +714,12 @@ class CPN(nn.Module):
         indices, counts, flag_v = ops.compact_scores(select_map, thresh, extra_flag=flag)
         if flag_v:
             raise AssertionError('Inputs should be in interval (0.0, 1.0)')  # models/commons.py:696-697
+        if self.functional and int(indices.shape[0]) > 0:
+            # cpn.py:591-592 views the Fourier map as [n, c / 2, 2, h, w]; fouriers2contours then indexes columns (1, 3) of a
+            # last dimension of size 2 (ops/cpn.py:93-94): with at least one proposal the reference's forward raises this
+            # IndexError, without proposals the empty index passes and `fourier` comes back as [0, c / 2, 2] (both recorded from
+            # the imported reference: tests/golden/reference_behaviours.json)
+            raise IndexError('index 3 is out of bounds for dimension 0 with size 2')
         iters = self.refinement_iterations if (self.refinement and refinement is not None) else 0
         gathered = locations is None
         if gathered:  # score-gated heads: location / Fourier head values of the proposals only (ops.sparse_heads)
@@ -717,6 +747,8 @@ class CPN(nn.Module):
             flat['classes'] = torch.ones((offs[-1],), dtype=torch.int64, device=scores.device)
         else:
             flat['classes'] = class_map.reshape(-1)[indices.long()].to(torch.int64)
+        if self.functional:  # (no proposals: see above)
+            flat['fourier'] = flat['fourier'].reshape(0, 2 * flat['fourier'].shape[1], 2)
         keys = ['contours', 'boxes', 'scores', 'classes', 'locations', 'fourier', 'contour_proposals']
         nms_weights = flat['scores']
         if uncertainty is not None:  # cpn.py:634-636,723-726

@@ -220,16 +220,33 @@ def _two_conv_norm_relu(P, x, cout, prefix, bias=True, src1=None, up0=False, up1
         x = P.conv(x, cout, 3, w=prefix + '3.', bn=prefix + '4.', bias=bias, act='relu')
         P.conv_bridge()  # both convs as one kernel where the output holds a 16 x 32 tile (64-channel bridges: the ResNet-UNets)
         return x
-    lat = x
+    x = _first_conv(P, x, cout, prefix + '0.', prefix + '1.', bias, src1, up0, up1, subpixel)
+    return P.conv(x, cout, 3, w=prefix + '3.', bn=prefix + '4.', bias=bias, act='relu')
+
+
+def _first_conv(P, lat, cout, w, bn, bias, src1, up0, up1, subpixel):
+    """conv 3x3 + BN + ReLU over cat(lat, nearest-upsampled src1) (or over ``lat`` alone), as a sub-pixel triple where asked."""
     sub = bool(subpixel) and src1 is not None and up1 and not up0
-    x = P.conv(lat, cout, 3, w=prefix + '0.', bn=prefix + '1.', bias=bias, act='relu', src1=src1, up0=up0, up1=up1,
-               sub='head' if sub else None)
+    x = P.conv(lat, cout, 3, w=w, bn=bn, bias=bias, act='relu', src1=src1, up0=up0, up1=up1, sub='head' if sub else None)
     if sub:
         c0 = P.tensors[lat]['c']
-        ph = P.conv(src1, cout, 2, w=prefix + '0.', bn=prefix + '1.', bias=bias, pad=1, sub=('phase', c0))
-        P.conv(lat, cout, 3, w=prefix + '0.', bn=prefix + '1.', bias=bias, act='relu', res=ph, res_up='shuffle',
-               sub=('lateral', c0), dst=x)
-    return P.conv(x, cout, 3, w=prefix + '3.', bn=prefix + '4.', bias=bias, act='relu')
+        ph = P.conv(src1, cout, 2, w=w, bn=bn, bias=bias, pad=1, sub=('phase', c0))
+        P.conv(lat, cout, 3, w=w, bn=bn, bias=bias, act='relu', res=ph, res_up='shuffle', sub=('lateral', c0), dst=x)
+    return x
+
+
+def _cd_res_block(P, x, cin, cout, prefix, src1=None, up1=False, subpixel=False):
+    """celldetection ``ResBlock`` (models/commons.py:259-359), the block class of ResUNet (unet.py:434-464), stride 1:
+    conv3x3(no bias)-BN-ReLU-conv3x3(no bias)-BN + identity, ReLU; the identity is a 1x1 ConvNorm (no bias) when the channel
+    counts differ -- over the same virtual concat [x | upsampled src1] in the decoder.  State-dict order: downsample.*, block.*."""
+    if cin != cout:
+        idt = P.conv(x, cout, 1, w=prefix + 'downsample.0.', bn=prefix + 'downsample.1.', src1=src1, up1=up1)
+    elif src1 is None:
+        idt = x
+    else:
+        raise NotImplementedError('ResBlock over a concat with as many input as output channels (identity shortcut over a cat)')
+    t = _first_conv(P, x, cout, prefix + 'block.0.', prefix + 'block.1.', False, src1, False, up1, subpixel)
+    return P.conv(t, cout, 3, w=prefix + 'block.3.', bn=prefix + 'block.4.', res=idt, act='relu')
 
 
 # constructor options of the reference backbones that the HIP graph does not model: accepted only with the listed
@@ -261,19 +278,20 @@ def _check_kwargs(kw: dict, allowed: tuple, where: str):
                                   f'(supported: {sorted(allowed)}; default-valued reference options are accepted)')
 
 
-def _unet_encoder(P, x, in_channels, prefix, depth=5, base_channels=64, factor=2, **unused):
-    """UNetEncoder (unet.py:29-58) with pool=True, TwoConvNormRelu blocks."""
+def _unet_encoder(P, x, in_channels, prefix, depth=5, base_channels=64, factor=2, res_blocks=False, **unused):
+    """UNetEncoder (unet.py:29-58) with pool=True; TwoConvNormRelu blocks (U22 family) or ResBlocks (ResUNet)."""
     _check_kwargs(unused, (), 'UNetEncoder')
     feats, channels = [], []
+    in_c = in_channels
     for i in range(depth):
         out_c = base_channels * (factor ** i)
-        if i == 0:
-            x = _two_conv_norm_relu(P, x, out_c, f'{prefix}0.')
-        else:
+        if i > 0:
             x = P.maxpool(x, 2, 2, 0)
-            x = _two_conv_norm_relu(P, x, out_c, f'{prefix}{i}.1.')
+        bp = f'{prefix}0.' if i == 0 else f'{prefix}{i}.1.'
+        x = _cd_res_block(P, x, in_c, out_c, bp) if res_blocks else _two_conv_norm_relu(P, x, out_c, bp)
         feats.append(x)
         channels.append(out_c)
+        in_c = out_c
     return feats, channels, [2 ** i for i in range(depth)]
 
 
@@ -349,7 +367,7 @@ def _resnet(P, x, in_channels, prefix, kind, base_channel=64, stem_fast=False, f
 # decoders
 # ---------------------------------------------------------------------------------------------------------------------
 
-def _generalized_unet(P, feats, channels, strides, prefix, subpixel=False):
+def _generalized_unet(P, feats, channels, strides, prefix, subpixel=False, res_blocks=False):
     """GeneralizedUNet (unet.py:62-249), default kwargs: nearest interpolation, cat_order 0, TwoConvNormRelu blocks,
     bridge blocks (bias=False) for the log2(first stride) missing levels.  The 1x1 ``inner`` conv is applied BEFORE
     the nearest upsample (bit-identical per pixel, 4x fewer MACs); the upsample itself and the channel concat are
@@ -379,7 +397,10 @@ def _generalized_unet(P, feats, channels, strides, prefix, subpixel=False):
         entries_inner[i] = P.entries[mark:]
         del P.entries[mark:]
         ouc = out_list[i]
-        if lat is not None:
+        if lat is not None and res_blocks:
+            last = _cd_res_block(P, lat, P.tensors[lat]['c'] + P.tensors[top]['c'], ouc, f'{prefix}layer_blocks.{i}.', src1=top,
+                                 up1=True, subpixel=subpixel)
+        elif lat is not None:
             last = _two_conv_norm_relu(P, lat, ouc, f'{prefix}layer_blocks.{i}.', bias=True, src1=top, up1=True,
                                        subpixel=subpixel)
         else:
@@ -434,6 +455,10 @@ for _k in _RESNETS:
     BACKBONES[f'{_k}UNet'] = ('unet', _k)
     BACKBONES[f'{_k}FPN'] = ('fpn', _k)
 BACKBONES['U22'] = ('unet', 'U22')
+# the other UNetEncoder-based U-Nets of models/unet.py:434-524: (fixed base_channels or None, ResBlocks?)
+_UNET_ENCODERS = {'U22': (None, False), 'SlimU22': (32, False), 'WideU22': (128, False), 'ResUNet': (None, True)}
+for _k in ('SlimU22', 'WideU22', 'ResUNet'):
+    BACKBONES[_k] = ('unet', _k)
 
 
 def _readout(P, x, cmid, cout, prefix, act, act_scale, out_index, k=7, fuse=True, up0=False, stride=1, deferred=False,
@@ -489,7 +514,7 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
                kernel_sizes: dict = None, fuse_bilinear: bool = True, contour_head_stride: int = 1,
                refinement_head_stride: int = 1, features: dict = None, sparse_heads: bool = False,
                subpixel: bool = False, stem_fast: bool = False, fuse_blocks: bool = False, hoist_heads: bool = True,
-               bilinear_phases: bool = False, head_activations: dict = None) -> Plan:
+               bilinear_phases: bool = False, head_activations: dict = None, refinement_full_res: bool = True) -> Plan:
     """Plan of ``Cpn<backbone>`` (celldetection/models/cpn.py:287-439,771-2061; heads: CPNCore.__init__
     cpn.py:125-236).  ``kernel_sizes``: optional {'score'|'location'|'fourier'|'uncertainty'|'refinement': k}
     (the reference's ``kernel_size_<head>`` kwargs, default 7).  ``contour_head_stride`` / ``refinement_head_stride``: stride
@@ -514,7 +539,8 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
     ``bilinear_phases`` (bf16 / fp8 plans): the refinement head over the bilinear-resized feature map (FPN models) additionally
     carries its sub-pixel decomposition (``_readout``).  ``head_activations``: optional {'score'|'location'|'fourier'|
     'uncertainty'|'refinement': plan activation name} = the reference's ``head_activation`` / ``head_activation_<head>`` kwargs
-    (cpn.py:183-233; default 'relu'; see ``head_activation_name``)."""
+    (cpn.py:183-233; default 'relu'; see ``head_activation_name``).  ``refinement_full_res=False``: the refinement head reads its
+    feature at the feature's resolution (cpn.py:276-279)."""
     ha = dict(score='relu', location='relu', fourier='relu', uncertainty='relu', refinement='relu')
     ha.update(head_activations or {})
     if any(v not in _ACT or v == 'tanh_scaled' for v in ha.values()):
@@ -536,9 +562,15 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
         P.entries.append(('order_weights', (order, 1), 'buffer'))
     x = P.input(in_channels)
     bp = 'core.backbone.'
-    if enc == 'U22':
+    res_blocks = False
+    if enc in _UNET_ENCODERS:
         ekw = dict(bkw.get('backbone_kwargs') or {})
-        feats, channels, strides = _unet_encoder(P, x, in_channels, bp + 'body.', **ekw)
+        base, res_blocks = _UNET_ENCODERS[enc]
+        if base is not None:
+            if 'base_channels' in ekw:  # SlimU22 / WideU22 pass base_channels themselves (unet.py:490,520)
+                raise TypeError(f"{enc}: got multiple values for keyword argument 'base_channels'")
+            ekw['base_channels'] = base
+        feats, channels, strides = _unet_encoder(P, x, in_channels, bp + 'body.', res_blocks=res_blocks, **ekw)
     else:
         ekw = dict(bkw.get('backbone_kwargs') or {})
         feats, channels, strides = _resnet(P, x, in_channels, bp + 'body.', enc, stem_fast=bool(stem_fast),
@@ -549,7 +581,7 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
     wanted = {k for name, v in feats_cfg.items() for k in _keys(v)
               if (name != 'uncertainty' or uncertainty_head) and (name != 'refinement' or refinement)}
     if family == 'unet':
-        results, out_list = _generalized_unet(P, feats, channels, strides, bp + 'unet.', subpixel=subpixel)
+        results, out_list = _generalized_unet(P, feats, channels, strides, bp + 'unet.', subpixel=subpixel, res_blocks=res_blocks)
         level = {str(i): (results[i], out_list[i]) for i in results}
         level.update({f'encoder.{i}': (feats[i], channels[i]) for i in range(len(feats))})
     else:
@@ -639,7 +671,9 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
         # U22: level 0 has the input size by construction (3x3 convs, padding 1)
         # bf16 / fp8 plans: the resize is fused into the head conv's halo loader (up0 = 'bilinear': the full-resolution
         # 256-channel map of the FPN models is never written); the fp32 verification plan keeps the separate op
-        resize = family == 'fpn' or enc != 'U22' or _keys(feats_cfg['refinement']) != ['0']
+        # refinement_full_res=False (cpn.py:276-279): the head runs at the feature's own resolution, its 2 * buckets output
+        # maps are resized to the input size instead (the engine's fp32 bilinear kernel, cpn._Engine.run)
+        resize = (family == 'fpn' or enc not in _UNET_ENCODERS or _keys(feats_cfg['refinement']) != ['0']) and refinement_full_res
         kr = ks.get('refinement', 7)
         fused_resize = resize and fuse_bilinear and kr > 1 and refinement_head_stride == 1
         r_low = None

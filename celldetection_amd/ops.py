@@ -69,21 +69,31 @@ def bucket_tables(samples: int, num_buckets: int, device):
 
 
 def fouriers2contours(fourier: Tensor, locations: Tensor, samples: int = 64, sampling=None, cache=None):
-    """celldetection/ops/cpn.py:44-95 (default sampling only). fourier [..., order, 4], locations [..., 2]
-    -> (contours [..., samples, 2], sampling)."""
-    if sampling is not None:
-        raise NotImplementedError('custom sampling is a training-time feature (out of scope)')
+    """celldetection/ops/cpn.py:44-95. fourier [..., order, 4], locations [..., 2] -> (contours [..., samples, 2], sampling).
+    ``sampling``: optional sampling positions t shared by all contours, Tensor[samples] (or [1, ..., samples]); the cos / sin
+    tables are built from it with the reference's expression (on the host, like the default table).  Per-contour samplings
+    (``sampling[b]`` of the training targets, cpn.py:606,641) are a training-time feature and raise."""
     _need_cuda(fourier, locations)
     lead = fourier.shape[:-2]
     order = fourier.shape[-2]
     f = fourier.reshape(-1, order, 4).contiguous().float()
     loc = locations.reshape(-1, 2).contiguous().float()
     P = f.shape[0]
-    cos_t, sin_t = sampling_tables(order, samples, f.device)
+    if sampling is not None:
+        sampling = torch.as_tensor(sampling)
+        if sampling.numel() != sampling.shape[-1]:
+            raise NotImplementedError('per-contour sampling tensors are a training-time feature (out of scope); pass one '
+                                      'sampling vector shared by all contours')
+        t = sampling.detach().reshape(-1).float().cpu()
+        samples = int(t.shape[0])
+        c = float(np.pi) * 2 * (torch.arange(1, order + 1)[..., None]) * t[None]  # ops/cpn.py:66-78
+        cos_t, sin_t = torch.cos(c).contiguous().to(f.device), torch.sin(c).contiguous().to(f.device)
+    else:
+        cos_t, sin_t = sampling_tables(order, samples, f.device)
     out = torch.empty((P, samples, 2), dtype=torch.float32, device=f.device)
     check(_lib.load().cpn_fouriers2contours(ptr(f), ptr(loc), P, order, samples, ptr(cos_t), ptr(sin_t), ptr(out),
                                             stream_ptr()), 'fouriers2contours')
-    return out.reshape(*lead, samples, 2), torch.linspace(0, 1.0, samples, device=f.device)
+    return out.reshape(*lead, samples, 2), (sampling if sampling is not None else torch.linspace(0, 1.0, samples, device=f.device))
 
 
 def local_refinement(contours: Tensor, refinement: Tensor, num_loops: int, b: Tensor, original_size=None,

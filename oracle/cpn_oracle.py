@@ -47,6 +47,23 @@ def _two_conv_norm_relu(x, sd, p):
     return F.relu(_bn(_conv(x, sd, p + '3.', padding=1), sd, p + '4.'))
 
 
+def _cd_res_block(x, sd, p):
+    """celldetection ``ResBlock`` (models/commons.py:259-359; the block of ResUNet, unet.py:434-464): conv3x3(no bias)-BN-ReLU-
+    conv3x3(no bias)-BN + identity (a 1x1 ConvNorm without bias when the channel counts differ), ReLU."""
+    identity = x
+    if (p + 'downsample.0.weight') in sd:
+        identity = _bn(_conv(x, sd, p + 'downsample.0.'), sd, p + 'downsample.1.')
+    out = F.relu(_bn(_conv(x, sd, p + 'block.0.', padding=1), sd, p + 'block.1.'))
+    out = _bn(_conv(out, sd, p + 'block.3.', padding=1), sd, p + 'block.4.')
+    return F.relu(out + identity)
+
+
+def _unet_block(x, sd, p):
+    """The U-Net's block class, recognised from the keys: TwoConvNormRelu (``0.`` / ``1.`` / ``3.`` / ``4.``) or ResBlock
+    (``block.*`` / ``downsample.*``)."""
+    return _cd_res_block(x, sd, p) if (p + 'block.0.weight') in sd else _two_conv_norm_relu(x, sd, p)
+
+
 def _has(sd, prefix):
     return any(k.startswith(prefix) for k in sd)
 
@@ -57,10 +74,10 @@ def _unet_encoder(x, sd, p):
     i = 0
     while _has(sd, f'{p}{i}.'):
         if i == 0:
-            x = _two_conv_norm_relu(x, sd, f'{p}0.')
+            x = _unet_block(x, sd, f'{p}0.')
         else:
             x = F.max_pool2d(x, 2, 2)
-            x = _two_conv_norm_relu(x, sd, f'{p}{i}.1.')
+            x = _unet_block(x, sd, f'{p}{i}.1.')
         feats[str(i)] = x
         i += 1
     return feats
@@ -127,7 +144,7 @@ def _generalized_unet(feats, sd, p, bridges):
         if (ip + 'weight') in sd:
             top = _conv(top, sd, ip)
         inp = torch.cat((lateral, top), 1) if lateral is not None else top
-        last_inner = _two_conv_norm_relu(inp, sd, f'{p}layer_blocks.{i}.')
+        last_inner = _unet_block(inp, sd, f'{p}layer_blocks.{i}.')
         results.insert(0, last_inner)
     return OrderedDict((str(i), r) for i, r in enumerate(results))
 
@@ -177,8 +194,18 @@ def _head_features(feats, keys, sd, fuse_prefix):
     return F.relu(_bn(_conv(x, sd, fuse_prefix + 'block.0.'), sd, fuse_prefix + 'block.1.'))
 
 
+def _resize(x, size, mode):
+    """``_equal_size`` (models/cpn.py:109-115): F.interpolate(x, size, mode=mode, align_corners=False) -- torch rejects the
+    align_corners argument for 'nearest', so that mode cannot run in the reference; 'nearest-exact' / 'area' would hit the same
+    error.  Modes that do run there: bilinear, bicubic."""
+    if x.shape[2:] == tuple(size):
+        return x
+    return F.interpolate(x, tuple(size), mode=mode, align_corners=False)
+
+
 def core_forward(state_dict, x, refinement_margin=3., with_uncertainty=False, contour_head_stride=1,
-                 refinement_head_stride=1, features=None, head_activations=None):
+                 refinement_head_stride=1, features=None, head_activations=None, refinement_interpolation='bilinear',
+                 refinement_full_res=True):
     """CPNCore.forward, models/cpn.py:238-283 -> (raw scores, locations, refinement, fourier), all fp32 NCHW
     (+ the sigmoid uncertainty map [N,4,h,w] or None as fifth element when ``with_uncertainty``).
 
@@ -190,7 +217,7 @@ def core_forward(state_dict, x, refinement_margin=3., with_uncertainty=False, co
     assert bool(torch.all(x >= 0.)) and bool(torch.all(x <= 1.)), 'Inputs should be in interval (0.0, 1.0)'
     p = 'core.backbone.'
     with torch.no_grad():
-        if sd[p + 'body.0.0.weight'].shape[-1] == 7:
+        if (p + 'body.0.0.weight') in sd and sd[p + 'body.0.0.weight'].shape[-1] == 7:
             feats = _resnet_body(x, sd, p + 'body.')
             bridges = 1
         else:
@@ -218,11 +245,10 @@ def core_forward(state_dict, x, refinement_margin=3., with_uncertainty=False, co
             uncertainty = torch.sigmoid(_readout(_head_features(feats, fk['uncertainty'], sd, 'core.uncertainty_fuse.'), sd,
                                                  'core.uncertainty_head.', hs, ha['uncertainty']))
         f0 = _head_features(feats, fk['refinement'], sd, 'core.refinement_fuse.')
-        if f0.shape[2:] != x.shape[2:]:  # cpn.py:277-278
-            f0 = F.interpolate(f0, x.shape[2:], mode='bilinear', align_corners=False)
+        if refinement_full_res:  # cpn.py:277-278
+            f0 = _resize(f0, x.shape[2:], refinement_interpolation)
         refinement = torch.tanh(_readout(f0, sd, 'core.refinement_head.', refinement_head_stride, ha['refinement'])) * refinement_margin
-        if refinement.shape[2:] != x.shape[2:]:
-            refinement = F.interpolate(refinement, x.shape[2:], mode='bilinear', align_corners=False)
+        refinement = _resize(refinement, x.shape[2:], refinement_interpolation)  # cpn.py:279
     if with_uncertainty:
         return scores, locations, refinement, fourier, uncertainty
     return scores, locations, refinement, fourier
@@ -232,21 +258,22 @@ def core_forward(state_dict, x, refinement_margin=3., with_uncertainty=False, co
 # 2. decode (numpy; index work bit-exact, float work in IEEE fp32 with the reference's operation order)
 # =====================================================================================================
 
-def sampling_table(order, samples):
-    """sin/cos table of ops/cpn.py:66-78: t = linspace(0,1,S); c = float(pi)*2*k*t (fp32); cos/sin via torch CPU
-    so that the bits equal the reference's CPU result."""
-    t = torch.linspace(0, 1.0, samples)
+def sampling_table(order, samples, sampling=None):
+    """sin/cos table of ops/cpn.py:66-78: t = linspace(0,1,S) (or the caller's ``sampling`` vector); c = float(pi)*2*k*t
+    (fp32); cos/sin via torch CPU so that the bits equal the reference's CPU result."""
+    t = torch.linspace(0, 1.0, samples) if sampling is None else torch.as_tensor(sampling, dtype=torch.float32).reshape(-1)
     c = float(np.pi) * 2 * (torch.arange(1, order + 1)[..., None]) * t[None]
     return torch.cos(c).numpy(), torch.sin(c).numpy()
 
 
-def fouriers2contours(fourier, locations, samples):
+def fouriers2contours(fourier, locations, samples, sampling=None):
     """ops/cpn.py:44-95: con = loc; con += sum_k(f[k,(1,3)]*sin_k); con += sum_k(f[k,(0,2)]*cos_k)
-    (fp32 products, sum over k in ascending order)."""
+    (fp32 products, sum over k in ascending order).  ``sampling``: one sampling vector shared by all contours."""
     fourier = np.asarray(fourier, np.float32)
     locations = np.asarray(locations, np.float32)
     order = fourier.shape[-2]
-    c_cos, c_sin = sampling_table(order, samples)
+    c_cos, c_sin = sampling_table(order, samples, sampling)
+    samples = c_cos.shape[-1]
     con = np.zeros(fourier.shape[:-2] + (samples, 2), np.float32) + locations[..., None, :]
     for cols, tab in (((1, 3), c_sin), ((0, 2), c_cos)):
         acc = None

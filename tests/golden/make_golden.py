@@ -126,6 +126,14 @@ MODEL_SPECS = {
                                                       head_activation_location='mish', head_activation_refinement='hardswish',
                                                       backbone_kwargs={'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}),
                                (1, 3, 64, 96)),
+    # round 6 (keep in sync with tests/model_specs.py)
+    'CpnResNet18UNet': ('CpnResNet18UNet', dict(in_channels=3, backbone_kwargs={'backbone_kwargs': {'base_channel': 8}}), (2, 3, 64, 96)),
+    'CpnResNet34UNet': ('CpnResNet34UNet', dict(in_channels=3, backbone_kwargs={'backbone_kwargs': {'base_channel': 8}}), (1, 3, 96, 64)),
+    'CpnResUNet': ('CpnResUNet', dict(in_channels=3, backbone_kwargs={'backbone_kwargs': {'base_channels': 8}}), (2, 3, 64, 96)),
+    'CpnSlimU22': ('CpnSlimU22', dict(in_channels=3), (1, 3, 64, 96)),
+    'CpnWideU22': ('CpnWideU22', dict(in_channels=1, order=3), (1, 1, 48, 64)),
+    'CpnResNet18FPN_lowres': ('CpnResNet18FPN', dict(in_channels=3, refinement_full_res=False, backbone_kwargs={
+        'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}), (2, 3, 64, 96)),
     'CpnResNet50UNet_feats': ('CpnResNet50UNet', dict(in_channels=3, score_features='2', contour_features='2',
                                                       location_features='2', refinement_features=['0', 'encoder.0'],
                                                       backbone_kwargs={'backbone_kwargs': {'base_channel': 8}}),
@@ -219,6 +227,17 @@ def gen_ops():
     out['stitch_overlaps'] = npy(overlaps)
     out['stitch_keep'] = npy(rops.filter_contours_by_stitching_rule(con, (48, 64), overlaps, rule='ex_br',
                                                                     offsets=offsets))
+    # G1b fouriers2contours with a caller-supplied sampling vector (appended in round 6 with its own generator: the arrays above
+    # keep their values)
+    g2 = torch.Generator().manual_seed(4242)
+    f = torch.randn(9, 6, 4, generator=g2) * 2
+    loc = torch.rand(9, 2, generator=g2) * 100
+    # (32 samples: with 2 * S a multiple of the SIMD block torch's CPU sum over `order` runs in ascending order -- for other S its
+    # remainder columns go through a 4-accumulator cascade, a machine-dependent order that only the 1e-4 tolerance tests cover)
+    samp = torch.sort(torch.rand(32, generator=g2)).values
+    con, samp_out = rops.fouriers2contours(f, loc, samples=5, sampling=samp)  # (`samples` is ignored then)
+    assert torch.equal(samp_out, samp) and con.shape == (9, 32, 2)
+    out['f2c_s_fourier'], out['f2c_s_loc'], out['f2c_s_sampling'], out['f2c_s_out'] = npy(f), npy(loc), npy(samp), npy(con)
     save('ops.npz', **out)
 
 
@@ -287,6 +306,8 @@ MODEL_CALIBRATION = {'CpnU22_classes4': dict(score_shift=-3.5),
                      'CpnResNet50UNet_feats': dict(score_shift=-.3, fourier_std=.25, location_std=.4),
                      'CpnU22_stride4': dict(score_shift=1.2, fourier_std=.07, location_std=.3, refinement_raw_std=.3),
                      'CpnU22_headact': _U22_SMALL, 'CpnResNet18FPN_headact': _FPN_DENSE,
+                     'CpnResNet18UNet': _U22_SMALL, 'CpnResNet34UNet': _U22_SMALL, 'CpnResUNet': _U22_SMALL, 'CpnSlimU22': _U22_SMALL,
+                     'CpnWideU22': _U22_SMALL, 'CpnResNet18FPN_lowres': _FPN_DENSE,
                      'CpnResNet18FPN_fuse': dict(score_shift=-.5, fourier_std=.4, location_std=.4),
                      'CpnResNet18FPN_fuse3': dict(score_shift=.5, fourier_std=.4, location_std=.4, refinement_raw_std=.3),
                      'CpnResNet18FPN_fuse5': dict(score_shift=.5, fourier_std=.4, location_std=.4, refinement_raw_std=.3)}
@@ -505,6 +526,44 @@ def gen_labels():
     save('labels.npz', **out)
 
 
+def gen_behaviours():
+    """Error behaviour of options of the built rows, RECORDED from the imported reference: what
+    ``CPN.forward`` does with ``functional=True`` and with a non-interpolating ``refinement_interpolation``."""
+    import json
+    rec = {}
+
+    def run(fn):
+        try:
+            fn()
+            return None
+        except Exception as e:
+            return dict(type=type(e).__name__, message=str(e))
+
+    tiny = dict(backbone_kwargs={'backbone_kwargs': {'base_channels': 8}})
+    m = cd.models.CpnU22(3, **tiny).eval()
+    m.functional = True
+    x = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        # default init: no pixel above the threshold -> the empty advanced index does not fail; with proposals it does
+        y = m(x)
+        rec['functional_true_no_proposals'] = dict(error=None, fourier_shape=list(y['fourier'][0].shape),
+                                                   contours_shape=list(y['contours'][0].shape))
+        m.core.score_head.block[4].bias += 6.
+        rec['functional_true_with_proposals'] = run(lambda: m(x))
+        fpn = dict(backbone_kwargs={'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}})
+        for mode in ('nearest', 'area', 'nearest-exact'):
+            mm = cd.models.CpnResNet18FPN(3, refinement_interpolation=mode, **fpn).eval()
+            rec[f'refinement_interpolation_{mode}_fpn_forward'] = run(lambda: mm(x))
+        # U22: level 0 has the input size -> no resize -> the mode is never used
+        mu = cd.models.CpnU22(3, refinement_interpolation='nearest', **tiny).eval()
+        rec['refinement_interpolation_nearest_u22_forward'] = run(lambda: mu(x))
+        rec['slimu22_base_channels_kwarg'] = run(lambda: cd.models.CpnSlimU22(3, backbone_kwargs={'backbone_kwargs': {'base_channels': 8}}))
+    path = os.path.join(HERE, 'reference_behaviours.json')
+    with open(path, 'w') as f:
+        json.dump(rec, f, indent=1, sort_keys=True)
+    print(json.dumps(rec, indent=1))
+
+
 FORWARD_TILED_CASES = [
     # name, crop, stride, kwargs of forward_tiled (inputs_mask: built below)
     ('default', 96, 64, dict()),
@@ -658,9 +717,11 @@ def gen_checkpoint():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['ops', 'tiling', 'models', 'stitch', 'checkpoint', 'labels', 'preprocess', 'forward_tiled']
+    which = sys.argv[1:] or ['ops', 'tiling', 'models', 'stitch', 'checkpoint', 'labels', 'preprocess', 'forward_tiled', 'behaviours']
     if 'forward_tiled' in which:
         gen_forward_tiled()
+    if 'behaviours' in which:
+        gen_behaviours()
     if 'preprocess' in which:
         gen_preprocess()
     if 'labels' in which:

@@ -573,6 +573,18 @@ def test_fouriers2contours_golden(dev, gops, tag, samples):
     np.testing.assert_array_equal(out.cpu().numpy(), gops[f'f2c_{tag}_out'])
 
 
+def test_fouriers2contours_custom_sampling_golden(dev, gops):
+    """``sampling=`` of ops/cpn.py:44-95: one caller-supplied sampling vector shared by all contours (golden from the reference)."""
+    from celldetection_amd import ops
+    samp = torch.as_tensor(gops['f2c_s_sampling'])
+    out, s_out = ops.fouriers2contours(torch.as_tensor(gops['f2c_s_fourier']).to(dev), torch.as_tensor(gops['f2c_s_loc']).to(dev),
+                                       samples=5, sampling=samp.to(dev))
+    np.testing.assert_array_equal(out.cpu().numpy(), gops['f2c_s_out'])
+    assert torch.equal(s_out.cpu(), samp)
+    with pytest.raises(NotImplementedError):
+        ops.fouriers2contours(torch.zeros(9, 6, 4, device=dev), torch.zeros(9, 2, device=dev), sampling=torch.rand(9, 32))
+
+
 def test_local_refinement_golden(dev, gops):
     from celldetection_amd import ops
     for iters in (1, 4):

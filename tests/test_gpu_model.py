@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from model_specs import ALL_SPECS, HEAD_SPECS, MODEL_SPECS, SIZE_SPECS, VARIANT_SPECS
+from model_specs import ALL_SPECS, HEAD_SPECS, MODEL_SPECS, SIZE_SPECS, VARIANT_SPECS, bf16_bounds
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
@@ -150,8 +150,34 @@ def test_conv_stack_vs_reference_maps(dev, name):
         rel = (err.norm() / (e.norm() + 1e-12)).item()
         report[key] = (rel, err.max().item(), e.abs().max().item())
     print(name, {k: f'relL2 {v[0]:.3e} max {v[1]:.3e} (ref max {v[2]:.2e})' for k, v in report.items()})
+    bounds, _ = bf16_bounds(name)  # 2 x the error measured on the MI355X (tests/golden/bf16_measured.json)
     for key, (rel, mx, ref_mx) in report.items():
-        assert rel < 6e-2, f'{name} {key}: relative L2 error {rel:.3e}'
+        assert rel < bounds[key], f'{name} {key}: relative L2 error {rel:.3e} (bound {bounds[key]:.3e})'
+
+
+@pytest.mark.parametrize('name', ['CpnU22', 'CpnResNeXt101UNet', 'CpnResNet18FPN', 'CpnResNet50FPN', 'CpnResNet18UNet'])
+def test_bf16_gates_catch_a_one_ulp_weight_perturbation(dev, name):
+    """the bf16 gates (2 x the measured error, tests/golden/bf16_measured.json) are the only model-level guard on
+    the product kernels, so they must notice a kernel-sized regression.  Here every packed bf16 weight of the engine is moved by
+    ONE ulp away from zero (bit pattern + 1: twice the rounding error the weights already carry, in one direction) -- at least one
+    head map must leave its bound."""
+    model, g = build(name, dev)
+    x = torch.as_tensor(g['x']).to(dev)
+    exp = dict(scores=torch.sigmoid(torch.as_tensor(g['core.scores'])), locations=torch.as_tensor(g['core.locations']),
+               refinement=torch.as_tensor(g['core.refinement']), fourier=torch.as_tensor(g['core.fourier']))
+    bounds, _ = bf16_bounds(name)
+    rel = lambda maps: {k: ((m.cpu() - exp[k]).norm() / (exp[k].norm() + 1e-12)).item()
+                        for k, m in zip(('scores', 'locations', 'refinement', 'fourier'), maps)}
+    clean = rel(model.core_forward(x))
+    assert all(clean[k] < bounds[k] for k in clean), (clean, bounds)
+    eng = model.engine(dev)
+    assert eng.wblob.dtype == torch.bfloat16
+    eng.wblob.view(torch.int16).add_(1)  # in place: the native plan reads this very buffer
+    torch.cuda.synchronize()
+    bad = rel(model.core_forward(x))
+    print(name, 'clean', {k: f'{v:.3e}' for k, v in clean.items()}, 'perturbed', {k: f'{v:.3e}' for k, v in bad.items()},
+          'bounds', {k: f'{v:.3e}' for k, v in bounds.items()})
+    assert any(bad[k] >= bounds[k] for k in bad), 'a 1-ulp perturbation of every weight passes the bf16 gates'
 
 
 def _iou_match_rate(boxes_a, boxes_b, thr=.5):
@@ -180,7 +206,7 @@ def test_end_to_end_match_rate(dev, name):
         # measured (round 2, six model families): match rates 0.956 .. 1.0, counts within a few per cent
         assert abs(n_ref - n_got) <= max(3, 0.1 * n_ref), f'{name}[{i}]: proposals {n_got} vs reference {n_ref}'
     print(name, 'proposal IoU>0.5 match rates', rates)
-    assert min(rates) > .9, rates
+    assert min(rates) > bf16_bounds(name)[1], (rates, bf16_bounds(name)[1])  # measured - 0.03
     y = model(x)  # with NMS: output contract
     assert list(y.keys()) == ['contours', 'boxes', 'scores', 'classes', 'locations', 'fourier', 'contour_proposals',
                               'box_uncertainties']
@@ -408,7 +434,7 @@ def test_variant_fp32_end_to_end_and_bf16_stack(dev, name):
                fourier=torch.as_tensor(g['core.fourier']))
     if 'core.uncertainty' in g.files:
         exp['uncertainty'] = torch.as_tensor(g['core.uncertainty'])
-    for precision, tol in (('bf16', 6e-2), ('fp32', 2e-4)):
+    for precision, tol in (('bf16', None), ('fp32', 2e-4)):
         model.precision = precision
         s, l, r, f = [t.cpu() for t in model.core_forward(x)]
         got = dict(scores=s, locations=l, refinement=r, fourier=f)
@@ -418,7 +444,8 @@ def test_variant_fp32_end_to_end_and_bf16_stack(dev, name):
             assert got[key].shape == e.shape, (key, got[key].shape, e.shape)
             rel = ((got[key] - e).norm() / (e.norm() + 1e-12)).item()
             print(name, precision, key, f'relL2 {rel:.3e}')
-            assert rel < tol, (name, precision, key, rel)
+            bound = bf16_bounds(name)[0][key] if tol is None else tol  # bf16: 2 x the error measured on the MI355X
+            assert rel < bound, (name, precision, key, rel, bound)
     n = x.shape[0]  # fp32 path end to end
     check_exact('nms', model(x), g, n, raw_atol=5e-4, flip_frac=1e-3)
     check_exact('nonms', model(x, nms=False), g, n, raw_atol=5e-4, flip_frac=1e-3)
@@ -652,14 +679,15 @@ def test_arbitrary_input_sizes(dev, name):
                                             scores_lower_bound=torch.as_tensor(g['scores_lower_bound']).to(dev)), g, n)
     exp = dict(scores=torch.sigmoid(torch.as_tensor(g['core.scores'])), locations=torch.as_tensor(g['core.locations']),
                refinement=torch.as_tensor(g['core.refinement']), fourier=torch.as_tensor(g['core.fourier']))
-    for precision, tol in (('bf16', 6e-2), ('fp32', 2e-4)):
+    for precision, tol in (('bf16', None), ('fp32', 2e-4)):
         model.precision = precision
         got = dict(zip(('scores', 'locations', 'refinement', 'fourier'), [t.cpu() for t in model.core_forward(x)]))
         for key, e in exp.items():
             assert got[key].shape == e.shape, (key, got[key].shape, e.shape)
             rel = ((got[key] - e).norm() / (e.norm() + 1e-12)).item()
             print(name, precision, key, f'relL2 {rel:.3e}')
-            assert rel < tol, (name, precision, key, rel)
+            bound = bf16_bounds(name)[0][key] if tol is None else tol  # bf16: 2 x the error measured on the MI355X
+            assert rel < bound, (name, precision, key, rel, bound)
     check_exact('nms', model(x), g, n, raw_atol=5e-4, flip_frac=1e-3)  # fp32 path, whole forward
     check_exact('nonms', model(x, nms=False), g, n, raw_atol=5e-4, flip_frac=1e-3)
 
@@ -849,14 +877,15 @@ def test_head_options(dev, name):
     check_exact('offs', model.postprocess(*maps, size, offsets=torch.as_tensor(g['offsets'])), g, n)
     exp = dict(scores=torch.sigmoid(torch.as_tensor(g['core.scores'])), locations=torch.as_tensor(g['core.locations']),
                refinement=torch.as_tensor(g['core.refinement']), fourier=torch.as_tensor(g['core.fourier']))
-    for precision, tol in (('bf16', 6e-2), ('fp32', 2e-4)):
+    for precision, tol in (('bf16', None), ('fp32', 2e-4)):
         model.precision = precision
         got = dict(zip(('scores', 'locations', 'refinement', 'fourier'), [t.cpu() for t in model.core_forward(x)]))
         for key, e in exp.items():
             assert got[key].shape == e.shape, (key, got[key].shape, e.shape)
             rel = ((got[key] - e).norm() / (e.norm() + 1e-12)).item()
             print(name, precision, key, f'relL2 {rel:.3e}')
-            assert rel < tol, (name, precision, key, rel)
+            bound = bf16_bounds(name)[0][key] if tol is None else tol  # bf16: 2 x the error measured on the MI355X
+            assert rel < bound, (name, precision, key, rel, bound)
     check_exact('nms', model(x), g, n, raw_atol=5e-4, flip_frac=1e-3)  # fp32 path, whole forward
 
 
@@ -887,7 +916,7 @@ def test_bilinear_phase_refinement_head_on_golden_models(dev, name, monkeypatch)
     e_old, e_new, e_pair = rel(old, ref), rel(new, ref), rel(new, old)
     print(f'{name}: refinement map relL2 vs fp32 reference: resized-map conv {e_old:.3e}, phases + frame {e_new:.3e}; '
           f'between the two {e_pair:.3e}')
-    assert e_new < 6e-2 and e_new < 1.25 * e_old + 1e-3 and e_pair < 2e-2
+    assert e_old < bf16_bounds(name)[0]['refinement'] and e_new < 1.25 * e_old + 1e-3 and e_pair < 2e-2
     for a, b in zip(m1.core_forward(x)[:2], m0.core_forward(x)[:2]):  # the other head maps are untouched
         assert torch.equal(a, b)
     # the frame really comes from the frame op and the interior from the phase convs: both regions carry finite, distinct values
@@ -1038,3 +1067,36 @@ def test_bilinear_phase_frame_pixels_identical_any_size(dev, size, monkeypatch):
     rel = (inner.norm() / (old[..., f:-f, f:-f].norm() + 1e-12)).item()
     print(size, 'interior relL2 between phases and the conv over the resized map', f'{rel:.3e}')
     assert 0 < rel < 5e-2
+
+
+def test_error_behaviour_of_options_recorded_from_the_reference(dev):
+    """options of built rows whose behaviour in the reference IS an error (tests/golden/reference_behaviours.json,
+    recorded by make_golden.py gen_behaviours from the imported reference) behave the same here -- no NotImplementedError in
+    their place: ``functional=True`` (IndexError as soon as there is a proposal, empty outputs with a [0, 2 * order, 2] Fourier
+    tensor otherwise) and a non-interpolating ``refinement_interpolation`` (torch's ValueError where a resize is needed, nothing
+    where none is)."""
+    import json
+    import celldetection_amd as cda
+    with open(os.path.join(G, 'reference_behaviours.json')) as f:
+        rec = json.load(f)
+    model, g = build('CpnU22', dev)
+    x = torch.as_tensor(g['x']).to(dev)
+    model.functional = True
+    e = rec['functional_true_with_proposals']
+    assert e['type'] == 'IndexError'
+    with pytest.raises(IndexError, match=e['message']):
+        model(x)
+    model.score_thresh = 1.1  # no proposals
+    y = model(x)
+    assert list(y['fourier'][0].shape) == rec['functional_true_no_proposals']['fourier_shape']
+    assert list(y['contours'][0].shape) == rec['functional_true_no_proposals']['contours_shape']
+    fpn = dict(backbone_kwargs={'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}})
+    for mode in ('nearest', 'area', 'nearest-exact'):
+        e = rec[f'refinement_interpolation_{mode}_fpn_forward']
+        m = cda.models.CpnResNet18FPN(3, refinement_interpolation=mode, **fpn).to(dev)
+        with pytest.raises(ValueError, match='align_corners option can only be set'):
+            m(x)
+        assert e['type'] == 'ValueError' and e['message'].startswith('align_corners option can only be set')
+    assert rec['refinement_interpolation_nearest_u22_forward'] is None
+    mu = cda.models.CpnU22(3, refinement_interpolation='nearest', backbone_kwargs={'backbone_kwargs': {'base_channels': 8}}).to(dev)
+    mu(x)  # level 0 has the input size: no resize, the mode is never used

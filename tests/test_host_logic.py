@@ -468,3 +468,52 @@ def test_bilinear_triple_in_fpn_plans(monkeypatch):
     assert abs(saved - (1024 * 49 - 94 * 49 - 4 * 256 * 25) * tile) < 1e-3 * head
     head8 = 2. * 512 * 512 * 64 * 32 * 49  # (fp8 plans pad channels to 64)
     assert f8['0'][1] == f8[None][1] and 0.3 * head8 < f8['0'][0] - f8[None][0] < 0.5 * head8
+
+
+def test_unet_family_constructors_follow_the_reference():
+    """CpnSlimU22 / CpnWideU22 / CpnResUNet (models/cpn.py:811-927, unet.py:434-524): state-dict keys and shapes equal the
+    reference's (recorded in the golden fixtures); SlimU22 / WideU22 pass ``base_channels`` themselves, so a caller's value is the
+    reference's TypeError (tests/golden/reference_behaviours.json)."""
+    import json
+    import celldetection_amd as cda
+    from model_specs import ALL_SPECS, G, ref_template_state_dict
+    for name in ('CpnSlimU22', 'CpnWideU22', 'CpnResUNet', 'CpnResNet18UNet', 'CpnResNet34UNet', 'CpnResNet18FPN_lowres'):
+        spec = ALL_SPECS[name]
+        m = getattr(cda.models, spec['cls'])(**spec['kwargs'])
+        tmpl = ref_template_state_dict(name)
+        sd = m.state_dict()
+        assert list(sd.keys()) == list(tmpl.keys()), name
+        assert all(tuple(sd[k].shape) == tuple(tmpl[k].shape) for k in sd), name
+    with open(os.path.join(G, 'reference_behaviours.json')) as f:
+        rec = json.load(f)
+    assert rec['slimu22_base_channels_kwarg']['type'] == 'TypeError'
+    for cls in ('CpnSlimU22', 'CpnWideU22'):
+        with pytest.raises(TypeError, match="multiple values for keyword argument 'base_channels'"):
+            getattr(cda.models, cls)(3, backbone_kwargs={'backbone_kwargs': {'base_channels': 8}})
+
+
+def test_every_unet_backbone_packs_into_a_valid_native_plan():
+    """Plan.hoist must never split a fused pair / bridge unit -- every UNet backbone's default bf16 plan (heads
+    hoisted, sub-pixel decoders, fused bridge) is accepted by cpn_plan_create (which validates the op order; no GPU needed)."""
+    from ctypes import c_void_p
+    import celldetection_amd as cda
+    from celldetection_amd import _lib, graph
+    lib = _lib.load()
+    tiny = {'backbone_kwargs': {'base_channel': 8}}
+    for bb in ('ResNet18UNet', 'ResNet34UNet', 'ResNet50UNet', 'ResNeXt101UNet', 'WideResNet50UNet'):
+        for hoist in (True, False):
+            m = getattr(cda.models, 'Cpn' + bb)(3, backbone_kwargs=tiny)
+            P = graph.build_plan(bb, 3, backbone_kwargs=tiny, subpixel=True, stem_fast=True, fuse_blocks=True,
+                                 bilinear_phases=True, hoist_heads=hoist)
+            tens, ops, w, b = graph.pack(P, m.state_dict(), 'cpu', 'bf16')
+            h = c_void_p()
+            rc = lib.cpn_plan_create(h, tens, len(tens), ops, len(ops), _lib.ptr(w), w.numel() * 2, _lib.ptr(b), b.numel(),
+                                     _lib.PRECISION_BF16)
+            assert rc == 0, (bb, hoist, lib.cpn_last_error())
+            lib.cpn_plan_destroy(h)
+            for i, o in enumerate(P.ops):  # a fused op sits right behind the two convs it restates
+                if o['op'] in ('conv_pair', 'conv_bridge'):
+                    assert o['first'] == i - 2 and P.ops[i - 1]['src0'] == P.ops[i - 2]['dst']
+            if hoist:  # the heads did move in front of the bridge level
+                names = [o.get('w') for o in P.ops]
+                assert names.index('core.score_head.block.0.') < names.index('core.backbone.unet.layer_blocks.0.0.')

@@ -24,6 +24,11 @@ def test_fouriers2contours_bit_exact(ops, tag, samples):
     np.testing.assert_array_equal(out, ops[f'f2c_{tag}_out'])
 
 
+def test_fouriers2contours_custom_sampling_bit_exact(ops):
+    out = orc.fouriers2contours(ops['f2c_s_fourier'], ops['f2c_s_loc'], 5, sampling=ops['f2c_s_sampling'])
+    np.testing.assert_array_equal(out, ops['f2c_s_out'])
+
+
 def test_local_refinement_bit_exact(ops):
     for iters in (1, 4):
         res, all_res = orc.local_refinement(ops['refine_in'], ops['refine_map'], ops['refine_b'], iters, (24, 40))

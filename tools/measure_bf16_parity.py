@@ -1,0 +1,54 @@
+"""Measures, on an MI355X, what the bf16 product kernels do on every golden model fixture: relative L2 error of the head maps
+against the reference's fp32 maps and the IoU > 0.5 match rate of the proposals (nms=False) against the reference's.
+Writes tests/golden/bf16_measured.json (run through gpurun: into gpurun_out/, then copy); the GPU tests gate on
+2 x the measured error and measured - 0.03 match rate (tests/model_specs.py bf16_bounds) -- VERDICT r5 item 3.
+
+    python tools/measure_bf16_parity.py [out.json]
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p_ in (ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'oracle')):
+    sys.path.insert(0, p_)
+from model_specs import ALL_SPECS  # noqa: E402
+from test_gpu_model import _iou_match_rate, build  # noqa: E402
+
+
+def measure(name, dev):
+    model, g = build(name, dev)
+    x = torch.as_tensor(g['x']).to(dev)
+    maps = [t.cpu() for t in model.core_forward(x)]
+    sc = torch.as_tensor(g['core.scores'])
+    multi = sc.shape[1] > 1
+    exp = dict(scores=sc if multi else torch.sigmoid(sc), locations=torch.as_tensor(g['core.locations']),
+               refinement=torch.as_tensor(g['core.refinement']), fourier=torch.as_tensor(g['core.fourier']))
+    rel = {k: float((m - exp[k]).norm() / (exp[k].norm() + 1e-12)) for k, m in zip(('scores', 'locations', 'refinement', 'fourier'), maps)}
+    if 'core.uncertainty' in g.files and model._last_uncertainty is not None:
+        e = torch.as_tensor(g['core.uncertainty'])
+        rel['uncertainty'] = float((model._last_uncertainty.cpu() - e).norm() / (e.norm() + 1e-12))
+    y = model(x, nms=False)
+    rates = [_iou_match_rate(y['boxes'][i].cpu().numpy(), g[f'nonms.boxes.{i}']) for i in range(x.shape[0])]
+    counts = [[int(len(y['scores'][i])), int(len(g[f'nonms.scores.{i}']))] for i in range(x.shape[0])]
+    return dict(rel=rel, match=min(rates), proposals_hip_ref=counts)
+
+
+def main():
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'tests', 'golden', 'bf16_measured.json')
+    dev = torch.device('cuda:0')
+    res = {}
+    for name in ALL_SPECS:
+        res[name] = measure(name, dev)
+        print(name, json.dumps(res[name]), flush=True)
+    meta = dict(device=torch.cuda.get_device_name(0), note='bf16 product kernels vs the reference fp32 fixtures; gates: '
+                'rel < 2 x measured (floor 2e-3), match > measured - 0.03 (tests/model_specs.py)')
+    with open(out, 'w') as f:
+        json.dump(dict(meta=meta, fixtures=res), f, indent=1, sort_keys=True)
+
+
+if __name__ == '__main__':
+    main()
