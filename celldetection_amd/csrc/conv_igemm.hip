@@ -52,6 +52,7 @@
 namespace CPN_NS {
 using namespace cpn;
 
+
 #if CPN_FP8
 typedef unsigned char elem_t;    // e4m3
 #else
@@ -139,6 +140,9 @@ __device__ __forceinline__ void add_res8(float (&v)[8], const store8_t r, float)
 #endif
 #ifndef CPN_S1F_DEFAULT
 #define CPN_S1F_DEFAULT 1  // see flat_ok
+#endif
+#ifndef CPN_WAVE_PRIO
+#define CPN_WAVE_PRIO 1  // alternating wave priority in the e4m3 main loop of the 8-wave tiles (bf16: measured negative)
 #endif
 // MODE_S1F (round 5) = MODE_S1 for TWO co-resident 4-wave workgroups per CU (tile 8 x 32 px x 128 cout, the flagship's 128 px x
 // 64 cout wave tile): a tile's head (first DMA round trip) and tail (LDS-staged epilogue + 64 KiB of stores, MFMA idle) overlap
@@ -290,19 +294,24 @@ __device__ __forceinline__ void wait_frags(frag_t (&w)[WN], frag_t (&p)[WM]) {
     else
         asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(w[0]), "+v"(p[0]) : "n"(N));
 }
+#ifdef CPN_EXP_NOVMWAIT  // tuning ablation (races by construction): the step boundary does not wait for the DMA
+#define CPN_WAIT_ALL_ASM "s_waitcnt lgkmcnt(0)"
+#else
+#define CPN_WAIT_ALL_ASM "s_waitcnt vmcnt(0) lgkmcnt(0)"
+#endif
 // step boundary: all my DMA landed + all my LDS reads returned (fragment set named "+v" as above)
 template <int WN, int WM>
 __device__ __forceinline__ void wait_all(frag_t (&w)[WN], frag_t (&p)[WM]) {
     if constexpr (WN == 2 && WM == 4)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]) :: "memory");
+        asm volatile(CPN_WAIT_ALL_ASM : "+v"(w[0]), "+v"(w[1]), "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]) :: "memory");
     else if constexpr (WN == 2 && WM == 2)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(p[0]), "+v"(p[1]) :: "memory");
+        asm volatile(CPN_WAIT_ALL_ASM : "+v"(w[0]), "+v"(w[1]), "+v"(p[0]), "+v"(p[1]) :: "memory");
     else if constexpr (WN == 2 && WM == 1)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(p[0]) :: "memory");
+        asm volatile(CPN_WAIT_ALL_ASM : "+v"(w[0]), "+v"(w[1]), "+v"(p[0]) :: "memory");
     else if constexpr (WN == 1 && WM == 2)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(w[0]), "+v"(p[0]), "+v"(p[1]) :: "memory");
+        asm volatile(CPN_WAIT_ALL_ASM : "+v"(w[0]), "+v"(p[0]), "+v"(p[1]) :: "memory");
     else
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(w[0]), "+v"(p[0]) :: "memory");
+        asm volatile(CPN_WAIT_ALL_ASM : "+v"(w[0]), "+v"(p[0]) :: "memory");
 }
 template <int WN, int WM, int FRAG_STRIDE>
 __device__ __forceinline__ void load_frags(frag_t (&w)[WN], frag_t (&p)[WM], unsigned paddr, unsigned waddr) {
@@ -375,6 +384,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave / C::WAVES_N;
     const int wave_n = wave % C::WAVES_N;
+    constexpr bool prio_wave = C::NWAVES == 8;  // (two waves per SIMD: alternating priority in the e4m3 main loop)
 
     // ---- block coordinates
     const int tiles_x = (a.Wout + TW - 1) / TW;
@@ -880,6 +890,81 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
     }
     unsigned pa = ITEM_PADDR(i0.c, i0.ky, i0.kx);
     unsigned wa = (unsigned) ldsW_off + w_lane;
+#ifndef CPN_FP8_HALFSETS
+    // Round 6: WHOLE operand sets alternate (set 0 = X|Y of a step's first item, set 1 = of its second): the twelve reads of the
+    // next item are issued in front of the eight MFMAs of the current one, so no MFMA group waits for a read that was issued right
+    // in front of it.  (Rounds 3-5 alternated half sets -- Y of item i and X of item i+1 in flight per group: the MFMAs of item 0
+    // waited for Y0 issued two instructions earlier, the step boundary for Y1 issued right in front of it: two exposed LDS
+    // latencies per step with BOTH waves of a SIMD in lockstep behind the workgroup barrier, MFMA busy 0.64 of the CU cycles at
+    // all-zero operands, profiles/r05_kernel_experiments.txt #8.)  Same registers, same K order per accumulator: bit-identical.
+    // The step boundary's DMA issue (four 1-KiB LDS-DMA instructions per wave + the chunk's halo rows) and the reads of the next
+    // step's first item sit BETWEEN the two halves of item 1's MFMA group, whose operands are in registers.
+#define MMA4(WX, WY, PX, PY, J)                                                                                \
+    _Pragma("unroll") for (int f = 0; f < WM; ++f)                                                             \
+        acc[J][f] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                           \
+            CAT8(WX[J], WY[J]), CAT8(PX[f], PY[f]), acc[J][f], 0, 0, 0, 127, 0, 127);
+#define PIN_ACC(J) asm volatile("" : "+v"(acc[J][0]), "+v"(acc[J][1]), "+v"(acc[J][2]), "+v"(acc[J][3]))
+    static_assert(WN == 2 || WN == 1, "fp8 main loop: one or two weight fragments per wave");
+    LOAD_GROUP(wX0, pX0, pa, wa);
+    LOAD_GROUP(wY0, pY0, pa ^ 16u, wa ^ 16u);
+    for (int st = 0; st + 1 < nsteps; ++st) {
+#if CPN_WAVE_PRIO
+        // Alternating wave priority (round 6): the two waves of a SIMD (w and w + NWAVES / 2) share its matrix pipe, arbitrated by
+        // priority, then AGE -- at equal priority the older wave's MFMAs always go first, it reaches the barrier ~900 cycles before
+        // its partner (s_memtime stamps, profiles/r06_kernel_experiments.txt) and idles there while the partner runs its remaining
+        // MFMA groups and gaps alone.  From the barrier to the middle of a step the younger half has priority, from there to the
+        // barrier the older half: each wave gets its MFMA groups through while the other is in its DMA-issue / fragment-read gaps.
+        if (prio_wave) { if (wave >= C::NWAVES / 2) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+#endif
+        const unsigned pa1 = ITEM_PADDR(i1.c, i1.ky, i1.kx), wa1 = wa + WITEM;
+        LOAD_GROUP(wX1, pX1, pa1, wa1);               // item 1 (both parts) in flight behind ...
+        LOAD_GROUP(wY1, pY1, pa1 ^ 16u, wa1 ^ 16u);
+        wait_frags<2 * NF, WN, WM>(wX0, pX0);         // ... item 0, whose reads have returned
+        MMA8(wX0, wY0, pX0, pY0, 2 * NF);             // item 0
+        if constexpr (WM == 4 && WN == 2) {           // (issued in FRONT of the boundary: 8 x 64 cycles of queued matrix work
+            PIN_ACC(0);                               // cover the wait for the DMA and the barrier; left to itself hipcc sinks
+            PIN_ACC(1);                               // seven of the eight behind the barrier)
+        }
+        const ItemState n0i = next_item(i1, KH, KW);  // first item of step st+1
+        wait_all<WN, WM>(wY1, pY1);                   // my DMA for step st+1 landed, all my LDS reads returned
+        wait_frags<0, WN, WM>(wX1, pX1);              // (names the X set of item 1 as complete, too)
+#ifndef CPN_EXP_NOBAR  // (tuning ablation: wrong results)
+        __builtin_amdgcn_s_barrier();
+#endif
+#if CPN_WAVE_PRIO
+        if (prio_wave) { if (wave >= C::NWAVES / 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#endif
+        if constexpr (WM == 4 && WN == 2) {
+            MMA4(wX1, wY1, pX1, pY1, 0);              // item 1, first weight fragment (operands in registers)
+            PIN_ACC(0);
+        }
+        ISSUE_AT_TRANSITION(n0i, st + 1, n0i.c != i0.c);
+        pa = ITEM_PADDR(n0i.c, n0i.ky, n0i.kx);
+        wa = (unsigned) (ldsW_off + ((st + 1) & 1) * WBUF) + w_lane;
+        LOAD_GROUP(wX0, pX0, pa, wa);                 // item 0 of step st+1 (both parts)
+        LOAD_GROUP(wY0, pY0, pa ^ 16u, wa ^ 16u);
+        if constexpr (WM == 4 && WN == 2) {
+            asm volatile("" : "+v"(wX1[1]), "+v"(wY1[1]));  // (keeps the MFMAs below behind the reads above)
+            MMA4(wX1, wY1, pX1, pY1, 1);              // item 1, second weight fragment
+        } else {
+            MMA8(wX1, wY1, pX1, pY1, 2 * NF);
+        }
+        CPN_BL_FLUSH();
+        i0 = n0i;
+        i1 = next_item(n0i, KH, KW);
+    }
+    {   // last step (two items: an odd item count was padded with a zero slab)
+        const unsigned pa1 = ITEM_PADDR(i1.c, i1.ky, i1.kx), wa1 = wa + WITEM;
+        LOAD_GROUP(wX1, pX1, pa1, wa1);
+        LOAD_GROUP(wY1, pY1, pa1 ^ 16u, wa1 ^ 16u);
+        wait_frags<2 * NF, WN, WM>(wX0, pX0);
+        MMA8(wX0, wY0, pX0, pY0, 2 * NF);
+        wait_frags<0, WN, WM>(wX1, pX1);
+        MMA8(wX1, wY1, pX1, pY1, 0);
+    }
+#undef MMA4
+#undef PIN_ACC
+#else
     LOAD_GROUP(wX0, pX0, pa, wa);
     wait_frags<0, WN, WM>(wX0, pX0);
     for (int st = 0; st + 1 < nsteps; ++st) {
@@ -911,6 +996,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
         wait_frags<NF, WN, WM>(wX1, pX1);
         MMA8(wX1, wY1, pX1, pY1, 0);
     }
+#endif
 #undef MMA8
 #undef CAT8
 #else
