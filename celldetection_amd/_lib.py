@@ -10,7 +10,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CPN_HIP_LIB') or os.path.join(HERE, 'libcpn_hip.so')  # env: kernel A/B tuning only
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 PRECISION_BF16, PRECISION_F32, PRECISION_FP8 = 0, 1, 2
 E_INVALID, E_UNSUPPORTED, E_WORKSPACE = -1, -2, -3
 
@@ -110,6 +110,7 @@ _SIGNATURES = [
                                        c_int32, c_void_p, c_void_p]),
     ('cpn_resize_bilinear_f32', ctypes.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
                                                c_void_p]),
+    ('cpn_resize_f32', ctypes.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     ('cpn_border_keep_batched', ctypes.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
                                                c_float, c_float, c_float, c_void_p, c_void_p]),
     ('cpn_histogram', ctypes.c_int, [c_void_p, c_int32, c_int64, c_void_p, c_void_p]),

@@ -311,7 +311,8 @@ class _Engine:
             self._launch(x, dt, h, w, ws, need, (scores, locations, fourier, ref, self.last_uncertainty), flag, nb,
                          _timed=_timed, _absmax=_absmax)
         if ref is not None and tuple(ref.shape[2:]) != (h, w):  # strided refinement head: `_equal_size(.., inputs)`, cpn.py:279
-            ref = _equal_size(ref, x)
+            ref = _equal_size(ref, x, 'bicubic' if any(o.get('mode') == 'bicubic' for o in self.plan.ops) or
+                              self.plan.meta.get('refinement_interpolation') == 'bicubic' else 'bilinear')
         self.last_sparse = None
         if gated:  # where the heads' source tensor lives in this run's arena (it stays intact until the arena's next turn)
             from ctypes import c_int32, c_int64
@@ -325,16 +326,16 @@ class _Engine:
         return scores, locations, ref, fourier, flag
 
 
-def _equal_size(x, reference):
-    """celldetection/models/cpn.py:109-115: bilinear resize (align_corners=False) of an fp32 NCHW map to the spatial
+def _equal_size(x, reference, mode='bilinear'):
+    """celldetection/models/cpn.py:109-115: bilinear (| bicubic) resize (align_corners=False) of an fp32 NCHW map to the spatial
     size of ``reference`` (own HIP kernel with torch CPU's arithmetic: the thresholded result must not depend on which
     backend resized the mask)."""
     if reference.shape[2:] != x.shape[2:]:
         x = x.contiguous().float()
         out = torch.empty(x.shape[:2] + tuple(reference.shape[2:]), dtype=torch.float32, device=x.device)
-        _lib.check(_lib.load().cpn_resize_bilinear_f32(_lib.ptr(x), _lib.ptr(out), x.shape[0] * x.shape[1], x.shape[2],
-                                                       x.shape[3], out.shape[2], out.shape[3], _lib.stream_ptr()),
-                   'resize_bilinear_f32')
+        _lib.check(_lib.load().cpn_resize_f32(_lib.ptr(x), _lib.ptr(out), x.shape[0] * x.shape[1], x.shape[2], x.shape[3],
+                                              out.shape[2], out.shape[3], 1 if mode == 'bicubic' else 0, _lib.stream_ptr()),
+                   'resize_f32')
         x = out
     return x
 
@@ -351,7 +352,7 @@ class CPN(nn.Module):
         super().__init__()
         unsupported = {k: v for k, v in kwargs.items() if (k in ('contour_head_stride', 'refinement_head_stride')
                                                            and v not in (None, 1, 2, 4, 8))
-                       or (k == 'refinement_interpolation' and v == 'bicubic') or (k == 'fuse_kwargs' and v)}
+                       }
         if unsupported:
             raise NotImplementedError(f'Unsupported CPN options on the HIP path: {unsupported}')
         features = {name: kwargs[key] for name, key in (('score', 'score_features'), ('location', 'location_features'),
@@ -386,7 +387,10 @@ class CPN(nn.Module):
                                  contour_head_stride=int(kwargs.get('contour_head_stride') or 1),
                                  refinement_head_stride=int(kwargs.get('refinement_head_stride') or 1),
                                  head_activations=head_act if any(v != 'relu' for v in head_act.values()) else None,
-                                 refinement_full_res=bool(kwargs.get('refinement_full_res', True)))
+                                 refinement_full_res=bool(kwargs.get('refinement_full_res', True)),
+                                 fuse_kwargs=kwargs.get('fuse_kwargs') or None,
+                                 refinement_interpolation='bicubic' if kwargs.get('refinement_interpolation') == 'bicubic'
+                                 else 'bilinear')
         # `_equal_size(.., mode=refinement_interpolation, align_corners=False)` (cpn.py:109-115,277-279): torch accepts
         # align_corners for the interpolating modes only, so in the reference every other mode ('nearest', 'area', ...) raises
         # as soon as a resize is needed; reproduced in `_Engine.run` / `core_forward` (bicubic: not built)
@@ -591,9 +595,7 @@ class CPN(nn.Module):
                 off, th, tw, cs = c_int64(0), c_int32(0), c_int32(0), c_int32(0)
                 _lib.check(_lib.load().cpn_plan_tensor_info(eng.handle, n, h, w, int(op['src0']), off, th, tw, cs), 'plan_tensor_info')
                 sizes.append((int(th.value), int(tw.value)))
-        if any(tuple(sz) != (h, w) for sz in sizes):
-            if self.refinement_interpolation == 'bicubic':
-                raise NotImplementedError("refinement_interpolation='bicubic' is not built on the HIP path")
+        if self.refinement_interpolation != 'bicubic' and any(tuple(sz) != (h, w) for sz in sizes):
             raise ValueError('align_corners option can only be set with the interpolating modes: linear | bilinear | bicubic | '
                              'trilinear')
 

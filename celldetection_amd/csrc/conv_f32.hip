@@ -163,6 +163,28 @@ __global__ __launch_bounds__(256) void bilinear_f32_kernel(const ResizeArgs a) {
     const int oy = (int) (pix % a.Hout);
     const int n = (int) (pix / a.Hout);
     const float sy = (float) a.Hin / (float) a.Hout, sx = (float) a.Win / (float) a.Wout;
+    if (a.mode == 1) {  // bicubic: see bicubic_taps (cpn_kernels.h)
+        int iy[4], ix[4];
+        float wy[4], wx[4];
+        bicubic_taps(sy, oy, a.Hin, iy, wy);
+        bicubic_taps(sx, ox, a.Win, ix, wx);
+        const float *base = (const float *) a.src + (long) n * a.Hin * a.Win * a.C + gidx * 4;
+        float4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 v = *(const float4 *) (base + ((long) iy[i] * a.Win + ix[j]) * a.C);
+                r.x = j == 0 ? v.x * wx[0] : r.x + v.x * wx[j]; r.y = j == 0 ? v.y * wx[0] : r.y + v.y * wx[j];
+                r.z = j == 0 ? v.z * wx[0] : r.z + v.z * wx[j]; r.w = j == 0 ? v.w * wx[0] : r.w + v.w * wx[j];
+            }
+            o.x = i == 0 ? r.x * wy[0] : o.x + r.x * wy[i]; o.y = i == 0 ? r.y * wy[0] : o.y + r.y * wy[i];
+            o.z = i == 0 ? r.z * wy[0] : o.z + r.z * wy[i]; o.w = i == 0 ? r.w * wy[0] : o.w + r.w * wy[i];
+        }
+        *(float4 *) ((float *) a.dst + (((long) n * a.Hout + oy) * a.Wout + ox) * a.C + gidx * 4) = o;
+        return;
+    }
     const float fy = fmaxf(sy * ((float) oy + 0.5f) - 0.5f, 0.f), fx = fmaxf(sx * ((float) ox + 0.5f) - 0.5f, 0.f);
     const int y0 = (int) fy, x0 = (int) fx;
     const int y1 = y0 + (y0 < a.Hin - 1 ? 1 : 0), x1 = x0 + (x0 < a.Win - 1 ? 1 : 0);

@@ -566,6 +566,12 @@ int cpn_plan_create(cpn_plan **plan, const cpn_tensor_desc *tensors, int32_t n_t
             return fail(CPN_E_INVALID, "cpn_plan_create: an activation op needs source and destination tensors of equal channel count "
                                        "and one of the elementwise activations");
         }
+        if (o.op == CPN_OP_BILINEAR && (o.act < 0 || o.act > 1 || (o.act == 1 && p->precision == CPN_PRECISION_FP8))) {
+            delete p;
+            return fail(o.act == 1 ? CPN_E_UNSUPPORTED : CPN_E_INVALID,
+                        "cpn_plan_create: a resize op takes act = 0 (bilinear) or 1 (bicubic; bf16 / fp32 plans only: bicubic weights "
+                        "are negative in places, the result leaves the e4m3 range of its source's scale)");
+        }
         if ((o.op == CPN_OP_CONV || o.op == CPN_OP_CONV_DEFERRED) && (o.act > CPN_ACT_TANH_SCALED || o.fuse_act > CPN_ACT_TANH_SCALED)) {
             delete p;
             return fail(CPN_E_INVALID, "cpn_plan_create: conv ops take CPN_ACT_NONE .. CPN_ACT_TANH_SCALED (other activations are CPN_OP_ACT ops)");
@@ -722,7 +728,8 @@ static int run_or_count(cpn_plan *plan, const void *input, int32_t in_dtype, int
                 if (flops) break;
                 if (sp.offsets[o.src0] == sp.offsets[o.dst]) break;  // same size: the planner aliased dst to src
                 ResizeArgs a{tptr(o.src0), tptr(o.dst), N, sp.th[o.src0], sp.tw[o.src0], sp.th[o.dst], sp.tw[o.dst],
-                             tch(o.src0), fp8 ? sp.ring[i] : 0};  // (ring: see propagate_dims, bilinear sub-pixel triple)
+                             tch(o.src0), fp8 ? sp.ring[i] : 0,  // (ring: see propagate_dims, bilinear sub-pixel triple)
+                             o.act == 1 ? 1 : 0};                // (CPN_OP_BILINEAR: act = 1 selects bicubic)
                 rc = check_hip((hipError_t) (f32 ? launch_bilinear_f32(a, st) : fp8 ? launch_bilinear_fp8(a, st)
                                                                                    : launch_bilinear(a, st)), "bilinear kernel");
                 break;

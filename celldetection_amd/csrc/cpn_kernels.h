@@ -184,7 +184,27 @@ struct ResizeArgs {
     const void *src; void *dst;
     int N, Hin, Win, Hout, Wout, C;
     int ring;  // fp8 kernel only: > 0 -> write just the pixels within `ring` of the output's border (0: the whole map)
+    int mode;  // 0 bilinear | 1 bicubic (bf16 / fp32 kernels; F.interpolate(mode=..., align_corners=False))
 };
+// PyTorch upsample_bicubic2d, align_corners=False (ATen UpSample.h: cubic convolution, A = -0.75): source position
+// scale * (dst + 0.5) - 0.5 (NOT clamped at 0, unlike bilinear), index = min(floor(pos), size - 1), lambda = clamp(pos - index, 0, 1),
+// taps index - 1 .. index + 2 clamped to the image, weights w[0..3] below; out = sum_i wy[i] * (sum_j wx[j] * v[i][j])
+__host__ __device__ inline void bicubic_taps(float scale, int dst, int size, int (&idx)[4], float (&w)[4]) {
+    const float pos = scale * ((float) dst + 0.5f) - 0.5f;
+    int i0 = (int) floorf(pos);
+    if (i0 > size - 1) i0 = size - 1;
+    const float t = fminf(fmaxf(pos - (float) i0, 0.f), 1.f);
+    const float A = -0.75f;
+    const float x0 = t + 1.f, x3 = 2.f - t, x2 = 1.f - t;
+    w[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+    w[1] = ((A + 2.f) * t - (A + 3.f)) * t * t + 1.f;
+    w[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
+    w[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+    for (int j = 0; j < 4; ++j) {
+        const int v = i0 - 1 + j;
+        idx[j] = v < 0 ? 0 : (v > size - 1 ? size - 1 : v);
+    }
+}
 int launch_bilinear(const ResizeArgs &a, hipStream_t stream);
 
 struct InputArgs {

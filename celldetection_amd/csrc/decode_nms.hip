@@ -10,6 +10,7 @@
 
 #include "../../include/cpn_hip.h"
 #include "cpn_error.h"
+#include "cpn_kernels.h"
 
 namespace {
 
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(256) void border_batched_kernel(const float *__rest
 // models/cpn.py:109-123,279): torch CPU's separable form out = (v00*wx0 + v01*wx1)*wy0 + (v10*wx0 + v11*wx1)*wy1 with
 // src = max(scale*(dst+0.5)-0.5, 0), scale = in/out, w1 = src - floor(src), w0 = 1 - w1; every product/sum rounded
 __global__ __launch_bounds__(256) void resize_f32_kernel(const float *__restrict__ src, float *__restrict__ dst,
-                                                        long planes, int Hin, int Win, int Hout, int Wout) {
+                                                        long planes, int Hin, int Win, int Hout, int Wout, int mode) {
     const long i = blockIdx.x * 256l + threadIdx.x;
     const long total = planes * Hout * Wout;
     if (i >= total) return;
@@ -335,6 +336,23 @@ __global__ __launch_bounds__(256) void resize_f32_kernel(const float *__restrict
     const long pl = t / Hout;
     const float sy = (float) Hin / (float) Hout, sx = (float) Win / (float) Wout;
     const float *p = src + pl * Hin * Win;
+    if (mode == 1) {  // bicubic, align_corners=False (cpn_kernels.h bicubic_taps): sum_i wy[i] * (sum_j wx[j] * v[i][j])
+        int iy[4], ix[4];
+        float wy[4], wx[4];
+        cpn::bicubic_taps(sy, oy, Hin, iy, wy);
+        cpn::bicubic_taps(sx, ox, Win, ix, wx);
+        float o = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float *row = p + (long) iy[a] * Win;
+            float r = __fmul_rn(row[ix[0]], wx[0]);
+#pragma unroll
+            for (int b = 1; b < 4; ++b) r = __fadd_rn(r, __fmul_rn(row[ix[b]], wx[b]));
+            o = a == 0 ? __fmul_rn(r, wy[0]) : __fadd_rn(o, __fmul_rn(r, wy[a]));
+        }
+        dst[i] = o;
+        return;
+    }
     int y0 = oy, y1 = oy, x0 = ox, x1 = ox;
     float wy0 = 1.f, wy1 = 0.f, wx0 = 1.f, wx1 = 0.f;
     if (Hin != Hout) {
@@ -740,15 +758,20 @@ int cpn_border_keep(const float *contours, int64_t P, int32_t samples, float off
     return cpn::check_hip(hipGetLastError(), "cpn_border_keep");
 }
 
-int cpn_resize_bilinear_f32(const float *src, float *dst, int64_t planes, int32_t Hin, int32_t Win, int32_t Hout,
-                            int32_t Wout, void *stream) {
-    if (planes < 0 || Hin < 1 || Win < 1 || Hout < 1 || Wout < 1 || !src || !dst)
-        return cpn::fail(CPN_E_INVALID, "cpn_resize_bilinear_f32: bad arguments");
+int cpn_resize_f32(const float *src, float *dst, int64_t planes, int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout,
+                   int32_t mode, void *stream) {
+    if (!src || !dst || planes < 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || (mode != 0 && mode != 1))
+        return cpn::fail(CPN_E_INVALID, "cpn_resize_f32: bad arguments (mode 0 bilinear | 1 bicubic)");
     const long total = (long) planes * Hout * Wout;
     if (total == 0) return 0;
     hipLaunchKernelGGL(resize_f32_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, (hipStream_t) stream,
-                       src, dst, (long) planes, Hin, Win, Hout, Wout);
-    return cpn::check_hip(hipGetLastError(), "cpn_resize_bilinear_f32");
+                       src, dst, (long) planes, Hin, Win, Hout, Wout, mode);
+    return cpn::check_hip(hipGetLastError(), "cpn_resize_f32");
+}
+
+int cpn_resize_bilinear_f32(const float *src, float *dst, int64_t planes, int32_t Hin, int32_t Win, int32_t Hout,
+                            int32_t Wout, void *stream) {
+    return cpn_resize_f32(src, dst, planes, Hin, Win, Hout, Wout, 0, stream);
 }
 
 int cpn_border_keep_batched(const float *contours, int64_t P, int32_t samples, const int32_t *image_index,

@@ -122,6 +122,36 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const ResizeArgs a) {
         pix /= a.Wout;
         const int oy = (int) (pix % a.Hout);
         const int n = (int) (pix / a.Hout);
+        if (a.mode == 1) {  // bicubic (refinement_interpolation='bicubic', models/cpn.py:109-115,277-279): 4 x 4 taps, fp32 math
+            int iy[4], ix[4];
+            float wy[4], wx[4];
+            bicubic_taps(sy, oy, a.Hin, iy, wy);
+            bicubic_taps(sx, ox, a.Win, ix, wx);
+            const unsigned short *base = (const unsigned short *) a.src + (long) n * a.Hin * a.Win * a.C + gidx * 8;
+            float acc[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float row[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const u32x4 v = *(const u32x4 *) (base + ((long) iy[i] * a.Win + ix[j]) * a.C);
+                    const unsigned int q[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float lo = from_bf16(q[e] & 0xffffu), hi = from_bf16(q[e] >> 16);
+                        row[2 * e] = j == 0 ? lo * wx[0] : row[2 * e] + lo * wx[j];
+                        row[2 * e + 1] = j == 0 ? hi * wx[0] : row[2 * e + 1] + hi * wx[j];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = i == 0 ? row[e] * wy[0] : acc[e] + row[e] * wy[i];
+            }
+            u32x4 ov;
+            ov.x = to_bf16(acc[0]) | (to_bf16(acc[1]) << 16); ov.y = to_bf16(acc[2]) | (to_bf16(acc[3]) << 16);
+            ov.z = to_bf16(acc[4]) | (to_bf16(acc[5]) << 16); ov.w = to_bf16(acc[6]) | (to_bf16(acc[7]) << 16);
+            *(u32x4 *) ((unsigned short *) a.dst + (((long) n * a.Hout + oy) * a.Wout + ox) * a.C + gidx * 8) = ov;
+            continue;
+        }
         const float fy = fmaxf(sy * ((float) oy + 0.5f) - 0.5f, 0.f);
         const float fx = fmaxf(sx * ((float) ox + 0.5f) - 0.5f, 0.f);
         const int y0 = (int) fy, x0 = (int) fx;

@@ -142,11 +142,11 @@ class Plan:
         self.ops.append(dict(op='maxpool', src0=src, dst=dst, k=k, stride=stride, pad=pad))
         return dst
 
-    def bilinear_to_input(self, src):
-        """``_equal_size(features, inputs)`` (models/cpn.py:109-115,277-278): bilinear resize (align_corners=False) to
+    def bilinear_to_input(self, src, mode='bilinear'):
+        """``_equal_size(features, inputs, mode)`` (models/cpn.py:109-115,277-278): bilinear | bicubic resize (align_corners=False) to
         the input size; the executor aliases source and destination when the sizes already agree."""
         dst = self.tensor(self.tensors[src]['c'], 1)
-        self.ops.append(dict(op='bilinear', src0=src, dst=dst))
+        self.ops.append(dict(op='bilinear', src0=src, dst=dst, mode=mode))
         return dst
 
     def input(self, in_channels):
@@ -514,7 +514,8 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
                kernel_sizes: dict = None, fuse_bilinear: bool = True, contour_head_stride: int = 1,
                refinement_head_stride: int = 1, features: dict = None, sparse_heads: bool = False,
                subpixel: bool = False, stem_fast: bool = False, fuse_blocks: bool = False, hoist_heads: bool = True,
-               bilinear_phases: bool = False, head_activations: dict = None, refinement_full_res: bool = True) -> Plan:
+               bilinear_phases: bool = False, head_activations: dict = None, refinement_full_res: bool = True,
+               refinement_interpolation: str = 'bilinear', fuse_kwargs: dict = None) -> Plan:
     """Plan of ``Cpn<backbone>`` (celldetection/models/cpn.py:287-439,771-2061; heads: CPNCore.__init__
     cpn.py:125-236).  ``kernel_sizes``: optional {'score'|'location'|'fourier'|'uncertainty'|'refinement': k}
     (the reference's ``kernel_size_<head>`` kwargs, default 7).  ``contour_head_stride`` / ``refinement_head_stride``: stride
@@ -540,7 +541,23 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
     carries its sub-pixel decomposition (``_readout``).  ``head_activations``: optional {'score'|'location'|'fourier'|
     'uncertainty'|'refinement': plan activation name} = the reference's ``head_activation`` / ``head_activation_<head>`` kwargs
     (cpn.py:183-233; default 'relu'; see ``head_activation_name``).  ``refinement_full_res=False``: the refinement head reads its
-    feature at the feature's resolution (cpn.py:276-279)."""
+    feature at the feature's resolution (cpn.py:276-279).  ``refinement_interpolation``: 'bilinear' | 'bicubic' -- the mode of that resize
+    (the non-interpolating modes raise in the reference as soon as a resize is needed, see cpn.CPN._check_refinement_interpolation).
+    ``fuse_kwargs`` (cpn.py:173 -> Fuse2d, commons.py:640-674): ``activation`` (a torch.nn name as for the heads, or None),
+    ``norm_layer`` (None | 'batchnorm2d'), ``bias``, and -- for heads fused over TWO features -- ``kernel_size`` k with ``padding``
+    k // 2 (a k x k conv over the virtual concat; over more features only the 1x1 conv commutes with the nearest resize)."""
+    fkw = dict(fuse_kwargs or {})
+    f_act = fkw.pop('activation', 'relu')
+    f_act = 'none' if f_act is None else head_activation_name(f_act)
+    f_norm = fkw.pop('norm_layer', 'batchnorm2d')
+    if f_norm is not None and str(getattr(f_norm, '__name__', f_norm)).lower() != 'batchnorm2d':
+        raise NotImplementedError(f'fuse_kwargs: norm_layer {f_norm!r} is not supported by the HIP engine (None | batchnorm2d)')
+    f_k, f_bias = int(fkw.pop('kernel_size', 1)), bool(fkw.pop('bias', True))
+    f_pad = int(fkw.pop('padding', 0))
+    if f_k % 2 == 0 or f_pad != f_k // 2:
+        raise NotImplementedError('fuse_kwargs: kernel_size must be odd with padding = kernel_size // 2 on the HIP path')
+    if fkw:
+        raise NotImplementedError(f'fuse_kwargs: options {sorted(fkw)} are not supported by the HIP engine')
     ha = dict(score='relu', location='relu', fourier='relu', uncertainty='relu', refinement='relu')
     ha.update(head_activations or {})
     if any(v not in _ACT or v == 'tanh_scaled' for v in ha.values()):
@@ -605,10 +622,18 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
             return t0, ch0
         ts = [level[k] for k in keys]
         (t1, ch1) = ts[1]
-        w_, bn_ = fuse_prefix + 'block.0.', fuse_prefix + 'block.1.'
+        w_, bn_ = fuse_prefix + 'block.0.', (fuse_prefix + 'block.1.' if f_norm is not None else None)
+        conv_act = f_act if f_act in ('relu', 'none') else 'none'  # (other activations: an elementwise op behind the conv)
+
+        def finish(t_):
+            return t_ if conv_act == f_act else P.act(t_, f_act)
+
         if len(keys) == 2:
-            t = P.conv(t0, ch0, 1, w=w_, bn=bn_, bias=True, act='relu', src1=t1, up1=True)
-            return t, ch0
+            t = P.conv(t0, ch0, f_k, w=w_, bn=bn_, bias=f_bias, act=conv_act, src1=t1, up1=True)
+            return finish(t), ch0
+        if f_k != 1:
+            raise NotImplementedError('fuse_kwargs: kernel_size > 1 over three or more features (the split into per-feature '
+                                      'convs needs a conv that commutes with the nearest resize: 1x1 only)')
         # three features: conv1x1(cat(f0, f1^, f2^)) = conv1x1 over [f0 | f1^] + (conv1x1 over f2)^ -- a 1x1 conv commutes with
         # the nearest resize, so the third feature's share runs at ITS resolution (no bias, BN scale folded) and joins as a
         # nearest-resized residual in front of bias + ReLU (the conv kernel reads two concat sources and one residual).
@@ -618,22 +643,23 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
         off = [0]
         for (_, c) in ts:
             off.append(off[-1] + c)
-        P.conv_keys(w_, ch0, off[-1], 1, True)
-        P.bn_keys(bn_, ch0)
+        P.conv_keys(w_, ch0, off[-1], 1, f_bias)
+        if bn_ is not None:
+            P.bn_keys(bn_, ch0)
         n = len(ts)
 
         def part(i):
-            return P.conv(ts[i][0], ch0, 1, w=w_, bn=bn_, bias=True, share=(off[i], off[i + 1], False))
+            return P.conv(ts[i][0], ch0, 1, w=w_, bn=bn_, bias=f_bias, share=(off[i], off[i + 1], False))
 
         res = part(2)
-        t = P.conv(t0, ch0, 1, w=w_, bn=bn_, bias=True, act='relu' if n == 3 else 'none', src1=t1, up1=True, res=res,
+        t = P.conv(t0, ch0, 1, w=w_, bn=bn_, bias=f_bias, act=conv_act if n == 3 else 'none', src1=t1, up1=True, res=res,
                    res_up=True, share=(0, off[2], n == 3))
         for i in range(3, n, 2):
             res = part(i + 1) if i + 1 < n else None
             last = i + 2 >= n
-            t = P.conv(t, ch0, 1, w=w_, bn=bn_, bias=True, act='relu' if last else 'none', src1=ts[i][0], up1=True, res=res,
+            t = P.conv(t, ch0, 1, w=w_, bn=bn_, bias=f_bias, act=conv_act if last else 'none', src1=ts[i][0], up1=True, res=res,
                        res_up=res is not None, share=(off[i], off[i + 1], last, ch0))
-        return t, ch0
+        return finish(t), ch0
 
     heads_begin = len(P.ops)
     f1s, c1 = _head_input('score', 'core.score_fuse.')
@@ -675,11 +701,13 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
         # maps are resized to the input size instead (the engine's fp32 bilinear kernel, cpn._Engine.run)
         resize = (family == 'fpn' or enc not in _UNET_ENCODERS or _keys(feats_cfg['refinement']) != ['0']) and refinement_full_res
         kr = ks.get('refinement', 7)
-        fused_resize = resize and fuse_bilinear and kr > 1 and refinement_head_stride == 1
+        bicubic = refinement_interpolation == 'bicubic'  # (its own resize op in every plan: the fused loader / phases are bilinear)
+        fused_resize = resize and fuse_bilinear and kr > 1 and refinement_head_stride == 1 and not bicubic
+        bilinear_phases = bilinear_phases and not bicubic
         r_low = None
         if resize and not fused_resize:
             r_low = r
-            r = P.bilinear_to_input(r)
+            r = P.bilinear_to_input(r, 'bicubic' if bicubic else 'bilinear')
             resize_op = P.ops[-1]
         _readout(P, r, cm0, 2 * refinement_buckets, 'core.refinement_head.', 'tanh_scaled', float(refinement_margin),
                  _lib.OUT_REFINEMENT, k=kr, fuse=fuse_readout, up0='bilinear' if fused_resize else False,
@@ -695,7 +723,8 @@ def build_plan(backbone: str, in_channels: int, order: int = 5, score_channels: 
             sparse_meta['ops'] = tuple(i - shift for i in sparse_meta['ops'])
     P.meta = dict(backbone=backbone, order=order, head_down=scale, refinement=refinement, in_channels=in_channels,
                   score_channels=score_channels, refinement_buckets=refinement_buckets,
-                  uncertainty_head=bool(uncertainty_head), sparse_heads=sparse_meta)
+                  uncertainty_head=bool(uncertainty_head), sparse_heads=sparse_meta,
+                  refinement_interpolation=refinement_interpolation)
     return P
 
 
@@ -861,6 +890,10 @@ def pack(plan: Plan, state_dict, device, precision: str = 'bf16', act_scales=Non
             continue
         if op['op'] == 'bilinear':
             d.op, d.src0, d.dst = _lib.OP_BILINEAR, op['src0'], op['dst']
+            d.act = 1 if op.get('mode') == 'bicubic' else 0  # (include/cpn_hip.h: a resize op's act selects the mode)
+            if d.act and fp8:
+                raise NotImplementedError("refinement_interpolation='bicubic' is a bf16 / fp32-plan feature (bicubic weights are "
+                                          'negative in places: the result leaves the e4m3 range of its source)')
             # feeds a bilinear sub-pixel triple: only the frame's neighbourhood of the map is needed when the phase convs run
             d.subpixel = _lib.SUBPIXEL_BL_FRAME if op.get('ring_for_bl') else _lib.SUBPIXEL_NONE
             continue

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CPN_ABI_VERSION 12
+#define CPN_ABI_VERSION 13
 
 #define CPN_E_INVALID (-1)
 #define CPN_E_UNSUPPORTED (-2)
@@ -376,6 +376,12 @@ int cpn_border_keep(const float *contours, int64_t P, int32_t samples, float off
  * masks and head maps (celldetection/models/cpn.py:109-123,279).  src [planes, Hin, Win] -> dst [planes, Hout, Wout]. */
 int cpn_resize_bilinear_f32(const float *src, float *dst, int64_t planes, int32_t Hin, int32_t Win, int32_t Hout,
                             int32_t Wout, void *stream);
+/* The same with the mode of CPNCore's `refinement_interpolation` (celldetection/models/cpn.py:109-115,277-279): mode 0 =
+ * bilinear (= cpn_resize_bilinear_f32), 1 = bicubic (PyTorch's cubic convolution, A = -0.75, align_corners=False).  The
+ * non-interpolating modes cannot run in the reference (torch rejects align_corners for them) and are no modes here.
+ * Inside a plan the resize op CPN_OP_BILINEAR selects bicubic with act = 1 (bf16 / fp32 plans). */
+int cpn_resize_f32(const float *src, float *dst, int64_t planes, int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout,
+                   int32_t mode, void *stream);
 
 /* The same rule for ALL detections of a forwarded batch of tiles in one launch (the per-tile loop of
  * celldetection_scripts/cpn_inference.py:370-380): contour p belongs to image image_index[p] (int32, device);

@@ -181,9 +181,10 @@ def _readout(x, sd, p, stride=1, act='relu'):
     return _conv(x, sd, p + 'block.4.')
 
 
-def _head_features(feats, keys, sd, fuse_prefix):
+def _head_features(feats, keys, sd, fuse_prefix, fuse_kwargs=None):
     """_resolve_features (cpn.py:103-106) + Fuse2d (commons.py:640-674): a list of keys is resized (nearest) to the
-    first feature's size, concatenated and passed through conv1x1 -> BN -> ReLU."""
+    first feature's size, concatenated and passed through conv (1x1 by default) -> BN -> ReLU.  ``fuse_kwargs`` (cpn.py:173):
+    kernel_size / padding / bias (read off the weights), ``norm_layer=None`` (no BN entries), ``activation`` (name or None)."""
     if not isinstance(keys, (list, tuple)):
         return feats[keys]
     xs = [feats[k] for k in keys]
@@ -191,7 +192,12 @@ def _head_features(feats, keys, sd, fuse_prefix):
     x = torch.cat([(F.interpolate(t, size) if t.shape[-2:] != size else t) for t in xs], 1)
     if len(xs) == 1:
         return x
-    return F.relu(_bn(_conv(x, sd, fuse_prefix + 'block.0.'), sd, fuse_prefix + 'block.1.'))
+    fk = dict(fuse_kwargs or {})
+    x = _conv(x, sd, fuse_prefix + 'block.0.', padding=fk.get('padding', 0))
+    if (fuse_prefix + 'block.1.running_mean') in sd:
+        x = _bn(x, sd, fuse_prefix + 'block.1.')
+    act = fk.get('activation', 'relu')
+    return x if act is None else _hidden_act(act)(x)
 
 
 def _resize(x, size, mode):
@@ -205,7 +211,7 @@ def _resize(x, size, mode):
 
 def core_forward(state_dict, x, refinement_margin=3., with_uncertainty=False, contour_head_stride=1,
                  refinement_head_stride=1, features=None, head_activations=None, refinement_interpolation='bilinear',
-                 refinement_full_res=True):
+                 refinement_full_res=True, fuse_kwargs=None):
     """CPNCore.forward, models/cpn.py:238-283 -> (raw scores, locations, refinement, fourier), all fp32 NCHW
     (+ the sigmoid uncertainty map [N,4,h,w] or None as fifth element when ``with_uncertainty``).
 
@@ -235,16 +241,16 @@ def core_forward(state_dict, x, refinement_margin=3., with_uncertainty=False, co
         hs = contour_head_stride
         ha = dict(score='relu', location='relu', fourier='relu', uncertainty='relu', refinement='relu')
         ha.update(head_activations or {})  # head_activation / head_activation_<head> (cpn.py:183-233)
-        scores = _readout(_head_features(feats, fk['score'], sd, 'core.score_fuse.'), sd, 'core.score_head.', hs, ha['score'])
-        locations = _readout(_head_features(feats, fk['location'], sd, 'core.location_fuse.'), sd, 'core.location_head.', hs,
+        scores = _readout(_head_features(feats, fk['score'], sd, 'core.score_fuse.', fuse_kwargs), sd, 'core.score_head.', hs, ha['score'])
+        locations = _readout(_head_features(feats, fk['location'], sd, 'core.location_fuse.', fuse_kwargs), sd, 'core.location_head.', hs,
                              ha['location'])
-        fourier = _readout(_head_features(feats, fk['contour'], sd, 'core.fourier_fuse.'), sd, 'core.fourier_head.', hs,
+        fourier = _readout(_head_features(feats, fk['contour'], sd, 'core.fourier_fuse.', fuse_kwargs), sd, 'core.fourier_head.', hs,
                            ha['fourier'])
         uncertainty = None
         if _has(sd, 'core.uncertainty_head.'):  # cpn.py:209-221,266-271: ReadOut with final sigmoid
-            uncertainty = torch.sigmoid(_readout(_head_features(feats, fk['uncertainty'], sd, 'core.uncertainty_fuse.'), sd,
+            uncertainty = torch.sigmoid(_readout(_head_features(feats, fk['uncertainty'], sd, 'core.uncertainty_fuse.', fuse_kwargs), sd,
                                                  'core.uncertainty_head.', hs, ha['uncertainty']))
-        f0 = _head_features(feats, fk['refinement'], sd, 'core.refinement_fuse.')
+        f0 = _head_features(feats, fk['refinement'], sd, 'core.refinement_fuse.', fuse_kwargs)
         if refinement_full_res:  # cpn.py:277-278
             f0 = _resize(f0, x.shape[2:], refinement_interpolation)
         refinement = torch.tanh(_readout(f0, sd, 'core.refinement_head.', refinement_head_stride, ha['refinement'])) * refinement_margin

@@ -134,6 +134,21 @@ MODEL_SPECS = {
     'CpnWideU22': ('CpnWideU22', dict(in_channels=1, order=3), (1, 1, 48, 64)),
     'CpnResNet18FPN_lowres': ('CpnResNet18FPN', dict(in_channels=3, refinement_full_res=False, backbone_kwargs={
         'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}), (2, 3, 64, 96)),
+    'CpnResNet18FPN_bicubic': ('CpnResNet18FPN', dict(in_channels=3, refinement_interpolation='bicubic', backbone_kwargs={
+        'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}), (1, 3, 75, 101)),
+    'CpnResNet18FPN_bicubic_lowres': ('CpnResNet18FPN', dict(in_channels=3, refinement_interpolation='bicubic',
+                                                             refinement_full_res=False, backbone_kwargs={
+        'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}), (2, 3, 64, 96)),
+    'CpnResNet18FPN_fusekw3': ('CpnResNet18FPN', dict(in_channels=3, score_features=['1', '2'], contour_features=['1', '0'],
+                                                      location_features=['1', '2'],
+                                                      fuse_kwargs=dict(kernel_size=3, padding=1, activation='LeakyReLU'),
+                                                      backbone_kwargs={'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}),
+                               (1, 3, 64, 96)),
+    'CpnResNet18FPN_fusekw': ('CpnResNet18FPN', dict(in_channels=3, score_features=['1', '2', '3'], contour_features=['1', '2'],
+                                                     refinement_features=['0', '1', '2'],
+                                                     fuse_kwargs=dict(norm_layer=None, activation=None, bias=False),
+                                                     backbone_kwargs={'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}),
+                              (1, 3, 75, 101)),
     'CpnResNet50UNet_feats': ('CpnResNet50UNet', dict(in_channels=3, score_features='2', contour_features='2',
                                                       location_features='2', refinement_features=['0', 'encoder.0'],
                                                       backbone_kwargs={'backbone_kwargs': {'base_channel': 8}}),
@@ -307,7 +322,10 @@ MODEL_CALIBRATION = {'CpnU22_classes4': dict(score_shift=-3.5),
                      'CpnU22_stride4': dict(score_shift=1.2, fourier_std=.07, location_std=.3, refinement_raw_std=.3),
                      'CpnU22_headact': _U22_SMALL, 'CpnResNet18FPN_headact': _FPN_DENSE,
                      'CpnResNet18UNet': _U22_SMALL, 'CpnResNet34UNet': _U22_SMALL, 'CpnResUNet': _U22_SMALL, 'CpnSlimU22': _U22_SMALL,
-                     'CpnWideU22': _U22_SMALL, 'CpnResNet18FPN_lowres': _FPN_DENSE,
+                     'CpnWideU22': _U22_SMALL, 'CpnResNet18FPN_lowres': _FPN_DENSE, 'CpnResNet18FPN_bicubic': _FPN_DENSE,
+                     'CpnResNet18FPN_bicubic_lowres': _FPN_DENSE,
+                     'CpnResNet18FPN_fusekw3': dict(score_shift=1., fourier_std=.35, location_std=.4, refinement_raw_std=.3),
+                     'CpnResNet18FPN_fusekw': dict(score_shift=.5, fourier_std=.4, location_std=.4, refinement_raw_std=.3),
                      'CpnResNet18FPN_fuse': dict(score_shift=-.5, fourier_std=.4, location_std=.4),
                      'CpnResNet18FPN_fuse3': dict(score_shift=.5, fourier_std=.4, location_std=.4, refinement_raw_std=.3),
                      'CpnResNet18FPN_fuse5': dict(score_shift=.5, fourier_std=.4, location_std=.4, refinement_raw_std=.3)}

@@ -105,6 +105,27 @@ HEAD_SPECS = {
     'CpnResNet18FPN_lowres': dict(cls='CpnResNet18FPN', kwargs=dict(
         in_channels=3, refinement_full_res=False, backbone_kwargs={'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}),
         cpn_kwargs=dict(_DEF), core_kwargs=dict(refinement_full_res=False)),
+    # refinement_interpolation='bicubic' (cpn.py:109-115,277-279): the FEATURE map resized bicubically (full_res) / the head's OUTPUT maps
+    'CpnResNet18FPN_bicubic': dict(cls='CpnResNet18FPN', kwargs=dict(
+        in_channels=3, refinement_interpolation='bicubic', backbone_kwargs={'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}),
+        cpn_kwargs=dict(_DEF), core_kwargs=dict(refinement_interpolation='bicubic')),
+    'CpnResNet18FPN_bicubic_lowres': dict(cls='CpnResNet18FPN', kwargs=dict(
+        in_channels=3, refinement_interpolation='bicubic', refinement_full_res=False,
+        backbone_kwargs={'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}),
+        cpn_kwargs=dict(_DEF), core_kwargs=dict(refinement_interpolation='bicubic', refinement_full_res=False)),
+    # fuse_kwargs (cpn.py:173 -> Fuse2d): 3x3 fuse conv + another activation over two features; no norm / no activation over three
+    'CpnResNet18FPN_fusekw3': dict(cls='CpnResNet18FPN', kwargs=dict(
+        in_channels=3, score_features=['1', '2'], contour_features=['1', '0'], location_features=['1', '2'],
+        fuse_kwargs=dict(kernel_size=3, padding=1, activation='LeakyReLU'),
+        backbone_kwargs={'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}), cpn_kwargs=dict(_DEF),
+        core_kwargs=dict(features=dict(score=['1', '2'], contour=['1', '0'], location=['1', '2']),
+                         fuse_kwargs=dict(kernel_size=3, padding=1, activation='LeakyReLU'))),
+    'CpnResNet18FPN_fusekw': dict(cls='CpnResNet18FPN', kwargs=dict(
+        in_channels=3, score_features=['1', '2', '3'], contour_features=['1', '2'], refinement_features=['0', '1', '2'],
+        fuse_kwargs=dict(norm_layer=None, activation=None, bias=False),
+        backbone_kwargs={'fpn_channels': 16, 'backbone_kwargs': {'base_channel': 8}}), cpn_kwargs=dict(_DEF),
+        core_kwargs=dict(features=dict(score=['1', '2', '3'], contour=['1', '2'], refinement=['0', '1', '2']),
+                         fuse_kwargs=dict(norm_layer=None, activation=None, bias=False))),
     'CpnResNet50UNet_feats': dict(cls='CpnResNet50UNet', kwargs=dict(
         in_channels=3, score_features='2', contour_features='2', location_features='2',
         refinement_features=['0', 'encoder.0'], backbone_kwargs=_R8), cpn_kwargs=dict(_DEF),

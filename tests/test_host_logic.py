@@ -156,6 +156,10 @@ def test_fp8_packing_passes_plan_validation(name):
     spec = ALL_SPECS[name]
     model = getattr(cda.models, spec['cls'])(**spec['kwargs'])
     plan = model.plan_for('fp8')
+    if spec['kwargs'].get('refinement_interpolation') == 'bicubic' and any(o['op'] == 'bilinear' for o in plan.ops):
+        with pytest.raises(NotImplementedError, match='bicubic'):  # bf16 / fp32 plans only (the result leaves the e4m3 range)
+            graph.pack(plan, model.state_dict(), 'cpu', precision='fp8', act_scales=[0.01] * len(plan.tensors))
+        return
     tens, ops, wblob, bblob, mblob, op_scales = graph.pack(plan, model.state_dict(), 'cpu', precision='fp8',
                                                            act_scales=[0.01 + 0.001 * i for i in range(len(plan.tensors))])
     assert wblob.dtype == torch.uint8 and all(t.channels % 64 == 0 for t in tens)
