@@ -9,7 +9,7 @@ import pytest
 
 P = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles')
 LINES = sorted(glob.glob(os.path.join(P, 'r03_bench_*.json')) + glob.glob(os.path.join(P, 'r04_bench_*.json')) +
-               glob.glob(os.path.join(P, 'r05_bench_*.json')))
+               glob.glob(os.path.join(P, 'r05_bench_*.json')) + glob.glob(os.path.join(P, 'r06_bench_*.json')))
 
 
 def _load(path):
@@ -158,3 +158,29 @@ def test_round_five_slide_lines():
         d = _load(os.path.join(P, name))
         assert d['scaling'] == 'strong' and d['value'] > floor, (name, d['value'])
         assert d['gated']['identical_to_dense'] is True and d['gated']['value'] > 1.2 * d['value']
+
+
+@pytest.mark.parametrize('name', ['r06_bench_n1.json', 'r06_bench_n1_box_a.json'])
+def test_round_six_line_carries_numeric_parity_and_configs3(name):
+    """the default line's `config.parity` is NUMBERS measured in-run (bf16 product path and fp32
+    verification path vs the oracle on one tile), `configs.lines` holds three entries incl. configs[3] on one GPU with the
+    gather / global-NMS milliseconds and the gated pass identical to the dense one, and the line states the host threads."""
+    d = _load(os.path.join(P, name))
+    par = d['config']['parity']
+    for k in ('proposals_hip', 'proposals_ref', 'iou50_match_rate', 'nms_set_f1', 'max_contour_dev_matched_px',
+              'median_contour_dev_matched_px', 'matched_detections'):
+        assert isinstance(par[k], (int, float)), k
+    assert abs(par['proposals_hip'] - par['proposals_ref']) <= 0.02 * par['proposals_ref'] and par['iou50_match_rate'] > .97
+    assert par['nms_set_f1'] > .75 and par['median_contour_dev_matched_px'] < .25
+    ns = par['fp32_path_vs_oracle']
+    assert ns['index_sets_identical'] is True and ns['classes_identical'] is True and ns['score_max_abs_diff'] < 1e-5
+    assert ns['contour_frac_off_by_more_than_1e-4'] < 5e-3  # pixel-snap flips of local_refinement
+    lines = d['configs']['lines']
+    assert [l['config'][:10] for l in lines] == ['configs[1]', 'configs[4]', 'configs[3]']
+    c3 = lines[2]
+    assert c3['tiles_total'] == 1849 and c3['slide'] == [3, 16384, 16384] and c3['batch'] == 16 and c3['stride'] == 384
+    assert abs(c3['value'] - 1849 / (c3['ms_per_step'] / 1e3)) / c3['value'] < 1e-6
+    assert c3['tile_loop_ms'] + c3['gather_ms'] + c3['global_nms_ms'] <= c3['ms_per_step'] * 1.001
+    assert c3['detections_final'] < c3['detections_gathered'] and c3['gated']['identical_to_dense'] is True
+    assert c3['gated']['value'] > c3['value']
+    assert d['host_threads_per_rank'] >= 1 and 'parity' in d['setup_s'] and 'configs' in d['setup_s']
