@@ -270,7 +270,10 @@ def cpu_baseline(sd, tile, seconds_budget=12.):
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import cpn_oracle as orc
     phys = _physical_cores() or (os.cpu_count() or 1)
-    cores = max(1, min(phys, 32))
+    quota = _cpu_quota()
+    # threads: min(physical cores, 32, the CPUs the container may keep busy) -- round 6 measured on a GPU host (16-CPU quota, 128
+    # physical cores; profiles/r06_cpu_baseline_threads.txt): 8 threads 0.41, 16: 0.60, 32: 0.58, 48: 0.50 tiles/s
+    cores = max(1, min(phys, 32, int(quota) if quota and quota >= 1 else 32))
     torch.set_num_threads(cores)
     batch = 2
     x = torch.rand(batch, 3, tile, tile, generator=torch.Generator().manual_seed(2))
@@ -298,7 +301,6 @@ def cpu_baseline(sd, tile, seconds_budget=12.):
     ORACLE_TILE['x'] = x[:1]
     ORACLE_TILE['proposals'] = orc.cpn_postprocess(s_, l_, r_, f_, input_size=size, uncertainty=u_, nms=False)
     ORACLE_TILE['detections'] = orc.cpn_postprocess(s_, l_, r_, f_, input_size=size, uncertainty=u_, nms=True)
-    quota = _cpu_quota()
     out['cpu_quota'] = quota  # (CPUs the container's cgroup lets it keep busy; None = no limit found)
     if quota is not None:
         out['sample'] += f'; the container may keep {quota:g} CPUs busy (cgroup cpu.max) of the host\'s {phys} physical cores'
