@@ -289,6 +289,22 @@ class _Engine:
         cin = self.plan.meta.get('in_channels')
         if cin is not None and x.shape[1] != cin:  # (a slot's input copy would silently broadcast a 1-channel batch)
             raise ValueError(f'inputs have {x.shape[1]} channels, the model was built for {cin}')
+        if _timed is None and _absmax is None and nb < n and self.precision != 'fp32' and not gated:
+            # a batch the engine has to split (2^31-byte tensors): every balanced sub-batch is a run of its own, so that it replays
+            # its hipGraph like any other shape (round 6: configs[4]'s 8 x 1024^2 ran its 4 + 4 tiles through ~125 eager launches
+            # each); the head maps of the parts are concatenated (copies out of the graph slots: always safe to keep)
+            parts, unc = [], []
+            keep = -(-n // nb) <= self.GRAPH_SLOTS  # (more parts than slots: a part's maps must be copied out before its slot returns)
+            for i0 in range(0, n, nb):
+                parts.append(self.run(x[i0:i0 + nb], order_total, refinement, static_ok=keep))
+                unc.append(self.last_uncertainty)
+            self.last_uncertainty = None if unc[0] is None else torch.cat(unc)
+            self.last_sparse = None
+            cat = lambda i: None if parts[0][i] is None else torch.cat([p_[i] for p_ in parts])
+            flag = parts[0][4].clone()
+            for p_ in parts[1:]:
+                flag = torch.maximum(flag, p_[4])
+            return cat(0), cat(1), cat(2), cat(3), flag
         slot = None
         if _timed is None and _absmax is None and nb == n and self.precision != 'fp32':
             # kernel-selection switches that are read per launch are frozen into a captured graph: part of the key

@@ -1116,3 +1116,29 @@ def test_error_behaviour_of_options_recorded_from_the_reference(dev):
     assert rec['refinement_interpolation_nearest_u22_forward'] is None
     mu = cda.models.CpnU22(3, refinement_interpolation='nearest', backbone_kwargs={'backbone_kwargs': {'base_channels': 8}}).to(dev)
     mu(x)  # level 0 has the input size: no resize, the mode is never used
+
+
+def test_split_batches_replay_their_graphs_and_equal_whole_batches(dev, monkeypatch):
+    """A batch the engine must split (2^31-byte tensors; forced here through ``max_batch``) runs as balanced sub-batches that are
+    graph runs of their own (round 6: they used to be eager launches): same head maps as the unsplit batch, bit for bit, across
+    repeated calls (the parts live in hipGraph slots and are copied out before a slot returns) -- two parts (<= GRAPH_SLOTS) and
+    five parts (> GRAPH_SLOTS), ragged last part included."""
+    from celldetection_amd import cpn
+    model, g = build('CpnResNet18FPN', dev)
+    model.sparse_heads = False
+    x = torch.as_tensor(g['x']).to(dev)
+    x = torch.cat([x, x.flip(-1), x.flip(-2)])[:5].contiguous()   # 5 images
+    whole = [t.clone() for t in model.core_forward(x)]
+    for cap in (3, 1):
+        monkeypatch.setattr(cpn._Engine, 'max_batch', lambda self, n, h, w, cap=cap: -(-n // -(-n // min(n, cap))))
+        for rep in range(4):  # (a shape is captured the second time in a row it is seen; later calls replay)
+            parts = model.core_forward(x)
+            for a, b in zip(parts, whole):
+                assert torch.equal(a, b), (cap, rep)
+        y = model(x)
+        assert len(y['scores']) == 5
+    monkeypatch.undo()
+    y0 = model(x)
+    for k in KEYS:
+        for a, b in zip(y[k], y0[k]):
+            assert torch.equal(a, b), k
