@@ -882,14 +882,25 @@ def main():
                                        'ms_per_step': 1e3 * dts / steps2,
                                        'conv_graph_ms': sum(a.elapsed_time(b) for a, b in evs) / steps2,
                                        'step_mode': 'forward() per step (dense graph), synchronous'}
-            out['gated'] = gated_lines(model, x, args, timed, warm_engine, gf, peak)
+            try:
+                out['gated'] = gated_lines(model, x, args, timed, warm_engine, gf, peak)
+            except Exception as e:
+                out['gated'] = {'error': f'{type(e).__name__}: {e}'}
             phase('extras')
             if (args.model, args.batch, args.tile) == ('CpnResNeXt101UNet', 16, 512):
-                out['configs'] = configs_lines(dev)
-                out['configs']['lines'].append(slide_line(model, dev, args))
+                # (sub-measurements outside the headline's timed region: a failure here must not cost the line)
+                try:
+                    out['configs'] = configs_lines(dev)
+                    out['configs']['lines'].append(slide_line(model, dev, args))
+                except Exception as e:
+                    out.setdefault('configs', {'lines': []})['error'] = f'{type(e).__name__}: {e}'
+                    torch.cuda.empty_cache()
                 phase('configs')
         if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline(sd, args.tile)
+            try:
+                out['cpu_baseline'] = cpu_baseline(sd, args.tile)
+            except Exception as e:  # (the contract asks for the object: say why it is missing rather than lose the line)
+                out['cpu_baseline'] = {'value': None, 'unit': 'tiles/s', 'cores': 0, 'kind': 'port', 'sample': f'failed: {type(e).__name__}: {e}'}
             phase('cpu_baseline')
             if args.precision == 'bf16' and ORACLE_TILE:
                 try:
