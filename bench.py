@@ -861,9 +861,10 @@ def main():
                              'random_operands': 0.794 if args.precision == 'fp8' else 0.701,
                              'source': 'profiles/r05_kernel_experiments.txt #8 (one MI355X box; power / clock bound)'},
                          # ... and with the operand fragments re-read from LDS every K step (the conv kernels' 2 x 4 wave tile, 6 reads per
-                         # 8 MFMAs, two fragment sets; no DMA, no barrier, no addressing): the bound of any LDS-fed bf16 main loop
-                         'lds_fed_mfma_loop_frac_of_peak': None if args.precision == 'fp8' else {
-                             'zero_operands': 0.905, 'random_operands': 0.615,
+                         # 8 MFMAs, two fragment sets; no DMA, no barrier, no addressing): the bound of any LDS-fed main loop
+                         'lds_fed_mfma_loop_frac_of_peak': {
+                             'zero_operands': 0.899 if args.precision == 'fp8' else 0.905,
+                             'random_operands': 0.677 if args.precision == 'fp8' else 0.615,
                              'source': 'profiles/r06_kernel_experiments.txt #14 (tools/probes/mfma_lds_ratio.hip)'}},
         }
         if gated is not None:
