@@ -469,6 +469,9 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
     HaloGeo G;
     G.sub = PW ? a.stride : 1;
     G.n = n; G.iy0 = RPF * oy0 * (PW ? a.stride : S) - pad_y; G.ix0 = ox0 * (PW ? a.stride : S) - pad_x;
+#ifdef CPN_EXP_HALO_SAMETILE  // (tuning ablation, wrong results: every workgroup stages the input tile of workgroup 0 -> the halo DMA hits the L2)
+    G.n = 0; G.iy0 = -pad_y; G.ix0 = -pad_x;
+#endif
     G.Hin = a.Hin; G.Win = a.Win;
     G.up0 = a.up0; G.up1 = a.up1;
     G.Hs0 = a.Hs0; G.Ws0 = a.Ws0; G.Hs1 = a.Hs1; G.Ws1 = a.Ws1;
@@ -532,7 +535,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
     unsigned f_voff[FQ];
     unsigned f_soff = 0;
     if constexpr (FL && !BR) {
-        f_soff = (unsigned) (((size_t) n * a.Hs0 * a.Ws0 * a.c0_stride + cin0) * ES);
+        f_soff = (unsigned) (((size_t) G.n * a.Hs0 * a.Ws0 * a.c0_stride + cin0) * ES);
 #pragma unroll
         for (int it = 0; it < FQ; ++it) {
             const int idx = ((wave + it * C::NWAVES) << 6) + lane;
@@ -545,6 +548,19 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
     }
 
 #define HALO_DMA(CHUNK) HALO_DMA_RANGE(CHUNK, 0, hinstr)
+    // cache policy of the activation / weight DMA (kernel A/B: -DCPN_HALO_AUX=2 = nt ...) and the traffic-free ablation of the halo DMA
+#ifndef CPN_HALO_AUX
+#define CPN_HALO_AUX 0
+#endif
+#ifndef CPN_W_AUX
+#define CPN_W_AUX 0
+#endif
+#ifndef CPN_EXP_HALO_OOB
+#define CPN_EXP_HALO_OOB 0
+#endif
+#ifndef CPN_EXP_HALO_NOISSUE  // (tuning ablation, wrong results: the halo path computes its addresses but issues no DMA instruction)
+#define CPN_EXP_HALO_NOISSUE 0
+#endif
 
     // instructions [Q0, Q1) of the halo tile of chunk CHUNK
 #define HALO_DMA_RANGE(CHUNK, Q0, Q1)                                                                          \
@@ -555,7 +571,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
         unsigned char *dstb_ = smem + (c_ & nhb_mask) * halo_buf;                                              \
         _Pragma("unroll") for (int it_ = 0; it_ < FQ; ++it_) {                                                 \
             const int q_ = wave + it_ * C::NWAVES;                                                             \
-            if (q_ < hinstr) bdma16(rs0, f_voff[it_], s_, dstb_ + (q_ << 10));                                 \
+            if (q_ < hinstr) bdma16<CPN_HALO_AUX>(rs0, f_voff[it_], s_, dstb_ + (q_ << 10));                   \
         }                                                                                                      \
     } else HALO_DMA_RANGE_ROWS(CHUNK, Q0, Q1)
 
@@ -583,13 +599,16 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
                 const int row_ = q_ / IPR, seg_ = q_ - row_ * IPR;          /* wave-uniform */                 \
                 const int iy_ = G.iy0 + row_ * G.sub;                                                          \
                 const bool ok_ = iy_ >= 0 && iy_ < G.Hin;                                                      \
-                const int ys_ = up_ ? nearest_src(iy_, sy_, Hs_) : iy_;                                        \
+                /* (wave-uniform, but the float path of nearest_src lives in VGPRs: named uniform, else hipcc wraps */ \
+                /*  every DMA instruction in a waterfall loop over its scalar offset) */                        \
+                const int ys_ = __builtin_amdgcn_readfirstlane(up_ ? nearest_src(iy_, sy_, Hs_) : iy_);        \
                 unsigned v_ = col_[0];                                                                         \
                 _Pragma("unroll") for (int j_ = 1; j_ < IPR; ++j_) v_ = seg_ == j_ ? col_[j_] : v_;           \
-                v_ = ok_ ? v_ : OOB_LANE;          /* rows above / below the image: every lane reads zeros */   \
+                v_ = (ok_ && !CPN_EXP_HALO_OOB) ? v_ : OOB_LANE;  /* rows above / below the image: every lane reads zeros */ \
                 const unsigned s_ = ok_ ? (unsigned) (img_ + ys_) * rowb_ + soff_ : 0u;                        \
-                if (from0_) bdma16(rs0, v_, s_, dstb_ + (q_ << 10));                                           \
-                else bdma16(rs1, v_, s_, dstb_ + (q_ << 10));                                                  \
+                if (CPN_EXP_HALO_NOISSUE) asm volatile("" :: "v"(v_), "s"(s_), "s"((unsigned) (size_t) (dstb_ + (q_ << 10)))); \
+                else if (from0_) bdma16<CPN_HALO_AUX>(rs0, v_, s_, dstb_ + (q_ << 10));                        \
+                else bdma16<CPN_HALO_AUX>(rs1, v_, s_, dstb_ + (q_ << 10));                                    \
             }                                                                                                  \
         }                                                                                                      \
     }
@@ -600,14 +619,14 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
         const unsigned soff_ = (unsigned) (cin0 + c_ * CH) * (unsigned) ES;                                    \
         unsigned char *dstb_ = smem + (c_ & nhb_mask) * halo_buf;                                              \
         _Pragma("unroll") for (int it = 0; it < A_INSTR_WAVE; ++it)                                            \
-            if (a_ok[it]) bdma16(rs0, a_voff[it], soff_, dstb_ + ((wave + it * C::NWAVES) << 10));             \
+            if (a_ok[it]) bdma16<CPN_HALO_AUX>(rs0, a_voff[it], soff_, dstb_ + ((wave + it * C::NWAVES) << 10)); \
     }
 
     // stages the (two) weight slabs of the next step in order into weight buffer BUF
 #define W_DMA(BUF)                                                                                             \
     if constexpr (!RW) {                                                                                       \
         _Pragma("unroll") for (int it = 0; it < W_IW; ++it)                                                    \
-            bdma16(rsw, w_voff[it], wsoff + (unsigned) w_k[it] * item_bytes, smem + w_m0[it] + (BUF) * WBUF);  \
+            bdma16<CPN_W_AUX>(rsw, w_voff[it], wsoff + (unsigned) w_k[it] * item_bytes, smem + w_m0[it] + (BUF) * WBUF); \
         wsoff += IPS * item_bytes;                                                                             \
     }
 
@@ -632,6 +651,9 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
     const unsigned nr_lane = NR ? (unsigned) ((l31 >> 4) * S * PITCH * REC) : 0u;  // narrow: lanes 16..31 = the fragment's 2nd row
 
     // ---- software-pipelined main loop -------------------------------------------------------------------------
+#ifndef CPN_BACKEDGE_WAIT  // 1 (default): the bf16 loops close every iteration with lgkmcnt(0); 0: the first group's reads stay in flight
+#define CPN_BACKEDGE_WAIT 1  // across the back-edge; 2: the wait pinned behind the last MFMA group -- all three within +-1 % (r06 experiments #17)
+#endif
     // A step has up to four MFMA groups (item x k-half), each WN + WM fragments and WN*WM MFMAs.  Two fragment
     // register sets alternate (A: groups 0,2; B: groups 1,3): the ds_reads of group g+1 are issued BEFORE the MFMAs
     // of group g, so LDS latency hides behind the matrix pipe (ablation: the non-MFMA skeleton of the un-pipelined
@@ -669,16 +691,24 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
         _Pragma("unroll") for (int j = 0; j < WN; ++j)                                                         \
             _Pragma("unroll") for (int f = 0; f < WM; ++f) CPN_EXP_MMA(acc[j][f], WF[j], PF[f]);               \
     }
+    // Branches of the step boundary that are taken once per chunk (or never: the 1x1 schedules of this instantiation): named unlikely,
+    // hipcc places their blocks behind the loop and the common path falls through -- bf16 +0.5 ... +2.8 % (two taken long-distance
+    // branches less per step), e4m3 neutral to negative (profiles/r06_kernel_experiments.txt #15): bf16 build only.
+#if CPN_FP8
+#define CPN_RARE(X) (X)
+#else
+#define CPN_RARE(X) __builtin_expect((X), 0)
+#endif
     // DMA issued at the transition INTO step ST1 (first item IA, flattened index 2*ST1): the weights of step
     // ST1+1 and the halo tiles that step ST1+1 (1x1) / the next chunk (KxK) will need
 #define ISSUE_AT_TRANSITION(IA, ST1, CHUNK_CHANGED)                                                            \
     {                                                                                                          \
         const int idx2_ = IPS * (ST1) + IPS; /* first item of step ST1+1 */                                    \
         if (idx2_ < nitems) {                                                                                  \
-            if (pw_fast) {                                                                                     \
+            if (CPN_RARE(pw_fast)) {                                                                           \
                 if (idx2_ < nreal) CPN_EXP_H(PW_HALO_DMA(idx2_));                                              \
                 if (idx2_ + 1 < nreal) CPN_EXP_H(PW_HALO_DMA(idx2_ + 1));                                      \
-            } else if (pw) {                                                                                   \
+            } else if (CPN_RARE(pw)) {                                                                         \
                 if (idx2_ < nreal) CPN_EXP_H(HALO_DMA(idx2_));                                                 \
                 if (idx2_ + 1 < nreal) CPN_EXP_H(HALO_DMA(idx2_ + 1));                                         \
             }                                                                                                  \
@@ -694,7 +724,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
     // step that follows the chunk change is early enough: the tile is first read >= floor(ntaps / 2) steps later
     int bl_pending = -1;
 #define CPN_HALO_AT_TRANSITION(IA, CHUNK_CHANGED)                                                              \
-    if (!pw && (CHUNK_CHANGED) && (IA).c + 1 < nchunks) {                                                      \
+    if (CPN_RARE(!pw && (CHUNK_CHANGED) && (IA).c + 1 < nchunks)) {                                            \
         if constexpr (BL) bl_pending = (IA).c + 1;                                                             \
         else CPN_EXP_H(HALO_DMA((IA).c + 1));                                                                  \
     }
@@ -863,6 +893,9 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
         }
     }
 
+#ifdef CPN_EXP_CLOCK  // (tuning probe: shader clock of the main loop = s_memtime ticks per 100-MHz s_memrealtime tick, one workgroup per launch)
+    const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     // ---- prologue: stage step 0, open it, stage step 1, first fragment reads
     HALO_DMA(0);
     if (pw && nchunks > 1) HALO_DMA(1);
@@ -1125,7 +1158,9 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
         wa = (unsigned) (ldsW_off + ((st + 1) & 1) * WBUF) + w_lane;
         LOAD_GROUP(wA, pA, pa, wa);                   // first group of step st+1
         MMA_GROUP(wB, pB, NF);                        // item 3, k-half 1 (operands already in registers)
+#if CPN_BACKEDGE_WAIT == 1                            // (see the two-item loop below)
         wait_frags<0, WN, WM>(wA, pA);
+#endif
     }
     QSTEP_HEAD();                                     // last step
     MMA_GROUP(wB, pB, 0);
@@ -1134,6 +1169,9 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
     } else {
     // every step that is followed by another step holds two items: the loop body is branch-free with respect to
     // the accumulators and fragment sets (conditional MFMA groups made hipcc rename/spill accumulators)
+#define PIN_ACC_ALL()                                                                                          \
+    _Pragma("unroll") for (int j_ = 0; j_ < WN; ++j_)                                                          \
+        _Pragma("unroll") for (int f_ = 0; f_ < WM; ++f_) asm volatile("" : "+v"(acc[j_][f_]))
     for (int st = 0; st + 1 < nsteps; ++st) {
         LOAD_GROUP(wB, pB, pa ^ 32u, wa ^ 32u);      // item 0, k-half 1
         MMA_GROUP(wA, pA, NF);                        // item 0, k-half 0
@@ -1152,7 +1190,12 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
         wa = (unsigned) (ldsW_off + ((st + 1) & 1) * WBUF) + w_lane;
         LOAD_GROUP(wA, pA, pa, wa);                   // first group of step st+1
         MMA_GROUP(wB, pB, NF);                        // last group of step st (operands already in registers)
+#if CPN_BACKEDGE_WAIT == 1
         wait_frags<0, WN, WM>(wA, pA);                // nothing is in flight across the loop back-edge
+#elif CPN_BACKEDGE_WAIT == 2
+        PIN_ACC_ALL();                                // the same wait, held behind the eight MFMAs of the group
+        wait_frags<0, WN, WM>(wA, pA);
+#endif
         CPN_BL_FLUSH();
         i0 = n0i;
         i1 = next_item(n0i, KH, KW);
@@ -1182,6 +1225,12 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
 #undef ISSUE_AT_TRANSITION
 #undef ITEM_PADDR
 
+#ifdef CPN_EXP_CLOCK
+    if (tid == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && blockIdx.z == 0) {
+        const unsigned long long dc = __builtin_readcyclecounter() - clk_c0, dr = __builtin_amdgcn_s_memrealtime() - clk_r0;
+        printf("CLK steps %d core_ticks %llu ref_ticks %llu -> %.0f MHz, %.0f core cycles / step\n", nsteps, dc, dr, 100. * dc / dr, (double) dc / nsteps);
+    }
+#endif
     // ---- epilogue
 #ifdef CPN_EXP_NOEPI
     if (a.N < 0)

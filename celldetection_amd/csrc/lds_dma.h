@@ -32,9 +32,11 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t make_rsrc(const void *base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void *) base, 0, (int) bytes, 0x00020000);
 }
+// AUX = cache policy bits of the instruction (gfx94x / gfx950: 1 = sc0, 2 = nt, 16 = sc1)
+template <int AUX = 0>
 __device__ __forceinline__ void bdma16(rsrc_t rsrc, unsigned lane_off, unsigned scalar_off, unsigned char *lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *) lds_wave_base, 16,
-                                             (int) lane_off, (int) scalar_off, 0, 0);
+                                             (int) lane_off, (int) scalar_off, 0, AUX);
 }
 
 // ---- hand-counted LDS fragment reads ----------------------------------------------------------------------------
