@@ -402,6 +402,25 @@ def _sclk_mhz(dev):
     return None
 
 
+def shader_clock_probe(args):
+    """roofline.shader_clock: shader MHz and matrix-pipe duty of the bf16 conv kernels while the conv graph of this workload runs,
+    measured inside the kernels by the probe library (tools/clock_probe.py, include/cpn_hip.h cpn_debug_clock_probe) in a child
+    process -- this process keeps the product library.  Outside every timed region; the GPU is idle here while the child runs."""
+    lib = os.path.join(ROOT, 'celldetection_amd', 'libcpn_hip_clock.so')
+    if not os.path.isfile(lib):
+        return {'error': 'celldetection_amd/libcpn_hip_clock.so is not built (python -m celldetection_amd.build)'}
+    env = dict(os.environ, CPN_HIP_LIB=lib)
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'clock_probe.py'), '20', args.model, str(args.batch), str(args.tile)],
+                           capture_output=True, text=True, timeout=300, env=env)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+        if r.returncode or not line:
+            return {'error': f'clock probe failed (rc {r.returncode}): {r.stderr.strip().splitlines()[-1:]}'}
+        return json.loads(line[-1])
+    except Exception as e:
+        return {'error': f'{type(e).__name__}: {e}'}
+
+
 def host_threads(world):
     """CPU threads one rank may use: the CPUs this container may keep busy (cgroup quota, else the visible CPUs) shared by the
     ranks of the node.  8 ranks x `os.cpu_count() // 8` = 32 threads each on a 16-CPU quota is the CFS throttling measured in
@@ -893,6 +912,8 @@ def main():
             except Exception as e:
                 out['gated'] = {'error': f'{type(e).__name__}: {e}'}
             phase('extras')
+            out['roofline']['shader_clock'] = shader_clock_probe(args)
+            phase('shader_clock')
             if (args.model, args.batch, args.tile) == ('CpnResNeXt101UNet', 16, 512):
                 # (sub-measurements outside the headline's timed region: a failure here must not cost the line)
                 try:

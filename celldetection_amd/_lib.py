@@ -10,7 +10,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CPN_HIP_LIB') or os.path.join(HERE, 'libcpn_hip.so')  # env: kernel A/B tuning only
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 PRECISION_BF16, PRECISION_F32, PRECISION_FP8 = 0, 1, 2
 E_INVALID, E_UNSUPPORTED, E_WORKSPACE = -1, -2, -3
 
@@ -115,6 +115,7 @@ _SIGNATURES = [
                                                c_float, c_float, c_float, c_void_p, c_void_p]),
     ('cpn_histogram', ctypes.c_int, [c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
     ('cpn_rescale_to_uint8', ctypes.c_int, [c_void_p, c_int32, c_int64, c_double, c_double, c_void_p, c_void_p]),
+    ('cpn_debug_clock_probe', ctypes.c_int, [POINTER(ctypes.c_uint64), c_int32]),
     ('cpn_window_any', ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p]),
     ('cpn_labels_prepare', ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                           c_void_p, c_void_p]),

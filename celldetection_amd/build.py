@@ -12,6 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libcpn_hip.so')
+OUT_CLOCK = os.path.join(HERE, 'libcpn_hip_clock.so')  # measurement variant: shader-clock probe in the bf16 conv kernels
 ARCH = 'gfx950'
 
 SOURCES = {
@@ -67,6 +68,22 @@ def build(force=False, verbose=True):
             raise RuntimeError(f'hipcc failed on {src}')
     if force or procs or _stale(OUT, objs):
         cmd = [_hipcc(), f'--offload-arch={ARCH}', '-shared', '-fPIC'] + objs + ['-o', OUT]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    # libcpn_hip_clock.so: the same library with the shader-clock probe compiled into the bf16 conv kernels
+    # (include/cpn_hip.h cpn_debug_clock_probe; bench.py runs it in a child process next to the roofline numbers)
+    s = os.path.join(CSRC, 'conv_igemm.hip')
+    o = os.path.join(objdir, 'conv_igemm_clock.o')
+    if force or _stale(o, [s] + hdrs):
+        cmd = [_hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-c', s, '-o', o, '-DCPN_EXP_CLOCK=2'] + \
+              os.environ.get('CPN_HIPCC_FLAGS', '').split()
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    cobjs = [o if x.endswith(os.sep + 'conv_igemm.o') else x for x in objs]
+    if force or _stale(OUT_CLOCK, cobjs):
+        cmd = [_hipcc(), f'--offload-arch={ARCH}', '-shared', '-fPIC'] + cobjs + ['-o', OUT_CLOCK]
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)

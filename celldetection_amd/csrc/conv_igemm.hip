@@ -33,6 +33,7 @@
 #include <atomic>
 #include <cstdlib>
 
+#include "cpn_error.h"
 #include "cpn_kernels.h"
 #include "lds_dma.h"
 
@@ -363,6 +364,11 @@ __device__ __forceinline__ ItemState next_item(const ItemState I, int KH, int KW
     }
     return N;
 }
+
+#if defined(CPN_EXP_CLOCK) && CPN_EXP_CLOCK == 2 && !CPN_FP8
+// [bin][core ticks, 100-MHz ticks, steps, launches] of the probed workgroup of every launch; bins: 7x7 | 3x3 | other tap counts
+__device__ unsigned long long g_clock_probe[12];
+#endif
 
 template <int TH, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE_S1F || MODE == MODE_BRF) ? 2 : 1)) void conv_igemm_kernel(const ConvArgs a) {
@@ -893,7 +899,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
         }
     }
 
-#ifdef CPN_EXP_CLOCK  // (tuning probe: shader clock of the main loop = s_memtime ticks per 100-MHz s_memrealtime tick, one workgroup per launch)
+#ifdef CPN_EXP_CLOCK  // (probe: shader clock of the main loop = s_memtime ticks per 100-MHz s_memrealtime tick, one workgroup per launch)
     const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     // ---- prologue: stage step 0, open it, stage step 1, first fragment reads
@@ -1228,7 +1234,12 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
 #ifdef CPN_EXP_CLOCK
     if (tid == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && blockIdx.z == 0) {
         const unsigned long long dc = __builtin_readcyclecounter() - clk_c0, dr = __builtin_amdgcn_s_memrealtime() - clk_r0;
+#if CPN_EXP_CLOCK == 2 && !CPN_FP8  // the probe library (libcpn_hip_clock.so): sums per tap count, read by cpn_debug_clock_probe
+        unsigned long long *g = g_clock_probe + 4 * (ntaps == 49 ? 0 : (ntaps == 9 ? 1 : 2));
+        atomicAdd(g, dc); atomicAdd(g + 1, dr); atomicAdd(g + 2, (unsigned long long) nsteps); atomicAdd(g + 3, 1ull);
+#else
         printf("CLK steps %d core_ticks %llu ref_ticks %llu -> %.0f MHz, %.0f core cycles / step\n", nsteps, dc, dr, 100. * dc / dr, (double) dc / nsteps);
+#endif
     }
 #endif
     // ---- epilogue
@@ -1785,4 +1796,22 @@ double conv_executed_flops(const ConvArgs &a) {
 namespace cpn {
 int launch_conv_fp8(const ConvArgs &a, hipStream_t stream) { return cpn_fp8::launch_conv(a, stream); }
 }  // namespace cpn
+#else
+// include/cpn_hip.h: shader-clock probe of the bf16 conv kernels (compiled in with -DCPN_EXP_CLOCK=2 only: libcpn_hip_clock.so)
+extern "C" int cpn_debug_clock_probe(unsigned long long *out12, int reset) {
+#if defined(CPN_EXP_CLOCK) && CPN_EXP_CLOCK == 2
+    if (out12) {
+        const int rc = cpn::check_hip(hipMemcpyFromSymbol(out12, HIP_SYMBOL(cpn::g_clock_probe), 12 * sizeof(unsigned long long)), "cpn_debug_clock_probe");
+        if (rc) return rc;
+    }
+    if (reset) {
+        const unsigned long long zero[12] = {};
+        return cpn::check_hip(hipMemcpyToSymbol(HIP_SYMBOL(cpn::g_clock_probe), zero, sizeof(zero)), "cpn_debug_clock_probe (reset)");
+    }
+    return 0;
+#else
+    (void) out12; (void) reset;
+    return cpn::fail(1, "cpn_debug_clock_probe: this library was built without the clock probe (-DCPN_EXP_CLOCK=2: libcpn_hip_clock.so)");
+#endif
+}
 #endif

@@ -60,6 +60,21 @@ def test_abi_exports_every_declared_symbol():
     assert lib.cpn_nms_workspace_bytes(1000, 1000, 1) > 1000 * 16 * 8
 
 
+def test_clock_probe_lives_in_the_measurement_library_only():
+    """include/cpn_hip.h cpn_debug_clock_probe: the product library carries no probe (the call fails with a message, without touching
+    the device); libcpn_hip_clock.so is built next to it and exports the same ABI."""
+    import ctypes
+    lib = _lib.load()
+    buf = (ctypes.c_uint64 * 12)()
+    assert lib.cpn_debug_clock_probe(buf, 0) == 1
+    assert b'without the clock probe' in lib.cpn_last_error()
+    clock = ctypes.CDLL(os.path.join(ROOT, 'celldetection_amd', 'libcpn_hip_clock.so'), mode=ctypes.RTLD_LOCAL)
+    for name in _lib.EXPORTED_SYMBOLS:
+        assert hasattr(clock, name), name
+    clock.cpn_abi_version.restype = ctypes.c_int
+    assert clock.cpn_abi_version() == _lib.ABI_VERSION
+
+
 def test_no_cpu_fallback():
     model = cda.models.CpnU22(3, backbone_kwargs={'backbone_kwargs': {'base_channels': 8}})
     with pytest.raises(RuntimeError, match='GPU'):
