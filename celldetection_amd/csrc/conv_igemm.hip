@@ -366,12 +366,16 @@ __device__ __forceinline__ ItemState next_item(const ItemState I, int KH, int KW
 }
 
 #if defined(CPN_EXP_CLOCK) && CPN_EXP_CLOCK == 2 && !CPN_FP8
-// [bin][core ticks, 100-MHz ticks, steps, launches] of the probed workgroup of every launch; bins: 7x7 | 3x3 | other tap counts
-__device__ unsigned long long g_clock_probe[12];
+// [bin][core ticks, 100-MHz ticks, steps, launches, 4 x matrix-pipe cycles per SIMD] of the probed workgroup of every launch;
+// bins: 7x7 | 3x3 | other tap counts
+__device__ unsigned long long g_clock_probe[15];
 #endif
 
 template <int TH, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE_S1F || MODE == MODE_BRF) ? 2 : 1)) void conv_igemm_kernel(const ConvArgs a) {
+#if defined(CPN_EXP_CLOCK) && CPN_EXP_CLOCK == 1
+    const unsigned long long clk_entry = __builtin_readcyclecounter();
+#endif
     using C = Cfg<TH, BN, WM, WN>;
     constexpr int S = ModeCfg<MODE>::S;
     constexpr int PITCH = ModeCfg<MODE>::PITCH;
@@ -1232,13 +1236,21 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
 #undef ITEM_PADDR
 
 #ifdef CPN_EXP_CLOCK
+    const unsigned long long clk_loop_end = __builtin_readcyclecounter();
+    unsigned long long clk_print = 0;  // (the printf below is a host call: its cycles are taken out of the epilogue phase)
     if (tid == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && blockIdx.z == 0) {
-        const unsigned long long dc = __builtin_readcyclecounter() - clk_c0, dr = __builtin_amdgcn_s_memrealtime() - clk_r0;
+        const unsigned long long dc = clk_loop_end - clk_c0, dr = __builtin_amdgcn_s_memrealtime() - clk_r0;
 #if CPN_EXP_CLOCK == 2 && !CPN_FP8  // the probe library (libcpn_hip_clock.so): sums per tap count, read by cpn_debug_clock_probe
-        unsigned long long *g = g_clock_probe + 4 * (ntaps == 49 ? 0 : (ntaps == 9 ? 1 : 2));
+        unsigned long long *g = g_clock_probe + 5 * (ntaps == 49 ? 0 : (ntaps == 9 ? 1 : 2));
+        // matrix-pipe cycles the loop's MFMAs occupy on one SIMD x 4: a 32x32x16 bf16 MFMA = 32 cycles, 2 k-halves x WN x WM per item
+        // and wave, NWAVES / 4 waves per SIMD, two co-resident workgroups in the flat modes
+        const unsigned long long pipe4 = (unsigned long long) nsteps * IPS * (2 * WN * WM * 32) * C::NWAVES *
+                                         ((MODE == MODE_S1F || MODE == MODE_BRF) ? 2 : 1);
         atomicAdd(g, dc); atomicAdd(g + 1, dr); atomicAdd(g + 2, (unsigned long long) nsteps); atomicAdd(g + 3, 1ull);
+        atomicAdd(g + 4, pipe4);
 #else
         printf("CLK steps %d core_ticks %llu ref_ticks %llu -> %.0f MHz, %.0f core cycles / step\n", nsteps, dc, dr, 100. * dc / dr, (double) dc / nsteps);
+        clk_print = __builtin_readcyclecounter() - clk_loop_end;
 #endif
     }
 #endif
@@ -1530,6 +1542,12 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
             }
         }
     }
+#if defined(CPN_EXP_CLOCK) && CPN_EXP_CLOCK == 1  // phases of the probed workgroup: set-up (coordinates, tables), prologue + main loop, epilogue
+    __syncthreads();
+    if (tid == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && blockIdx.z == 0)
+        printf("PHASES out_mode %d setup %llu loop %llu epilogue %llu cycles\n", (int) a.out_mode, clk_c0 - clk_entry, clk_loop_end - clk_c0,
+               (unsigned long long) __builtin_readcyclecounter() - clk_loop_end - clk_print);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1798,19 +1816,19 @@ int launch_conv_fp8(const ConvArgs &a, hipStream_t stream) { return cpn_fp8::lau
 }  // namespace cpn
 #else
 // include/cpn_hip.h: shader-clock probe of the bf16 conv kernels (compiled in with -DCPN_EXP_CLOCK=2 only: libcpn_hip_clock.so)
-extern "C" int cpn_debug_clock_probe(unsigned long long *out12, int reset) {
+extern "C" int cpn_debug_clock_probe(unsigned long long *out15, int reset) {
 #if defined(CPN_EXP_CLOCK) && CPN_EXP_CLOCK == 2
-    if (out12) {
-        const int rc = cpn::check_hip(hipMemcpyFromSymbol(out12, HIP_SYMBOL(cpn::g_clock_probe), 12 * sizeof(unsigned long long)), "cpn_debug_clock_probe");
+    if (out15) {
+        const int rc = cpn::check_hip(hipMemcpyFromSymbol(out15, HIP_SYMBOL(cpn::g_clock_probe), 15 * sizeof(unsigned long long)), "cpn_debug_clock_probe");
         if (rc) return rc;
     }
     if (reset) {
-        const unsigned long long zero[12] = {};
+        const unsigned long long zero[15] = {};
         return cpn::check_hip(hipMemcpyToSymbol(HIP_SYMBOL(cpn::g_clock_probe), zero, sizeof(zero)), "cpn_debug_clock_probe (reset)");
     }
     return 0;
 #else
-    (void) out12; (void) reset;
+    (void) out15; (void) reset;
     return cpn::fail(1, "cpn_debug_clock_probe: this library was built without the clock probe (-DCPN_EXP_CLOCK=2: libcpn_hip_clock.so)");
 #endif
 }

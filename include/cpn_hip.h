@@ -386,10 +386,11 @@ int cpn_resize_f32(const float *src, float *dst, int64_t planes, int32_t Hin, in
 /* Measurement aid (no reference counterpart): shader clock of the bf16 implicit-GEMM conv kernels, measured inside the kernels.
  * Only libcpn_hip_clock.so (csrc/conv_igemm.hip compiled with -DCPN_EXP_CLOCK=2; built next to libcpn_hip.so, selected with
  * CPN_HIP_LIB) carries the probe: one workgroup of every conv launch adds the s_memtime ticks (shader clock) and the 100-MHz
- * s_memrealtime ticks its main loop took, its K steps and 1 to out12[4 * bin + 0..3], bin 0 = 7x7 convs, 1 = 3x3, 2 = other tap
- * counts.  out12 (host, may be NULL) receives the sums, reset != 0 clears them afterwards.  The product library returns 1
- * ("built without the clock probe").  bench.py reports shader MHz = 100 * ticks / ref ticks next to the roofline. */
-int cpn_debug_clock_probe(unsigned long long *out12, int reset);
+ * s_memrealtime ticks its main loop took, its K steps, 1, and 4 x the matrix-pipe cycles its MFMAs occupy per SIMD (all waves of the
+ * CU counted) to out15[5 * bin + 0..4], bin 0 = 7x7 convs, 1 = 3x3, 2 = other tap counts.  out15 (host, may be NULL) receives the
+ * sums, reset != 0 clears them afterwards.  The product library returns 1 ("built without the clock probe").  bench.py reports
+ * shader MHz = 100 * ticks / ref ticks and matrix-pipe duty = pipe cycles / ticks next to the roofline. */
+int cpn_debug_clock_probe(unsigned long long *out15, int reset);
 
 /* The same rule for ALL detections of a forwarded batch of tiles in one launch (the per-tile loop of
  * celldetection_scripts/cpn_inference.py:370-380): contour p belongs to image image_index[p] (int32, device);

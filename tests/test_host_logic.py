@@ -65,7 +65,7 @@ def test_clock_probe_lives_in_the_measurement_library_only():
     the device); libcpn_hip_clock.so is built next to it and exports the same ABI."""
     import ctypes
     lib = _lib.load()
-    buf = (ctypes.c_uint64 * 12)()
+    buf = (ctypes.c_uint64 * 15)()
     assert lib.cpn_debug_clock_probe(buf, 0) == 1
     assert b'without the clock probe' in lib.cpn_last_error()
     clock = ctypes.CDLL(os.path.join(ROOT, 'celldetection_amd', 'libcpn_hip_clock.so'), mode=ctypes.RTLD_LOCAL)

@@ -20,7 +20,6 @@ from celldetection_amd import _lib  # noqa: E402
 from celldetection_amd.synth import synth_state_dict  # noqa: E402
 
 NOMINAL_MHZ = 2400.        # MI355X peak engine clock (the 2.5 PFLOP/s bf16 figure is quoted at it)
-PIPE_CYCLES_PER_STEP = 2048.  # a pipeline step = two K items = 2 waves x 16 MFMA 32x32x16 x 2 k-halves x 32 cycles per SIMD
 
 
 def main():
@@ -32,7 +31,7 @@ def main():
     model = model.to(dev)
     x = torch.rand(batch, 3, tile, tile, generator=torch.Generator().manual_seed(1)).to(dev)
     lib = _lib.load()
-    buf = (ctypes.c_uint64 * 12)()
+    buf = (ctypes.c_uint64 * 15)()
     for _ in range(10):  # warm-up: plan, hipGraph capture, the chip's power state
         model.core_forward(x)
     torch.cuda.synchronize()
@@ -45,16 +44,18 @@ def main():
     out = {'nominal_mhz': NOMINAL_MHZ, 'graph_executions': K, 'model': name, 'batch': batch, 'tile': tile,
            'method': 's_memtime (shader clock) / s_memrealtime (100 MHz) ticks over the main loop of one workgroup per conv launch, '
                      'summed per tap count (libcpn_hip_clock.so, cpn_debug_clock_probe)'}
-    tot = [0, 0, 0, 0]
+    tot = [0, 0, 0, 0, 0]
     for i, key in enumerate(('conv7x7', 'conv3x3', 'other_taps')):
-        core, ref, steps, launches = v[4 * i:4 * i + 4]
-        tot = [t + u for t, u in zip(tot, (core, ref, steps, launches))]
+        core, ref, steps, launches, pipe4 = v[5 * i:5 * i + 5]
+        tot = [t + u for t, u in zip(tot, (core, ref, steps, launches, pipe4))]
         if launches:
             out[key] = {'mhz': round(100. * core / ref, 1), 'frac_of_nominal': round(100. * core / ref / NOMINAL_MHZ, 4),
-                        'cycles_per_step': round(core / steps, 1), 'matrix_pipe_duty': round(PIPE_CYCLES_PER_STEP / (core / steps), 4),
+                        'cycles_per_step': round(core / steps, 1), 'matrix_pipe_duty': round(pipe4 / 4. / core, 4),
                         'launches': launches}
     if tot[3]:
         out['all_convs_mhz'] = round(100. * tot[0] / tot[1], 1)
+        out['note'] = ('matrix_pipe_duty = cycles the MFMAs of the loop occupy on a SIMD (32 per 32x32x16 bf16 MFMA, all waves of the CU) / '
+                       'shader cycles of the loop; duty x frac_of_nominal = the fraction of the nominal peak the main loop sustains')
     print(json.dumps(out))
 
 
