@@ -184,3 +184,18 @@ def test_round_six_line_carries_numeric_parity_and_configs3(name):
     assert c3['detections_final'] < c3['detections_gathered'] and c3['gated']['identical_to_dense'] is True
     assert c3['gated']['value'] > c3['value']
     assert d['host_threads_per_rank'] >= 1 and 'parity' in d['setup_s'] and 'configs' in d['setup_s']
+
+
+def test_final_line_carries_the_shader_clock_measured_inside_the_conv_kernels():
+    """`roofline.shader_clock` (tools/clock_probe.py on libcpn_hip_clock.so, child process of bench.py): MHz and matrix-pipe duty of
+    the 7x7 heads and the 3x3 convs while the flagship graph runs; duty x clock / nominal must bracket what the HIP events say about
+    the dominant kernel (main loop only vs whole launch: prologue, epilogue and fused ReadOut tails are ~5 % of a workgroup)."""
+    d = _load(os.path.join(P, 'r06_bench_n1.json'))
+    sc = d['roofline']['shader_clock']
+    assert sc['nominal_mhz'] == 2400. and sc['graph_executions'] == 20
+    for k in ('conv7x7', 'conv3x3'):
+        assert 1200. < sc[k]['mhz'] < 2400. and 0.5 < sc[k]['matrix_pipe_duty'] < 1., (k, sc[k])  # below nominal: the power limit
+    loop_frac = sc['conv7x7']['matrix_pipe_duty'] * sc['conv7x7']['frac_of_nominal']
+    launch_frac = d['roofline']['dominant_kernel']['frac']
+    assert launch_frac < loop_frac < 1.12 * launch_frac, (loop_frac, launch_frac)
+    assert sc['conv7x7']['launches'] == 20 * 4  # four 49-tap launches per graph execution
