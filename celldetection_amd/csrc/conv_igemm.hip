@@ -716,11 +716,11 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
         const int idx2_ = IPS * (ST1) + IPS; /* first item of step ST1+1 */                                    \
         if (idx2_ < nitems) {                                                                                  \
             if (CPN_RARE(pw_fast)) {                                                                           \
-                if (idx2_ < nreal) CPN_EXP_H(PW_HALO_DMA(idx2_));                                              \
-                if (idx2_ + 1 < nreal) CPN_EXP_H(PW_HALO_DMA(idx2_ + 1));                                      \
+                if (idx2_ < nreal) { CPN_EXP_H(PW_HALO_DMA(idx2_)); }                                          \
+                if (idx2_ + 1 < nreal) { CPN_EXP_H(PW_HALO_DMA(idx2_ + 1)); }                                  \
             } else if (CPN_RARE(pw)) {                                                                         \
-                if (idx2_ < nreal) CPN_EXP_H(HALO_DMA(idx2_));                                                 \
-                if (idx2_ + 1 < nreal) CPN_EXP_H(HALO_DMA(idx2_ + 1));                                         \
+                if (idx2_ < nreal) { CPN_EXP_H(HALO_DMA(idx2_)); }                                             \
+                if (idx2_ + 1 < nreal) { CPN_EXP_H(HALO_DMA(idx2_ + 1)); }                                     \
             }                                                                                                  \
             CPN_EXP_W(W_DMA(((ST1) + 1) & 1));                                                                 \
         }                                                                                                      \
@@ -736,7 +736,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
 #define CPN_HALO_AT_TRANSITION(IA, CHUNK_CHANGED)                                                              \
     if (CPN_RARE(!pw && (CHUNK_CHANGED) && (IA).c + 1 < nchunks)) {                                            \
         if constexpr (BL) bl_pending = (IA).c + 1;                                                             \
-        else CPN_EXP_H(HALO_DMA((IA).c + 1));                                                                  \
+        else { CPN_EXP_H(HALO_DMA((IA).c + 1)); }                                                              \
     }
 #define CPN_BL_FLUSH()                                                                                         \
     if constexpr (BL) {                                                                                        \
@@ -908,7 +908,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
 #endif
     // ---- prologue: stage step 0, open it, stage step 1, first fragment reads
     HALO_DMA(0);
-    if (pw && nchunks > 1) HALO_DMA(1);
+    if (pw && nchunks > 1) { HALO_DMA(1); }
     if constexpr (!BR) W_DMA(0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (lgkmcnt: the MODE_BL halo is written with ds_write)
     __builtin_amdgcn_s_barrier();
