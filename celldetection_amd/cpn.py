@@ -11,7 +11,7 @@ through the fused decode / NMS kernels; PyTorch only provides device memory, str
 """
 import os
 import warnings
-from collections import OrderedDict
+from collections import OrderedDict, deque
 from ctypes import c_void_p
 
 import torch
@@ -615,6 +615,42 @@ class CPN(nn.Module):
             raise ValueError('align_corners option can only be set with the interpolating modes: linear | bilinear | bicubic | '
                              'trilinear')
 
+    # ---- batches the engine has to split (2^31-byte tensors, e.g. 8 x 3 x 1024^2 on the 256-channel FPN maps) on the forward paths:
+    # the score-gated heads read the heads' source of ONE graph run, so such a batch is forwarded as balanced sub-batches, each
+    # a complete forward of its own (gated conv graph -> post-processing), and the per-image results are put back together.
+    # Every output of CPN.forward is per image (decode, refinement, NMS: cpn.py:616-734), so this equals the one-batch result;
+    # up to round 5 these batches fell back to the dense plan (twice the head FLOPs).
+    def _gated_sub_batch(self, inputs):
+        """Sub-batch size if ``inputs`` must be split to keep the score-gated heads, else None."""
+        if self.precision != 'bf16' or not self._gate_requested(True) or inputs.shape[0] < 2:
+            return None
+        eng = self.engine(inputs.device, _forward_path=True)
+        if not eng.sparse:
+            return None
+        nb = eng.max_batch(inputs.shape[0], *inputs.shape[-2:])
+        return nb if nb < inputs.shape[0] else None
+
+    @staticmethod
+    def _slice_batch_kwargs(kwargs, i0, i1, n):
+        """Per-image keyword tensors (``offsets`` [N,2], score bounds [N,1,H,W], the loader's batch keys) follow their images."""
+        return {k: (v[i0:i1] if isinstance(v, torch.Tensor) and v.ndim > 0 and v.shape[0] == n else v) for k, v in kwargs.items()}
+
+    @staticmethod
+    def _merge_outputs(parts, sizes):
+        """Results of consecutive sub-batches (``sizes`` images each) as the result of the whole batch."""
+        if isinstance(parts[0], tuple):  # flat_output: (dict of flat tensors incl. the image index 'b', per-image counts)
+            flat, counts, i0 = {}, [], 0
+            for (f, c), sz in zip(parts, sizes):
+                for k, v in f.items():
+                    flat.setdefault(k, []).append(v + i0 if k == 'b' else v)
+                counts += list(c)
+                i0 += sz
+            return {k: torch.cat(v) for k, v in flat.items()}, counts
+        out = OrderedDict()
+        for k in parts[0]:
+            out[k] = None if parts[0][k] is None else [t for p_ in parts for t in p_[k]]
+        return out
+
     @torch.no_grad()
     def forward(self, inputs, targets=None, nms=True, **kwargs):
 
@@ -622,6 +658,12 @@ class CPN(nn.Module):
             raise NotImplementedError('Loss computation / training is out of scope of the HIP inference engine.')
         if not inputs.is_cuda:
             raise RuntimeError('celldetection_amd.CPN.forward needs GPU inputs (no CPU fallback).')
+        nb = self._gated_sub_batch(inputs)
+        if nb is not None:
+            n = inputs.shape[0]
+            cuts = list(range(0, n, nb)) + [n]
+            parts = [self.forward(inputs[a:b], nms=nms, **self._slice_batch_kwargs(kwargs, a, b, n)) for a, b in zip(cuts, cuts[1:])]
+            return self._merge_outputs(parts, [b - a for a, b in zip(cuts, cuts[1:])])
         original_size = tuple(inputs.shape[-2:])
         scores, locations, refinement, fourier = self.core_forward(inputs, _static_ok=True, _forward_path=True)
         return self.postprocess(scores, locations, refinement, fourier, original_size, nms=nms, flag=self._last_flag,
@@ -635,6 +677,32 @@ class CPN(nn.Module):
         (compaction -> decode -> NMS, incl. its host read-back of the proposal counts) runs on a second stream, so
         the host latency and the small post-processing kernels hide behind the MFMA work.  Results are identical to
         calling ``forward`` per batch."""
+        groups = deque()  # [sub-batch sizes still to come, results so far, sizes] of the caller's items, oldest first
+
+        def expanded():  # the caller's items, those the gated engine must split as consecutive sub-batch items
+            for item in batches:
+                x, kw = item if isinstance(item, (tuple, list)) else (item, {})
+                nb = self._gated_sub_batch(x) if x.is_cuda else None
+                if nb is None:
+                    groups.append([1, [], None])
+                    yield x, kw
+                else:
+                    n = x.shape[0]
+                    cuts = list(range(0, n, nb)) + [n]
+                    groups.append([len(cuts) - 1, [], [b - a for a, b in zip(cuts, cuts[1:])]])
+                    for a, b in zip(cuts, cuts[1:]):
+                        yield x[a:b], self._slice_batch_kwargs(dict(kwargs, **kw), a, b, n)
+
+        for out in self._forward_pipelined(expanded(), nms, _events, kwargs):
+            g = groups[0]
+            g[1].append(out)
+            g[0] -= 1
+            if g[0] == 0:
+                groups.popleft()
+                yield g[1][0] if g[2] is None else self._merge_outputs(g[1], g[2])
+
+    @torch.no_grad()
+    def _forward_pipelined(self, batches, nms, _events, kwargs):
         dev = self.order_weights_device()
         s_conv, s_post = self._streams(dev)
         caller = torch.cuda.current_stream(dev)
