@@ -31,6 +31,7 @@
 //     block-diagonal packed weights.
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 
 #include "cpn_error.h"
@@ -1732,6 +1733,13 @@ static TileChoice choose_tile(const ConvArgs &a) {
     if (BN == 64 && TH == 8 && a.Hout >= 16 && lds_bytes(a, 16, 64) <= LDS_MAX && blocks(16, 64) >= 2 * MIN_BLOCKS &&
         !(e64 && atoi(e64) == 8))
         TH = 16;
+    // CPN_PW_TILE="TH,BN" (read per call): tile of the 1x1 convs -- kernel A/B (r06 experiments #20)
+    if (const char *ep = getenv("CPN_PW_TILE"); ep && a.KH == 1 && a.KW == 1 && a.pad == 0 && a.out_mode == OUT_BF16_NHWC) {
+        int th = 0, bn = 0;
+        if (sscanf(ep, "%d,%d", &th, &bn) == 2 && (th == 4 || th == 8) && (bn == 64 || bn == 128 || bn == 256) && bn <= a.cout_b &&
+            a.Hout >= th && lds_bytes(a, th, bn) <= LDS_MAX)
+            return TileChoice{th, bn};
+    }
     return TileChoice{TH, BN};
 }
 
