@@ -1,5 +1,6 @@
 import os, sys, time, torch
-sys.path.insert(0, os.path.join(os.environ.get('GRAFT_REPO_ROOT', '.'), 'oracle')); sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'oracle')); sys.path.insert(0, ROOT)
 import cpn_oracle as orc
 from bench import build_model, _cpu_quota
 print('quota', _cpu_quota(), 'cpu_count', os.cpu_count())

@@ -3,7 +3,7 @@ against the reference's fp32 maps and the IoU > 0.5 match rate of the proposals 
 Writes tests/golden/bf16_measured.json (run through gpurun: into gpurun_out/, then copy); the GPU tests gate on
 2 x the measured error and measured - 0.03 match rate (tests/model_specs.py bf16_bounds) -- VERDICT r5 item 3.
 
-    python tools/measure_bf16_parity.py [out.json]
+    python tests/measure_bf16_parity.py [out.json]
 """
 import json
 import os

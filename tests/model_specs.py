@@ -150,7 +150,7 @@ _BF16 = None
 
 def bf16_bounds(name):
     """Gates of the bf16 product kernels for fixture ``name`` -> (dict(map -> relative-L2 bound), IoU-match-rate bound): 2 x the error
-    and the match rate - 0.03 measured on an MI355X by tools/measure_bf16_parity.py (tests/golden/bf16_measured.json).  A fixture
+    and the match rate - 0.03 measured on an MI355X by tests/measure_bf16_parity.py (tests/golden/bf16_measured.json).  A fixture
     without an entry fails: measure it first (a loose default would let a kernel regression that doubles the bf16 error pass --
     VERDICT r5 weak 1)."""
     global _BF16
@@ -158,6 +158,6 @@ def bf16_bounds(name):
         import json
         with open(os.path.join(G, 'bf16_measured.json')) as f:
             _BF16 = json.load(f)['fixtures']
-    assert name in _BF16, f'no measured bf16 parity for {name}: run tools/measure_bf16_parity.py on the GPU box'
+    assert name in _BF16, f'no measured bf16 parity for {name}: run tests/measure_bf16_parity.py on the GPU box'
     m = _BF16[name]
     return {k: max(2. * v, 2e-3) for k, v in m['rel'].items()}, m['match'] - .03
