@@ -84,9 +84,8 @@ def check(name, cfg):
     return None
 
 
-def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+def run(cases=200, seed=0):
+    rng = random.Random(seed)
     failed, errors, kinds = 0, 0, {}
     for i in range(cases):
         kind, cfg = sample(rng)
@@ -101,8 +100,8 @@ def main():
             failed += 1
             print(f'[{i}] {kind} FAILED {msg}  {cfg}', flush=True)
     print(f'fuzz_conv: {cases} cases {kinds}, {failed} failed, {errors} rejected')
-    sys.exit(1 if failed else 0)
+    return failed
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(1 if run(*(int(a) for a in sys.argv[1:3])) else 0)

@@ -32,9 +32,8 @@ FAMILIES = {
 NAMES = ('scores', 'locations', 'refinement', 'fourier')
 
 
-def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-    rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+def run(cases=40, seed=0):
+    rng = random.Random(seed)
     dev = torch.device('cuda:0')
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     failed = 0
@@ -96,8 +95,8 @@ def main():
             failed += 1
             print(tag, f'ERROR {type(e).__name__}: {str(e)[:300]}', flush=True)
     print('fuzz_model:', cases, 'cases,', failed, 'failed; worst rel L2', {f'{k[0]}.{k[1]}': f'{v:.2e}' for k, v in sorted(worst.items())})
-    sys.exit(1 if failed else 0)
+    return failed
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(1 if run(*(int(a) for a in sys.argv[1:3])) else 0)

@@ -21,9 +21,8 @@ from celldetection_amd import inference  # noqa: E402
 from celldetection_amd.synth import calibrate_heads, synth_state_dict  # noqa: E402
 
 
-def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-    rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+def run(cases=30, seed=0):
+    rng = random.Random(seed)
     dev = torch.device('cuda:0')
     model = cda.models.CpnU22(3, score_thresh=.6, backbone_kwargs={'backbone_kwargs': {'base_channels': 8}})
     sd = synth_state_dict(model.state_dict(), seed=3)
@@ -95,8 +94,8 @@ def main():
             failed += 1
             print(tag, f'ERROR {type(e).__name__}: {str(e)[:300]}', flush=True)
     print('fuzz_tiled:', cases, 'cases,', failed, 'failed')
-    sys.exit(1 if failed else 0)
+    return failed
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(1 if run(*(int(a) for a in sys.argv[1:3])) else 0)
