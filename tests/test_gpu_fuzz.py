@@ -1,4 +1,4 @@
-"""A slice of the seeded fuzzers (tests/fuzz_conv.py, fuzz_model.py, fuzz_tiled.py; profiles/r06_fuzz.txt holds the long runs) in the
+"""A slice of the seeded fuzzers (tests/fuzz_conv.py, fuzz_model.py, fuzz_tiled.py, fuzz_post.py; profiles/r06_fuzz.txt holds the long runs) in the
 GPU suite: random single convs against the fp32 conv of the same operands, random model family / width / batch / input size through
 the fp32 verification path (== oracle head maps and post-processing) and the bf16 path, random slides / tilings / masks through the
 slide loop against the oracle's stitching of the same per-tile detections (exact).  Seeds differ from the recorded long runs."""
@@ -27,3 +27,8 @@ def test_fuzz_models_and_input_sizes():
 def test_fuzz_slide_loop():
     import fuzz_tiled
     assert fuzz_tiled.run(40, 103) == 0
+
+
+def test_fuzz_exact_post_processing_kernels():
+    import fuzz_post
+    assert fuzz_post.run(40, 104) == 0
