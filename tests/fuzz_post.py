@@ -1,7 +1,7 @@
 """Seeded random inputs through the integer / index / fp32-exact kernels behind the conv graph against the oracle -- bit for bit:
 Fourier -> contour decode (any order / sample count), local refinement (out-of-range and x.5 coordinates, buckets), box NMS (ties,
 duplicates, degenerate and touching boxes, thresholds incl. 0; the segmented bit-mask kernel and the spatially binned slide-scale
-kernel), box voting, border rules.
+kernel), box voting, border rules, label rasterisation (contours2labels), percentile normalisation.
 
     python tests/fuzz_post.py [cases] [seed]
 """
@@ -122,6 +122,40 @@ def run(cases=60, seed=0):
         exp = exp if exp.dtype == bool else np.isin(np.arange(P), exp)
         if not np.array_equal(got, exp):
             report(i, f'border rule P={P} size={size} pad={pad} sides={sides} offsets={off}', f'{got.sum()} vs {exp.sum()} kept')
+        # ---- label rasterisation (contours2labels, data/cpn.py:292-358) and percentile normalisation (data/misc.py:156-161)
+        if i % 3 == 0:
+            import labels_oracle as lo
+            import preprocess_oracle as po
+            import celldetection_amd as cda
+            from celldetection_amd.preprocess import normalize_percentile
+            nrng = np.random.default_rng(seed * 7919 + i)
+            k, S = rng.choice([1, 12, 90, 250]), rng.choice([6, 16, 33])
+            size = (rng.randrange(16, 150), rng.randrange(16, 190))
+            t = np.linspace(0, 2 * np.pi, S, endpoint=False)
+            ctr = nrng.uniform([-3, -3], [size[1] + 3, size[0] + 3], (k, 1, 2))
+            rad = nrng.uniform(1.5, rng.choice([5., 14.]), (k, 1, 1)) * nrng.uniform(.6, 1.4, (k, S, 1))
+            con = (ctr + rad * np.stack((np.cos(t), np.sin(t)), -1)[None]).astype(np.float32)
+            con[::5] = np.round(con[::5]) + .5
+            kw = rng.choice([{}, dict(gap=0), dict(gap=2, initial_depth=2)])
+            exp = lo.contours2labels(con, size, **kw)
+            got = cda.contours2labels(torch.as_tensor(con).to(dev), size, **kw).cpu().numpy()
+            if got.shape != exp.shape or not np.array_equal(got, exp):
+                report(i, f'contours2labels k={k} S={S} size={size} {kw}', f'shape {got.shape} vs {exp.shape}' if got.shape != exp.shape
+                       else f'{(got != exp).sum()} pixels differ')
+            dt = rng.choice(['uint8', 'uint16', 'float32'])
+            shp = (rng.choice([1, 3]), rng.randrange(20, 200), rng.randrange(20, 230))
+            if dt == 'uint8':
+                x = nrng.integers(0, rng.choice([40, 256]), shp).astype(np.uint8)
+            elif dt == 'uint16':
+                x = nrng.gamma(2., rng.choice([60., 900.]), shp).clip(0, 65535).astype(np.uint16)
+            else:
+                x = (nrng.standard_normal(shp) * rng.choice([.1, 50.])).astype(np.float32)
+            pct = rng.choice([99.9, 99., (1., 97.5), (0.5, 99.5)])
+            tx = torch.as_tensor(x.astype(np.int32)).to(torch.uint16) if dt == 'uint16' else torch.as_tensor(x)
+            got = normalize_percentile(tx.to(dev), pct).cpu().numpy()
+            exp = po.normalize_percentile(x, pct)
+            if got.shape != exp.shape or not np.array_equal(got, exp):
+                report(i, f'normalize_percentile {dt} {shp} pct={pct}', f'{(got != exp).sum()} values differ' if got.shape == exp.shape else 'shape')
     print('fuzz_post:', cases, 'cases,', failed, 'failed')
     return failed
 
