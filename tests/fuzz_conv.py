@@ -84,6 +84,50 @@ def check(name, cfg):
     return None
 
 
+def sample_fp8(rng):
+    """Shapes for the e4m3 kernel (cpn_conv2d_fp8): the checker is tests/test_gpu_kernels.py::test_conv_fp8_vs_dequantised_reference
+    (fp32 conv on the same e4m3-quantised operands)."""
+    k = rng.choice([1, 3, 3, 5, 7])
+    cfg = dict(k=k, n=rng.choice([1, 2, 3]), h=rng.choice([16, 24, 32, 40, 64]), w=rng.choice([32, 48, 64, 96]),
+               cin=rng.choice([3, 24, 64, 128, 192, 256]), cout=rng.choice([40, 64, 128, 256]))
+    kind = rng.choice(['plain', 'plain', 'res', 'stride2', 'concat', 'grouped', 'f32out', 'fused'])
+    if kind == 'res':
+        cfg['res'] = True
+    elif kind == 'stride2':
+        cfg['stride'] = 2
+        cfg['k'] = rng.choice([1, 3, 7])
+    elif kind == 'concat':
+        cfg.update(cin=rng.choice([64, 128]), cin1=rng.choice([64, 128]), up1=rng.random() < .6, k=3)
+        cfg['h'] += cfg['h'] % 2
+    elif kind == 'grouped':
+        g_ = rng.choice([4, 32])
+        cfg.update(k=3, groups=g_, cin=g_ * 8, cout=g_ * 8)
+    elif kind == 'f32out':
+        cfg.update(k=1, cout=rng.choice([1, 2, 20]), bn=False, act='none', out_f32=True)
+    elif kind == 'fused':
+        cfg.update(k=rng.choice([3, 7]), cout=rng.choice([64, 256]), fuse_cout=rng.choice([1, 2, 20]), fuse_act='none')
+    return kind, cfg
+
+
+def run_fp8(cases=100, seed=0):
+    import test_gpu_kernels as tk
+    rng = random.Random(seed)
+    dev = torch.device('cuda:0')
+    failed, kinds = 0, {}
+    for i in range(cases):
+        kind, cfg = sample_fp8(rng)
+        kinds[kind] = kinds.get(kind, 0) + 1
+        tk.FP8_CASES['_fuzz'] = cfg
+        try:
+            tk.test_conv_fp8_vs_dequantised_reference(dev, '_fuzz')
+        except Exception as e:
+            failed += 1
+            print(f'[{i}] fp8 {kind} FAILED {type(e).__name__}: {str(e)[:200]}  {cfg}', flush=True)
+    tk.FP8_CASES.pop('_fuzz', None)
+    print(f'fuzz_conv (e4m3): {cases} cases {kinds}, {failed} failed')
+    return failed
+
+
 def run(cases=200, seed=0):
     rng = random.Random(seed)
     failed, errors, kinds = 0, 0, {}
@@ -104,4 +148,5 @@ def run(cases=200, seed=0):
 
 
 if __name__ == '__main__':
-    sys.exit(1 if run(*(int(a) for a in sys.argv[1:3])) else 0)
+    a_ = [int(a) for a in sys.argv[1:3]]
+    sys.exit(1 if run(*a_) + run_fp8(max(20, (a_[0] if a_ else 200) // 3), a_[1] if len(a_) > 1 else 0) else 0)

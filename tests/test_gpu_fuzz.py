@@ -17,6 +17,7 @@ def _gpu():
 def test_fuzz_single_convs():
     import fuzz_conv
     assert fuzz_conv.run(80, 101) == 0
+    assert fuzz_conv.run_fp8(30, 105) == 0
 
 
 def test_fuzz_models_and_input_sizes():
