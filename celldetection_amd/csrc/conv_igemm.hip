@@ -1236,6 +1236,12 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
 #undef ISSUE_AT_TRANSITION
 #undef ITEM_PADDR
 
+#if defined(CPN_EXP_CLOCK) && CPN_EXP_CLOCK == 1
+    unsigned long long clk_epi[3] = {0, 0, 0};
+#define CPN_EPI_STAMP(I) clk_epi[I] = __builtin_readcyclecounter()
+#else
+#define CPN_EPI_STAMP(I)
+#endif
 #ifdef CPN_EXP_CLOCK
     const unsigned long long clk_loop_end = __builtin_readcyclecounter();
     unsigned long long clk_print = 0;  // (the printf below is a host call: its cycles are taken out of the epilogue phase)
@@ -1453,7 +1459,40 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
         constexpr int RPW = TH / C::NWAVES;                // pixel rows per wave in the second GEMM
         const bool hscat = a.phase == 3;                   // bilinear phases: shared bias / multipliers, scattered planes
         const int gb = hscat ? 0 : g * cout_b;
+        // Per-channel bias (and e4m3 dequantisation multiplier) of the block's BN channels through an LDS table behind the staging
+        // area: ONE coalesced global load per thread.  (Up to round 6 every (fragment, channel quad) of a lane loaded its four biases
+        // / multipliers with single-dword global loads behind null-pointer branches and waited for them: 32 exposed L2 round trips
+        // per lane, ~25 k of the 26 - 32 k cycles of this epilogue = 5 % of a 7x7 head workgroup in bf16, 11 - 19 % in e4m3 --
+        // profiles/r06_phases_in_graph.txt, r06_phases_configs4_fp8.txt.)  Same expression per element: bit-identical.
+        // The tail's weights W2[32][BN] (bf16, 16 KiB at BN = 256) take the same route into an LDS tile behind the table (rows XOR-
+        // swizzled like the staging area): every wave needs all of W2 as the A operand of its pixel row, and eight waves reading it
+        // from L2 -- five loads at a time inside the dependent MFMA chain -- were 9 k cycles of the epilogue; from LDS the chain runs
+        // at MFMA latency.
+        float *const ep_tab = (float *) (smem + (size_t) TH * 32 * BN * 2);
+        unsigned char *const ep_w2 = (unsigned char *) (ep_tab + 2 * BN);
+        constexpr int W2CH = 32 * SPR;                               // 16-byte chunks of W2
+        constexpr int W2PT = (W2CH + C::THREADS - 1) / C::THREADS;   // ... per thread
+        float ep_b = 0.f, ep_m = 1.f;
+        u32x4 w2c[W2PT];
+        if (tid < BN) {
+            if (a.bias) ep_b = a.bias[gb + tid];
+            if (CPN_FP8 && a.mult) ep_m = a.mult[gb + tid];
+        }
+#pragma unroll
+        for (int i = 0; i < W2PT; ++i)
+            if (tid + i * C::THREADS < W2CH) w2c[i] = *(const u32x4 *) ((const unsigned char *) a.fuse_w + (size_t) (tid + i * C::THREADS) * 16);
         __syncthreads();
+        if (tid < BN) {
+            ep_tab[tid] = ep_b;
+            ep_tab[BN + tid] = ep_m;
+        }
+#pragma unroll
+        for (int i = 0; i < W2PT; ++i) {
+            const int c = tid + i * C::THREADS, row = c / SPR, slot = c % SPR;
+            if (c < W2CH) *(u32x4 *) (ep_w2 + row * (BN * 2) + ((slot ^ (row & (SW - 1))) << 4)) = w2c[i];
+        }
+        __syncthreads();
+        CPN_EPI_STAMP(0);
 #pragma unroll
         for (int f = 0; f < WM; ++f) {
             const int p = (wave_m * WM + f) * 32 + l31;
@@ -1463,11 +1502,20 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int cb = wave_n * WN * 32 + j * 32 + 8 * q + 4 * lhi;  // channel within the block (n0 == 0)
+                    const float4 b4 = *(const float4 *) (ep_tab + cb);
+                    const float bq[4] = {b4.x, b4.y, b4.z, b4.w};
+#if CPN_FP8
+                    const float4 m4 = *(const float4 *) (ep_tab + BN + cb);
+                    const float mq[4] = {m4.x, m4.y, m4.z, m4.w};
+#endif
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[j][f][q * 4 + e] * (CPN_FP8 && a.mult ? a.mult[gb + cb + e] : 1.f) +
-                               (a.bias ? a.bias[gb + cb + e] : 0.f);
+#if CPN_FP8
+                        v[e] = acc[j][f][q * 4 + e] * mq[e] + bq[e];
+#else
+                        v[e] = acc[j][f][q * 4 + e] + bq[e];
+#endif
                         if (a.act == ACT_RELU) v[e] = fmaxf(v[e], 0.f);
                     }
                     u32x2 o;
@@ -1478,21 +1526,29 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
                 }
         }
         __syncthreads();
-        const unsigned char *w2 = (const unsigned char *) a.fuse_w + l31 * (BN * 2) + lhi * 16;
+        CPN_EPI_STAMP(1);
+        const unsigned char *w2 = ep_w2 + l31 * (BN * 2);
+        const int w2x = l31 & (SW - 1);
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             const int row = wave * RPW + r;
             const int p = row * 32 + l31;
             const int fp = (p >> PSH) & (SW - 1);
             f32x16 acc2;
+            float fb2[16];  // the tail's biases of this lane's 16 output channels: in flight behind the MFMA chain below
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
+            for (int e = 0; e < 16; ++e) {
+                acc2[e] = 0.f;
+                const int c2 = (e & 3) + 8 * (e >> 2) + 4 * lhi;
+                fb2[e] = (a.fuse_b && c2 < a.fuse_cout) ? a.fuse_b[c2] : 0.f;
+            }
 #pragma unroll
             for (int ks = 0; ks < BN / 16; ++ks) {
-                const bf16x8 wv = *(const bf16x8 *) (w2 + ks * 32);
                 const bf16x8 xv = *(const bf16x8 *) (smem + p * (BN * 2) + (((ks * 2 + lhi) ^ fp) << 4));
+                const bf16x8 wv = *(const bf16x8 *) (w2 + (((ks * 2 + lhi) ^ w2x) << 4));
                 acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, xv, acc2, 0, 0, 0);
             }
+            CPN_EPI_STAMP(2);
             const int oy = oy0 + row, ox = wrap ? (l31 < WRAP_HALF ? a.Wout - WRAP_HALF + l31 : l31 - WRAP_HALF) : ox0 + l31;
             if (oy >= a.Hout || ox >= a.Wout) continue;
             if (a.region) {  // 1: only inside the box [m, H - m) x [m, W - m); 2: only outside it
@@ -1507,7 +1563,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
             for (int e = 0; e < 16; ++e) {
                 const int c2 = (e & 3) + 8 * (e >> 2) + 4 * lhi;
                 if (c2 >= a.fuse_cout) continue;
-                float x = acc2[e] + (a.fuse_b ? a.fuse_b[c2] : 0.f);
+                float x = acc2[e] + fb2[e];
                 if (a.fuse_act == ACT_RELU) x = fmaxf(x, 0.f);
                 else if (a.fuse_act == ACT_SIGMOID) x = 1.f / (1.f + expf(-x));
                 else if (a.fuse_act == ACT_TANH_SCALED) x = tanhf(x) * a.fuse_scale;
@@ -1546,8 +1602,9 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
 #if defined(CPN_EXP_CLOCK) && CPN_EXP_CLOCK == 1  // phases of the probed workgroup: set-up (coordinates, tables), prologue + main loop, epilogue
     __syncthreads();
     if (tid == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && blockIdx.z == 0)
-        printf("PHASES out_mode %d setup %llu loop %llu epilogue %llu cycles\n", (int) a.out_mode, clk_c0 - clk_entry, clk_loop_end - clk_c0,
-               (unsigned long long) __builtin_readcyclecounter() - clk_loop_end - clk_print);
+        printf("PHASES out_mode %d setup %llu loop %llu epilogue %llu cycles (fused head: table %llu, stage 1 %llu, tail GEMM %llu)\n", (int) a.out_mode,
+               clk_c0 - clk_entry, clk_loop_end - clk_c0, (unsigned long long) __builtin_readcyclecounter() - clk_loop_end - clk_print,
+               clk_epi[0] ? clk_epi[0] - clk_loop_end - clk_print : 0ull, clk_epi[1] - clk_epi[0], clk_epi[2] - clk_epi[1]);
 #endif
 }
 
@@ -1664,7 +1721,7 @@ template <int TH, int BN, int WM, int WN, int MODE>
 static int launch_mode(const ConvArgs &a, hipStream_t stream) {
     using C = Cfg<TH, BN, WM, WN>;
     size_t lds = std::max(lds_bytes(a, TH, BN), staging_bytes(C::NWAVES, WN));
-    if (a.out_mode == OUT_FUSED_HEAD) lds = std::max(lds, (size_t) TH * 32 * BN * 2);
+    if (a.out_mode == OUT_FUSED_HEAD) lds = std::max(lds, (size_t) TH * 32 * BN * 2 + 2 * (size_t) BN * 4 + (size_t) 32 * BN * 2);  // staging + bias / multiplier table + W2
     // the dynamic-LDS limit is a per-device function attribute: remember it per device ordinal (atomic flags: plans of
     // different devices / host threads may launch the same instantiation concurrently)
     static std::atomic<bool> attr_set[MAX_DEVICES];
