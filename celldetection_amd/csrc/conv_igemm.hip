@@ -1561,6 +1561,7 @@ __global__ __launch_bounds__((64 * (TH / WM) * (BN / (32 * WN))), ((MODE == MODE
             const int py_ = hscat ? 2 * oy + (g >> 1) : oy, px_ = hscat ? 2 * ox + (g & 1) : ox;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
+                if (8 * (e >> 2) >= a.fuse_cout) continue;  // (wave-uniform: a 1- or 2-channel head leaves three of the four quads out)
                 const int c2 = (e & 3) + 8 * (e >> 2) + 4 * lhi;
                 if (c2 >= a.fuse_cout) continue;
                 float x = acc2[e] + fb2[e];
