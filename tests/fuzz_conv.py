@@ -78,7 +78,9 @@ def check(name, cfg):
     scale = ref.abs().max().item() + 1e-6
     tol = (2e-3 if f32 else 1e-2) * max(scale, 1.)
     bad = (err > tol + (0 if f32 else 8e-3) * ref.abs()).sum().item()
-    allowed = max(1, int(1e-4 * err.numel())) if cfg.get('fuse_cout') else 0  # (a rounding-boundary flip of the bf16 intermediate)
+    # fused tails round the hidden activation to bf16: a value on a rounding boundary may round the other way than in the reference,
+    # and ONE flipped hidden unit moves all fuse_cout outputs of its pixel (tanh_scaled x 3 on top)
+    allowed = max(int(cfg['fuse_cout']), int(2e-4 * err.numel())) if cfg.get('fuse_cout') else 0
     if bad > allowed or (allowed and err.max().item() >= 5e-2 * max(scale, 1.)):
         return f'{bad} / {err.numel()} elements off; max abs err {err.max().item():.4e}, ref max {scale:.3e}'
     return None
